@@ -1,0 +1,510 @@
+"""CPU restatement (torch fp32, ATen CPU kernels) of the reference's YOLO forward path.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Every function cites the reference
+file:line it follows (paths relative to /root/reference/ultralytics).
+
+The graph is described by our own layer tables (GRAPHS below); widths/repeats are scaled exactly as
+nn/tasks.py:parse_model does (:940-1105).  Parameters are addressed by the reference's own
+state_dict names ("model.<i>.<...>") so a reference state_dict drops in unchanged.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3  # utils/torch_utils.py:424 (initialize_weights sets BatchNorm2d.eps = 1e-3)
+
+# --------------------------------------------------------------------------------------------
+# Graph tables.  (from, repeats, type, args) -- same information as cfg/models/11/yolo11-seg.yaml:15-47
+# (stock YOLO11 backbone+neck) and cfg/models/v8/yolov8-seg.yaml:15-46, written in our own notation.
+# HEAD is appended by build_model (Detect or Segment).
+# --------------------------------------------------------------------------------------------
+SCALES = {
+    "yolo11": {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.00, 512),
+               "l": (1.00, 1.00, 512), "x": (1.00, 1.50, 512)},
+    "yolov8": {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768),
+               "l": (1.00, 1.00, 512), "x": (1.00, 1.25, 512)},
+}
+GRAPHS = {
+    "yolo11": [
+        (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "Conv", (128, 3, 2)), (-1, 2, "C3k2", (256, False, 0.25)),
+        (-1, 1, "Conv", (256, 3, 2)), (-1, 2, "C3k2", (512, False, 0.25)), (-1, 1, "Conv", (512, 3, 2)),
+        (-1, 2, "C3k2", (512, True)), (-1, 1, "Conv", (1024, 3, 2)), (-1, 2, "C3k2", (1024, True)),
+        (-1, 1, "SPPF", (1024, 5)), (-1, 2, "C2PSA", (1024,)),
+        (-1, 1, "Upsample", ()), ((-1, 6), 1, "Concat", ()), (-1, 2, "C3k2", (512, False)),
+        (-1, 1, "Upsample", ()), ((-1, 4), 1, "Concat", ()), (-1, 2, "C3k2", (256, False)),
+        (-1, 1, "Conv", (256, 3, 2)), ((-1, 13), 1, "Concat", ()), (-1, 2, "C3k2", (512, False)),
+        (-1, 1, "Conv", (512, 3, 2)), ((-1, 10), 1, "Concat", ()), (-1, 2, "C3k2", (1024, True)),
+    ],
+    "yolov8": [
+        (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "Conv", (128, 3, 2)), (-1, 3, "C2f", (128, True)),
+        (-1, 1, "Conv", (256, 3, 2)), (-1, 6, "C2f", (256, True)), (-1, 1, "Conv", (512, 3, 2)),
+        (-1, 6, "C2f", (512, True)), (-1, 1, "Conv", (1024, 3, 2)), (-1, 3, "C2f", (1024, True)),
+        (-1, 1, "SPPF", (1024, 5)),
+        (-1, 1, "Upsample", ()), ((-1, 6), 1, "Concat", ()), (-1, 3, "C2f", (512,)),
+        (-1, 1, "Upsample", ()), ((-1, 4), 1, "Concat", ()), (-1, 3, "C2f", (256,)),
+        (-1, 1, "Conv", (256, 3, 2)), ((-1, 12), 1, "Concat", ()), (-1, 3, "C2f", (512,)),
+        (-1, 1, "Conv", (512, 3, 2)), ((-1, 9), 1, "Concat", ()), (-1, 3, "C2f", (1024,)),
+    ],
+}
+HEAD_FROM = {"yolo11": (16, 19, 22), "yolov8": (15, 18, 21)}
+
+
+def make_divisible(x, d):  # utils/ops.py:130-143
+    return math.ceil(x / d) * d
+
+
+def autopad(k, p=None):  # nn/modules/conv.py:29-35 (d == 1 on this path)
+    return k // 2 if p is None else p
+
+
+# --------------------------------------------------------------------------------------------
+# Module restatements.  Each holds its parameter-name prefix; forward(P, x) pulls tensors from P.
+# --------------------------------------------------------------------------------------------
+class Conv:
+    """conv -> BN -> SiLU; after fold: SiLU(conv(x) + b).  nn/modules/conv.py:133-151."""
+
+    def __init__(self, name, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        self.name, self.c1, self.c2, self.k, self.s, self.g, self.act = name, c1, c2, k, s, g, act
+        self.p = autopad(k, p)
+
+    def specs(self):
+        n = self.name
+        yield (n + ".conv.weight", (self.c2, self.c1 // self.g, self.k, self.k))
+        for suf in ("weight", "bias", "running_mean", "running_var"):
+            yield (n + ".bn." + suf, (self.c2,))
+
+    def folded(self, P):
+        """utils/torch_utils.py:242-269 fuse_conv_and_bn (conv has no bias here)."""
+        n = self.name
+        if n + ".conv.bias" in P and n + ".bn.weight" not in P:  # already-fused state_dict
+            return P[n + ".conv.weight"], P[n + ".conv.bias"]
+        w = P[n + ".conv.weight"]
+        bw, bb, mu, var = (P[n + ".bn." + s] for s in ("weight", "bias", "running_mean", "running_var"))
+        scale = bw.div(torch.sqrt(BN_EPS + var))
+        wf = torch.mm(torch.diag(scale), w.view(self.c2, -1)).view(w.shape)
+        bf = bb - bw.mul(mu).div(torch.sqrt(var + BN_EPS))
+        return wf, bf
+
+    def __call__(self, P, x):
+        w, b = self.folded(P)
+        y = F.conv2d(x, w, b, self.s, self.p, 1, self.g)
+        return F.silu(y) if self.act else y
+
+
+def DWConv(name, c1, c2, k=1, s=1, act=True):  # nn/modules/conv.py:224-229
+    return Conv(name, c1, c2, k, s, g=math.gcd(c1, c2), act=act)
+
+
+class PlainConv:
+    """bare nn.Conv2d with bias (Detect/Segment output convs, head.py:41-43)."""
+
+    def __init__(self, name, c1, c2, k=1):
+        self.name, self.c1, self.c2, self.k = name, c1, c2, k
+
+    def specs(self):
+        yield (self.name + ".weight", (self.c2, self.c1, self.k, self.k))
+        yield (self.name + ".bias", (self.c2,))
+
+    def __call__(self, P, x):
+        return F.conv2d(x, P[self.name + ".weight"], P[self.name + ".bias"])
+
+
+class Seq:
+    def __init__(self, mods):
+        self.mods = list(mods)
+
+    def specs(self):
+        for m in self.mods:
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        for m in self.mods:
+            x = m(P, x)
+        return x
+
+
+class Bottleneck:
+    """nn/modules/block.py:3405-3419."""
+
+    def __init__(self, name, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        c_ = int(c2 * e)
+        self.cv1 = Conv(name + ".cv1", c1, c_, k[0], 1)
+        self.cv2 = Conv(name + ".cv2", c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def specs(self):
+        yield from self.cv1.specs()
+        yield from self.cv2.specs()
+
+    def __call__(self, P, x):
+        y = self.cv2(P, self.cv1(P, x))
+        return x + y if self.add else y
+
+
+class C3k:
+    """C3 with k=3 Bottlenecks, e=1.0.  block.py:3320-3334 (C3) + :3807-3815 (C3k)."""
+
+    def __init__(self, name, c1, c2, n=1, shortcut=True, g=1, e=0.5, k=3):
+        c_ = int(c2 * e)
+        self.cv1 = Conv(name + ".cv1", c1, c_, 1, 1)
+        self.cv2 = Conv(name + ".cv2", c1, c_, 1, 1)
+        self.cv3 = Conv(name + ".cv3", 2 * c_, c2, 1)
+        self.m = Seq(Bottleneck(f"{name}.m.{i}", c_, c_, shortcut, g, k=(k, k), e=1.0) for i in range(n))
+
+    def specs(self):
+        for m in (self.cv1, self.cv2, self.cv3, self.m):
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        return self.cv3(P, torch.cat((self.m(P, self.cv1(P, x)), self.cv2(P, x)), 1))
+
+
+class C2f:
+    """block.py:3295-3317.  C3k2 (block.py:3796-3804 == :4148-4156) swaps the inner module list."""
+
+    def __init__(self, name, c1, c2, n=1, shortcut=False, g=1, e=0.5, c3k=None):
+        self.c = int(c2 * e)
+        self.cv1 = Conv(name + ".cv1", c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv(name + ".cv2", (2 + n) * self.c, c2, 1)
+        if c3k is None:  # plain C2f
+            self.m = [Bottleneck(f"{name}.m.{i}", self.c, self.c, shortcut, g, k=(3, 3), e=1.0) for i in range(n)]
+        elif c3k:
+            self.m = [C3k(f"{name}.m.{i}", self.c, self.c, 2, shortcut, g) for i in range(n)]
+        else:
+            self.m = [Bottleneck(f"{name}.m.{i}", self.c, self.c, shortcut, g) for i in range(n)]
+
+    def specs(self):
+        yield from self.cv1.specs()
+        yield from self.cv2.specs()
+        for m in self.m:
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        y = list(self.cv1(P, x).chunk(2, 1))
+        y.extend(m(P, y[-1]) for m in self.m)
+        return self.cv2(P, torch.cat(y, 1))
+
+
+def C3k2(name, c1, c2, n=1, c3k=False, e=0.5, g=1, shortcut=True):
+    return C2f(name, c1, c2, n, shortcut, g, e, c3k=bool(c3k))
+
+
+class SPPF:
+    """block.py:3114-3149."""
+
+    def __init__(self, name, c1, c2, k=5):
+        c_ = c1 // 2
+        self.cv1 = Conv(name + ".cv1", c1, c_, 1, 1)
+        self.cv2 = Conv(name + ".cv2", c_ * 4, c2, 1, 1)
+        self.k = k
+
+    def specs(self):
+        yield from self.cv1.specs()
+        yield from self.cv2.specs()
+
+    def __call__(self, P, x):
+        y = [self.cv1(P, x)]
+        y.extend(F.max_pool2d(y[-1], self.k, 1, self.k // 2) for _ in range(3))
+        return self.cv2(P, torch.cat(y, 1))
+
+
+class Attention:
+    """block.py:4235-4288."""
+
+    def __init__(self, name, dim, num_heads=8, attn_ratio=0.5):
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.key_dim = int(self.head_dim * attn_ratio)
+        self.scale = self.key_dim ** -0.5
+        h = dim + self.key_dim * num_heads * 2
+        self.qkv = Conv(name + ".qkv", dim, h, 1, act=False)
+        self.proj = Conv(name + ".proj", dim, dim, 1, act=False)
+        self.pe = Conv(name + ".pe", dim, dim, 3, 1, g=dim, act=False)
+
+    def specs(self):
+        for m in (self.qkv, self.proj, self.pe):
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        B, C, H, W = x.shape
+        N = H * W
+        qkv = self.qkv(P, x)
+        q, k, v = qkv.view(B, self.num_heads, self.key_dim * 2 + self.head_dim, N).split(
+            [self.key_dim, self.key_dim, self.head_dim], dim=2)
+        attn = (q.transpose(-2, -1) @ k) * self.scale
+        attn = attn.softmax(dim=-1)
+        x = (v @ attn.transpose(-2, -1)).view(B, C, H, W) + self.pe(P, v.reshape(B, C, H, W))
+        return self.proj(P, x)
+
+
+class PSABlock:
+    """block.py:4348-4383."""
+
+    def __init__(self, name, c, attn_ratio=0.5, num_heads=4, shortcut=True):
+        self.attn = Attention(name + ".attn", c, num_heads=num_heads, attn_ratio=attn_ratio)
+        self.ffn = Seq([Conv(name + ".ffn.0", c, c * 2, 1), Conv(name + ".ffn.1", c * 2, c, 1, act=False)])
+        self.add = shortcut
+
+    def specs(self):
+        yield from self.attn.specs()
+        yield from self.ffn.specs()
+
+    def __call__(self, P, x):
+        x = x + self.attn(P, x) if self.add else self.attn(P, x)
+        x = x + self.ffn(P, x) if self.add else self.ffn(P, x)
+        return x
+
+
+class C2PSA:
+    """block.py:4429-4468."""
+
+    def __init__(self, name, c1, c2, n=1, e=0.5):
+        assert c1 == c2
+        self.c = int(c1 * e)
+        self.cv1 = Conv(name + ".cv1", c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv(name + ".cv2", 2 * self.c, c1, 1)
+        self.m = Seq(PSABlock(f"{name}.m.{i}", self.c, attn_ratio=0.5, num_heads=self.c // 64) for i in range(n))
+
+    def specs(self):
+        for m in (self.cv1, self.cv2, self.m):
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        a, b = self.cv1(P, x).split((self.c, self.c), dim=1)
+        b = self.m(P, b)
+        return self.cv2(P, torch.cat((a, b), 1))
+
+
+def make_anchors(feats, strides, offset=0.5):  # utils/tal.py:371-383
+    pts, st = [], []
+    for f, s in zip(feats, strides):
+        h, w = f.shape[2:]
+        sx = torch.arange(w, dtype=f.dtype) + offset
+        sy = torch.arange(h, dtype=f.dtype) + offset
+        sy, sx = torch.meshgrid(sy, sx, indexing="ij")
+        pts.append(torch.stack((sx, sy), -1).view(-1, 2))
+        st.append(torch.full((h * w, 1), float(s), dtype=f.dtype))
+    return torch.cat(pts), torch.cat(st)
+
+
+def dist2bbox(distance, anchor_points, xywh=True, dim=-1):  # utils/tal.py:386-395
+    lt, rb = distance.chunk(2, dim)
+    x1y1 = anchor_points - lt
+    x2y2 = anchor_points + rb
+    if xywh:
+        return torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), dim)
+    return torch.cat((x1y1, x2y2), dim)
+
+
+class Detect:
+    """head.py:21-148 (inference, non-export, non-end2end path)."""
+
+    def __init__(self, name, nc, ch, legacy, strides):
+        self.name, self.nc, self.nl, self.reg_max = name, nc, len(ch), 16
+        self.no = nc + 64
+        self.stride = strides
+        c2, c3 = max(16, ch[0] // 4, 64), max(ch[0], min(nc, 100))
+        self.cv2 = [Seq([Conv(f"{name}.cv2.{i}.0", x, c2, 3), Conv(f"{name}.cv2.{i}.1", c2, c2, 3),
+                         PlainConv(f"{name}.cv2.{i}.2", c2, 64)]) for i, x in enumerate(ch)]
+        if legacy:
+            self.cv3 = [Seq([Conv(f"{name}.cv3.{i}.0", x, c3, 3), Conv(f"{name}.cv3.{i}.1", c3, c3, 3),
+                             PlainConv(f"{name}.cv3.{i}.2", c3, nc)]) for i, x in enumerate(ch)]
+        else:
+            self.cv3 = [Seq([DWConv(f"{name}.cv3.{i}.0.0", x, x, 3), Conv(f"{name}.cv3.{i}.0.1", x, c3, 1),
+                             DWConv(f"{name}.cv3.{i}.1.0", c3, c3, 3), Conv(f"{name}.cv3.{i}.1.1", c3, c3, 1),
+                             PlainConv(f"{name}.cv3.{i}.2", c3, nc)]) for i, x in enumerate(ch)]
+
+    def specs(self):
+        for s in self.cv2:
+            yield from s.specs()
+        for s in self.cv3:
+            yield from s.specs()
+        yield (self.name + ".dfl.conv.weight", (1, 16, 1, 1))
+
+    def raw(self, P, xs):
+        return [torch.cat((self.cv2[i](P, x), self.cv3[i](P, x)), 1) for i, x in enumerate(xs)]
+
+    def decode(self, raw):
+        """head.py:100-131 _inference + block.py:58-77 DFL."""
+        b = raw[0].shape[0]
+        x_cat = torch.cat([xi.view(b, self.no, -1) for xi in raw], 2)
+        anchors, strides = (t.transpose(0, 1) for t in make_anchors(raw, self.stride, 0.5))
+        box, cls = x_cat.split((64, self.nc), 1)
+        a = box.shape[-1]
+        proj = torch.arange(16, dtype=box.dtype).view(1, 16, 1, 1)
+        dfl = F.conv2d(box.view(b, 4, 16, a).transpose(2, 1).softmax(1), proj).view(b, 4, a)
+        dbox = dist2bbox(dfl, anchors.unsqueeze(0), xywh=True, dim=1) * strides
+        return torch.cat((dbox, cls.sigmoid()), 1)
+
+    def __call__(self, P, xs):
+        raw = self.raw(P, xs)
+        return self.decode(raw), raw
+
+
+class Proto:
+    """block.py:80-97."""
+
+    def __init__(self, name, c1, c_=256, c2=32):
+        self.name = name
+        self.cv1 = Conv(name + ".cv1", c1, c_, 3)
+        self.cv2 = Conv(name + ".cv2", c_, c_, 3)
+        self.cv3 = Conv(name + ".cv3", c_, c2, 1)
+        self.c_ = c_
+
+    def specs(self):
+        yield from self.cv1.specs()
+        yield (self.name + ".upsample.weight", (self.c_, self.c_, 2, 2))
+        yield (self.name + ".upsample.bias", (self.c_,))
+        yield from self.cv2.specs()
+        yield from self.cv3.specs()
+
+    def __call__(self, P, x):
+        x = self.cv1(P, x)
+        x = F.conv_transpose2d(x, P[self.name + ".upsample.weight"], P[self.name + ".upsample.bias"], 2, 0)
+        return self.cv3(P, self.cv2(P, x))
+
+
+class Segment(Detect):
+    """head.py:175-197."""
+
+    def __init__(self, name, nc, nm, npr, ch, legacy, strides):
+        super().__init__(name, nc, ch, legacy, strides)
+        self.nm = nm
+        self.proto = Proto(name + ".proto", ch[0], npr, nm)
+        c4 = max(ch[0] // 4, nm)
+        self.cv4 = [Seq([Conv(f"{name}.cv4.{i}.0", x, c4, 3), Conv(f"{name}.cv4.{i}.1", c4, c4, 3),
+                         PlainConv(f"{name}.cv4.{i}.2", c4, nm)]) for i, x in enumerate(ch)]
+
+    def specs(self):
+        yield from Detect.specs(self)
+        yield from self.proto.specs()
+        for s in self.cv4:
+            yield from s.specs()
+
+    def __call__(self, P, xs):
+        p = self.proto(P, xs[0])
+        bs = p.shape[0]
+        mc = torch.cat([self.cv4[i](P, x).view(bs, self.nm, -1) for i, x in enumerate(xs)], 2)
+        y, raw = Detect.__call__(self, P, xs)
+        return torch.cat([y, mc], 1), (raw, mc, p)
+
+
+# --------------------------------------------------------------------------------------------
+# Model: graph walk as nn/tasks.py:138-165 (_predict_once) over layers built as parse_model :940-1105
+# --------------------------------------------------------------------------------------------
+class Model:
+    def __init__(self, family="yolo11", scale="s", nc=80, task="detect", ch=3):
+        depth, width, max_ch = SCALES[family][scale]
+        self.family, self.scale, self.nc, self.task = family, scale, nc, task
+        legacy = True
+        chans: List[int] = []
+        self.layers = []
+        for i, (f, n, t, args) in enumerate(GRAPHS[family]):
+            name = f"model.{i}"
+            n = max(round(n * depth), 1) if n > 1 else n  # tasks.py:972
+            if t in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA"):
+                c1 = chans[f] if chans else ch  # tasks.py:1014 (ch[f]; the first layer sees the image)
+                c2 = make_divisible(min(args[0], max_ch) * width, 8)  # tasks.py:1016
+                if t == "Conv":
+                    m = Conv(name, c1, c2, *args[1:])
+                elif t == "C3k2":
+                    legacy = False  # tasks.py:1046-1049
+                    a = list(args[1:])
+                    if scale in "mlx":
+                        a[0] = True
+                    m = C3k2(name, c1, c2, n, *a)
+                elif t == "C2f":
+                    m = C2f(name, c1, c2, n, *args[1:])
+                elif t == "SPPF":
+                    m = SPPF(name, c1, c2, *args[1:])
+                else:
+                    m = C2PSA(name, c1, c2, n)
+            elif t == "Upsample":
+                m, c2 = "up", chans[f]
+            elif t == "Concat":
+                m, c2 = "cat", sum(chans[x] for x in f)
+            else:
+                raise ValueError(t)
+            self.layers.append((f, m))
+            chans.append(c2)
+        hf = HEAD_FROM[family]
+        hch = [chans[x] for x in hf]
+        self.strides = [8.0, 16.0, 32.0]  # tasks.py:333-344 stride probe result for these graphs
+        hname = f"model.{len(self.layers)}"
+        if task == "detect":
+            head = Detect(hname, nc, hch, legacy, self.strides)
+        else:
+            npr = make_divisible(min(256, max_ch) * width, 8)  # tasks.py:1082-1083
+            head = Segment(hname, nc, 32, npr, hch, legacy, self.strides)
+        self.layers.append((hf, head))
+        self.head = head
+        self.save = sorted({x % len(self.layers) for f, _ in self.layers for x in ([f] if isinstance(f, int) else f)
+                            if x != -1})
+
+    def param_specs(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        out = []
+        for _, m in self.layers:
+            if not isinstance(m, str):
+                out.extend(m.specs())
+        return out
+
+    def num_params(self):
+        """Count as the reference does (Parameters only: BN running stats are buffers)."""
+        return sum(int(np.prod(s)) for n, s in self.param_specs() if "running_" not in n)
+
+    def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor):
+        y: List = []
+        for f, m in self.layers:
+            if f != -1:
+                x = y[f] if isinstance(f, int) else [x if j == -1 else y[j] for j in f]
+            if m == "up":
+                x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            elif m == "cat":
+                x = torch.cat(x, 1)
+            else:
+                x = m(P, x)
+            y.append(x)
+        return x
+
+
+# --------------------------------------------------------------------------------------------
+# Deterministic synthetic parameters, addressed by state_dict name.  Shared by
+# tests/golden/make_fixtures.py (which writes them INTO the reference model) and the tests.
+# --------------------------------------------------------------------------------------------
+CLS_BIAS = -6.0  # shifts the class logits so that O(1 %) of anchors pass conf 0.25
+
+
+def synth_param(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor:
+    rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+    shape = tuple(int(s) for s in shape)
+    if name.endswith("dfl.conv.weight"):
+        return torch.arange(16, dtype=torch.float32).view(shape)
+    if name.endswith("bn.weight"):
+        a = rng.uniform(0.7, 1.3, shape)
+    elif name.endswith("bn.bias") or name.endswith("running_mean"):
+        a = rng.uniform(-0.3, 0.3, shape)
+    elif name.endswith("running_var"):
+        a = rng.uniform(0.5, 1.5, shape)
+    elif name.endswith(".bias"):
+        if ".cv3." in name:
+            a = rng.uniform(CLS_BIAS - 0.5, CLS_BIAS + 0.5, shape)
+        elif ".cv2." in name:
+            a = rng.uniform(0.5, 1.5, shape)
+        else:
+            a = rng.uniform(-0.2, 0.2, shape)
+    else:
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        if "upsample" in name:  # ConvTranspose2d weight (cin, cout, 2, 2): one tap per output pixel
+            fan_in = shape[0]
+        a = rng.standard_normal(shape) * math.sqrt(2.0 / max(fan_in, 1))
+    return torch.from_numpy(np.asarray(a, dtype=np.float32))
+
+
+def synth_params(model: Model, seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {n: synth_param(n, s, seed) for n, s in model.param_specs()}

@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/make_fixtures.py            # writes tests/golden/*.npz
+
+The reference (/root/reference, Ultralytics 8.3.56 fork) is imported in-process.  Third-party modules that are
+absent from this image (cv2, pywt, seaborn, cpuinfo, torchvision) are satisfied with in-process ``sys.modules``
+entries; nothing of the reference is modified or copied.  The two third-party *functions* the hot path calls are
+bound to the oracle's restatements so that the reference's own wrapper logic runs end to end:
+    torchvision.ops.nms  -> oracle.postproc_ref.greedy_nms      (utils/ops.py:296)
+    cv2.resize / cv2.copyMakeBorder -> oracle.letterbox_ref     (data/augment.py:1586-1591)
+(fixtures produced through those two are therefore pinned for the wrapper logic / geometry only; see oracle/__init__.py).
+
+Model parameters are NOT stored: both sides regenerate them from ``oracle.yolo_ref.synth_param(name, shape, seed)``
+keyed by the reference's own state_dict names, which this script writes INTO the reference modules.
+"""
+import importlib.metadata as md
+import json
+import os
+import sys
+import types
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.update(YOLO_OFFLINE="true", YOLO_AUTOINSTALL="false", YOLO_CONFIG_DIR="/tmp/yolocfg",
+                  PYTHONDONTWRITEBYTECODE="1", YOLO_VERBOSE="false")
+sys.dont_write_bytecode = True
+os.makedirs("/tmp/yolocfg", exist_ok=True)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import letterbox_ref, postproc_ref  # noqa: E402
+from oracle.yolo_ref import synth_param  # noqa: E402
+
+
+class _Dummy(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Dummy(self.__name__ + "." + k)
+
+    def __call__(self, *a, **k):
+        return None
+
+
+for _n in ("pywt", "pywt.data", "seaborn", "cpuinfo"):
+    sys.modules[_n] = _Dummy(_n)
+
+cv2 = _Dummy("cv2")
+cv2.INTER_LINEAR = 1
+cv2.BORDER_CONSTANT = 0
+
+
+def _cv2_resize(img, dsize, interpolation=1):
+    return letterbox_ref.resize_linear_u8(img, dsize)
+
+
+def _cv2_border(img, top, bottom, left, right, borderType, value=(114, 114, 114)):
+    h, w = img.shape[:2]
+    out = np.empty((h + top + bottom, w + left + right, img.shape[2]), dtype=img.dtype)
+    out[:] = np.asarray(value, dtype=img.dtype)
+    out[top:top + h, left:left + w] = img
+    return out
+
+
+cv2.resize = _cv2_resize
+cv2.copyMakeBorder = _cv2_border
+sys.modules["cv2"] = cv2
+
+tv = types.ModuleType("torchvision")
+tv.ops = types.ModuleType("torchvision.ops")
+tv.ops.nms = postproc_ref.greedy_nms
+tv.__version__ = "0.20.0"
+sys.modules["torchvision"] = tv
+sys.modules["torchvision.ops"] = tv.ops
+_v = md.version
+md.version = lambda n: "0.20.0" if n == "torchvision" else _v(n)
+
+sys.path.insert(0, "/root/reference")
+import yaml  # noqa: E402
+from ultralytics.data.augment import LetterBox  # noqa: E402
+from ultralytics.nn.modules import block as rb, conv as rc, head as rh  # noqa: E402
+from ultralytics.nn.tasks import DetectionModel, SegmentationModel  # noqa: E402
+from ultralytics.utils import ops as rops  # noqa: E402
+from ultralytics.utils.torch_utils import initialize_weights  # noqa: E402
+
+CFG = Path("/root/reference/ultralytics/cfg/models")
+
+
+def fill(module, prefix, seed):
+    """Write synth_param values into every parameter/buffer of a reference module (by state_dict name)."""
+    names = []
+    sd = module.state_dict()
+    for k, t in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        name = prefix + k
+        t.copy_(synth_param(name, t.shape, seed))
+        names.append((name, list(t.shape)))
+    return names
+
+
+def stock_cfg(family, scale, task, nc=80):
+    if family == "yolo11":
+        d = yaml.safe_load(open(CFG / "11" / "yolo11-seg.yaml"))  # stock backbone/neck (yolo11.yaml is the BS-YOLO graph)
+        if task == "detect":
+            d["head"][-1] = [[16, 19, 22], 1, "Detect", ["nc"]]
+    else:
+        d = yaml.safe_load(open(CFG / "v8" / "yolov8-seg.yaml"))
+        if task == "detect":
+            d["head"][-1] = [[15, 18, 21], 1, "Detect", ["nc"]]
+    d["scale"] = scale
+    d["nc"] = nc
+    return d
+
+
+def build_ref(family, scale, task, nc=80, seed=0):
+    cls = DetectionModel if task == "detect" else SegmentationModel
+    m = cls(stock_cfg(family, scale, task, nc), ch=3, nc=nc, verbose=False).eval()
+    names = fill(m, "", seed)
+    nparam = sum(p.numel() for p in m.parameters())
+    m.fuse(verbose=False)
+    return m, names, nparam
+
+
+def graph_fixture(tag, family, scale, task, shapes, nc=80, seed=0, keep_layers=False):
+    m, names, nparam = build_ref(family, scale, task, nc, seed)
+    out = {"meta": json.dumps({"family": family, "scale": scale, "task": task, "nc": nc, "seed": seed,
+                               "names": names, "nparam": nparam, "stride": [float(s) for s in m.stride],
+                               "save": list(m.save)})}
+    for si, (b, h, w) in enumerate(shapes):
+        g = torch.Generator().manual_seed(100 + si)
+        x = torch.rand(b, 3, h, w, generator=g)
+        layer_out = {}
+        hooks = []
+        if keep_layers and si == 0:
+            for i, layer in enumerate(list(m.model)[:-1]):
+                hooks.append(layer.register_forward_hook(
+                    lambda mod, inp, o, i=i: layer_out.__setitem__(i, o.detach().clone())))
+        with torch.inference_mode():
+            res = m(x)
+        for hk in hooks:
+            hk.remove()
+        out[f"x{si}"] = x.numpy()
+        if task == "detect":
+            y, raw = res
+            out[f"y{si}"] = y.numpy()
+            for li, r in enumerate(raw):
+                out[f"raw{si}_{li}"] = r.numpy()
+        else:
+            y, (raw, mc, p) = res
+            out[f"y{si}"] = y.numpy()
+            out[f"proto{si}"] = p.numpy()
+            for li, r in enumerate(raw):
+                out[f"raw{si}_{li}"] = r.numpy()
+        for i, o in layer_out.items():
+            out[f"layer{si}_{i}"] = o.numpy()
+    np.savez_compressed(HERE / f"graph_{tag}.npz", **out)
+    print("wrote", tag, {k: (v.shape if hasattr(v, "shape") else "") for k, v in out.items() if k != "meta"})
+
+
+def module_fixtures():
+    """Per-module known-answer vectors: reference module (eval, fused like BaseModel.fuse) in -> out."""
+    out = {}
+    cases = {}
+
+    def fuse_all(mod):
+        from ultralytics.utils.torch_utils import fuse_conv_and_bn
+        for sm in mod.modules():
+            if isinstance(sm, rc.Conv) and hasattr(sm, "bn"):
+                sm.conv = fuse_conv_and_bn(sm.conv, sm.bn)
+                delattr(sm, "bn")
+                sm.forward = sm.forward_fuse
+
+    def add(tag, mod, x, ctor):
+        mod.eval()
+        initialize_weights(mod)  # BN eps 1e-3 (torch_utils.py:417-427)
+        fill(mod, "m.", 7)
+        fuse_all(mod)
+        with torch.inference_mode():
+            y = mod(x)
+        out[tag + ".x"] = x.numpy()
+        out[tag + ".y"] = y.numpy()
+        cases[tag] = ctor
+
+    g = torch.Generator().manual_seed(5)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    add("conv_k1", rc.Conv(16, 32, 1, 1), rnd(2, 16, 12, 10), ["Conv", 16, 32, 1, 1])
+    add("conv_k3", rc.Conv(16, 24, 3, 1), rnd(2, 16, 12, 10), ["Conv", 16, 24, 3, 1])
+    add("conv_k3s2", rc.Conv(3, 16, 3, 2), rnd(2, 3, 32, 24), ["Conv", 3, 16, 3, 2])
+    add("conv_k3s2_odd", rc.Conv(8, 16, 3, 2), rnd(1, 8, 13, 11), ["Conv", 8, 16, 3, 2])
+    add("conv_noact", rc.Conv(32, 16, 1, 1, act=False), rnd(2, 32, 8, 8), ["ConvNoAct", 32, 16, 1, 1])
+    add("dwconv", rc.DWConv(32, 32, 3, 1), rnd(2, 32, 9, 7), ["DWConv", 32, 32, 3, 1])
+    add("bottleneck", rb.Bottleneck(32, 32, True), rnd(2, 32, 10, 10), ["Bottleneck", 32, 32, True])
+    add("bottleneck_noadd", rb.Bottleneck(32, 32, False), rnd(2, 32, 10, 10), ["Bottleneck", 32, 32, False])
+    add("c3k", rb.C3k(32, 32, 2), rnd(2, 32, 8, 8), ["C3k", 32, 32, 2])
+    add("c3k2_f", rb.C3k2(32, 64, 1, False, 0.25), rnd(2, 32, 12, 12), ["C3k2", 32, 64, 1, False, 0.25])
+    add("c3k2_t", rb.C3k2(64, 64, 1, True), rnd(2, 64, 8, 8), ["C3k2", 64, 64, 1, True])
+    add("c2f", rb.C2f(32, 32, 2, True), rnd(2, 32, 8, 8), ["C2f", 32, 32, 2, True])
+    add("sppf", rb.SPPF(64, 64, 5), rnd(2, 64, 10, 7), ["SPPF", 64, 64, 5])
+    add("attention", rb.Attention(128, num_heads=2, attn_ratio=0.5), rnd(2, 128, 10, 10), ["Attention", 128, 2, 0.5])
+    add("psablock", rb.PSABlock(128, 0.5, 2), rnd(2, 128, 6, 5), ["PSABlock", 128, 0.5, 2])
+    add("c2psa", rb.C2PSA(256, 256, 1), rnd(1, 256, 8, 8), ["C2PSA", 256, 256, 1])
+    add("proto", rb.Proto(32, 32, 16), rnd(1, 32, 8, 8), ["Proto", 32, 32, 16])
+    out["cases"] = json.dumps(cases)
+
+    # fuse_conv_and_bn known answer (utils/torch_utils.py:242-269)
+    from ultralytics.utils.torch_utils import fuse_conv_and_bn
+    c = rc.Conv(8, 12, 3, 1).eval()
+    initialize_weights(c)
+    fill(c, "m.", 11)
+    f = fuse_conv_and_bn(c.conv, c.bn)
+    out["fuse.w"] = f.weight.detach().numpy()
+    out["fuse.b"] = f.bias.detach().numpy()
+
+    # Detect decode (head.py:100-131 + block.py:58-77 + tal.py:371-395) on tiny raw maps
+    det = rh.Detect(nc=5, ch=(16, 32, 64)).eval()
+    det.stride = torch.tensor([8.0, 16.0, 32.0])
+    raws = [rnd(2, 69, 8, 6), rnd(2, 69, 4, 3), rnd(2, 69, 2, 2)]
+    with torch.inference_mode():
+        y = det._inference([r.clone() for r in raws])
+    for i, r in enumerate(raws):
+        out[f"decode.raw{i}"] = r.numpy()
+    out["decode.y"] = y.numpy()
+    np.savez_compressed(HERE / "modules.npz", **out)
+    print("wrote modules", len(cases), "cases")
+
+
+def synth_pred(b, nc, a, nm, seed, peaky, dtype=torch.float32):
+    """(B, 4+nc+nm, A) prediction tensor in Detect's output format with duplicated / overlapping boxes."""
+    g = torch.Generator().manual_seed(seed)
+    base = max(a // 8, 1)
+    cx = torch.rand(b, base, generator=g) * 600 + 20
+    cy = torch.rand(b, base, generator=g) * 600 + 20
+    w = torch.rand(b, base, generator=g) * 150 + 10
+    h = torch.rand(b, base, generator=g) * 150 + 10
+    rep = (a + base - 1) // base
+    jit = lambda t: (t.repeat(1, rep)[:, :a] + torch.randn(b, a, generator=g) * 4.0)  # noqa: E731
+    box = torch.stack((jit(cx), jit(cy), jit(w).abs() + 2, jit(h).abs() + 2), 1)
+    if peaky:
+        cls = torch.rand(b, nc, a, generator=g) ** 8
+    else:
+        cls = torch.rand(b, nc, a, generator=g) * 0.6
+    parts = [box, cls]
+    if nm:
+        parts.append(torch.randn(b, nm, a, generator=g))
+    return torch.cat(parts, 1).to(dtype)
+
+
+def nms_fixtures():
+    out = {}
+    cfgs = []
+    cases = [
+        ("predict_peaky", dict(b=3, nc=80, a=1050, nm=0, seed=1, peaky=True), dict(conf_thres=0.25, iou_thres=0.7)),
+        ("predict_flat", dict(b=2, nc=12, a=640, nm=0, seed=2, peaky=False), dict(conf_thres=0.25, iou_thres=0.45)),
+        ("val_multilabel", dict(b=2, nc=20, a=1000, nm=0, seed=3, peaky=True),
+         dict(conf_thres=0.001, iou_thres=0.7, multi_label=True)),
+        ("val_cap", dict(b=1, nc=40, a=2000, nm=0, seed=4, peaky=False),
+         dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_nms=3000, max_det=300)),
+        ("agnostic", dict(b=2, nc=8, a=512, nm=0, seed=5, peaky=False),
+         dict(conf_thres=0.3, iou_thres=0.5, agnostic=True, max_det=50)),
+        ("classes", dict(b=2, nc=8, a=512, nm=0, seed=6, peaky=False),
+         dict(conf_thres=0.3, iou_thres=0.5, classes=[1, 3, 6])),
+        ("seg_masks", dict(b=2, nc=10, a=700, nm=32, seed=7, peaky=True), dict(conf_thres=0.25, iou_thres=0.7, nc=10)),
+        ("empty", dict(b=2, nc=10, a=300, nm=0, seed=8, peaky=True), dict(conf_thres=0.9999, iou_thres=0.7)),
+        ("single_class", dict(b=2, nc=1, a=400, nm=0, seed=9, peaky=False),
+         dict(conf_thres=0.3, iou_thres=0.6, multi_label=True)),
+    ]
+    for tag, pk, kw in cases:
+        pred = synth_pred(**pk)
+        inp = pred.clone()
+        res = rops.non_max_suppression(pred, **kw)
+        out[tag + ".pred"] = inp.numpy()
+        out[tag + ".pred_after"] = pred[:, :4].numpy()  # in_place xywh->xyxy mutation (ops.py:243-244)
+        for i, r in enumerate(res):
+            out[f"{tag}.out{i}"] = r.numpy()
+        cfgs.append((tag, kw, len(res)))
+    out["cases"] = json.dumps(cfgs)
+
+    # scale_boxes / clip_boxes (ops.py:92-127, :319)
+    sb = []
+    g = torch.Generator().manual_seed(3)
+    for i, (s1, s0) in enumerate([((640, 480), (1080, 810)), ((384, 640), (720, 1280)), ((640, 640), (4000, 6000)),
+                                  ((640, 640), (333, 500)), ((1280, 1280), (100, 37))]):
+        boxes = torch.rand(50, 4, generator=g) * 700 - 30
+        res = rops.scale_boxes(s1, boxes.clone(), s0)
+        out[f"scale_boxes{i}.in"] = boxes.numpy()
+        out[f"scale_boxes{i}.out"] = res.numpy()
+        sb.append((s1, s0))
+    out["scale_boxes_cases"] = json.dumps(sb)
+    np.savez_compressed(HERE / "nms.npz", **out)
+    print("wrote nms", [c[0] for c in cfgs])
+
+
+def letterbox_fixtures():
+    out = {}
+    cases = []
+    rng = np.random.default_rng(0)
+    shapes = [(1080, 810), (720, 1280), (4000, 6000), (333, 500), (640, 640), (100, 37), (1280, 1280), (641, 959),
+              (480, 640)]
+    # geometry: output shape and where the image lands, for the shapes SURVEY 8c lists (no pixels stored)
+    for (h, w) in shapes:
+        for kw in (dict(new_shape=(640, 640), auto=True), dict(new_shape=(640, 640), auto=False),
+                   dict(new_shape=(1280, 1280), auto=False), dict(new_shape=(384, 640), auto=False, scaleup=False),
+                   dict(new_shape=(640, 640), auto=False, center=False)):
+            marker = np.full((h, w, 3), 7, np.uint8)
+            r2 = LetterBox(stride=32, **kw)(image=marker)
+            ys, xs = np.where(r2[..., 0] != 114)
+            cases.append({"shape": [h, w], "kw": kw, "out_shape": list(r2.shape),
+                          "box": [int(ys.min()), int(ys.max()) + 1, int(xs.min()), int(xs.max()) + 1]})
+    out["cases"] = json.dumps(cases)
+    # pixels (small): pinned only against the oracle's own cv2.resize restatement (see module docstring)
+    pix = []
+    for k, ((h, w), kw) in enumerate([((100, 37), dict(new_shape=(160, 160), auto=False)),
+                                      ((75, 120), dict(new_shape=(96, 128), auto=True)),
+                                      ((333, 500), dict(new_shape=(160, 224), auto=False)),
+                                      ((64, 64), dict(new_shape=(128, 128), auto=False)),
+                                      ((256, 192), dict(new_shape=(128, 128), auto=True))]):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out[f"img{k}"] = img
+        out[f"lb{k}"] = LetterBox(stride=32, **kw)(image=img)
+        pix.append({"kw": kw})
+    out["pixel_cases"] = json.dumps(pix)
+    np.savez_compressed(HERE / "letterbox.npz", **out)
+    print("wrote letterbox", len(cases), "geometry cases,", len(pix), "pixel cases")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    graph_fixture("yolo11n_detect", "yolo11", "n", "detect", [(2, 64, 64), (1, 96, 160)], keep_layers=True)
+    graph_fixture("yolo11s_detect", "yolo11", "s", "detect", [(1, 64, 96)])
+    graph_fixture("yolo11m_detect", "yolo11", "m", "detect", [(1, 64, 64)])
+    graph_fixture("yolo11n_segment", "yolo11", "n", "segment", [(1, 64, 64)])
+    graph_fixture("yolov8n_segment", "yolov8", "n", "segment", [(1, 64, 96)])
+    module_fixtures()
+    nms_fixtures()
+    letterbox_fixtures()
