@@ -1,0 +1,74 @@
+"""Build libbsyolo_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m bs_yolo_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libbsyolo_hip.so"
+ARCH = "gfx950"
+# per-file extra flags: NMS / letterbox decisions must round exactly like the fp32 CPU reference (no FMA contraction)
+SOURCES = {
+    "err.cpp": [],
+    "conv_mfma.hip": [],
+    "conv_first.hip": [],
+    "elementwise.hip": [],
+    "attention.hip": [],
+    "detect.hip": [],
+    "nms.hip": ["-ffp-contract=off"],
+    "letterbox.hip": ["-ffp-contract=off"],
+    "engine.hip": [],
+}
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    headers = [CSRC / "common.h", PKG.parent / "include" / "bsyolo.h"]
+    hipcc = _hipcc()
+    jobs = []
+    for src, extra in SOURCES.items():
+        obj = objdir / (src.rsplit(".", 1)[0] + ".o")
+        if force or _stale(obj, [CSRC / src, *headers]):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *extra, "-c",
+                   str(CSRC / src), "-o", str(obj)]
+            jobs.append(cmd)
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    objs = [str(objdir / (s.rsplit(".", 1)[0] + ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build_library(force="--force" in sys.argv, verbose=True)
+    print("built", p, p.stat().st_size, "bytes")

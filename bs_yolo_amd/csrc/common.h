@@ -1,0 +1,106 @@
+// Shared declarations for the gfx950 kernels of libbsyolo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/bsyolo.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (thread-local message, no C++ exceptions across the ABI) ----
+void bsy_set_error(const char* fmt, ...);
+#define BSY_FAIL(code, ...)        \
+    do {                           \
+        bsy_set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) BSY_FAIL(BSY_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                       __FILE__, __LINE__);                                               \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---- resolved (pointer-level) launch arguments; filled by the engine or by the stand-alone C entry points ----
+struct ConvArgs {
+    const half_t* src0;  // incl. channel offset
+    const half_t* src1;  // second concat operand or nullptr
+    int ld0, ld1;        // channels per pixel row of each source buffer
+    int C0, C1;          // channels taken from each source (Cin = C0 + C1), multiples of 8
+    int up0, up1;        // nearest-x2 read
+    int B, H, W, OH, OW; // logical input / output extents
+    int ksize, stride, pad;
+    const half_t* wgt;   // [CoutPad][Kpad]
+    const float* bias;   // [CoutPad]
+    void* dst;           // incl. channel offset; f16 or f32
+    int ldd, Cout, out_f32;
+    const half_t* res;   // incl. channel offset or nullptr
+    int ldr;
+    int act;
+    int dst_scale, dst_dy, dst_dx;
+};
+int launch_conv(const ConvArgs& a, hipStream_t s);
+
+struct ConvFirstArgs {
+    const void* img;
+    int img_dtype;
+    int B, H, W, OH, OW, ksize, stride, pad;
+    const float* w;  // [k*k*3][Cout]
+    const float* b;
+    half_t* dst;
+    int ldd, Cout, act;
+};
+int launch_conv_first(const ConvFirstArgs& a, hipStream_t s);
+
+struct DwArgs {
+    const half_t* src;
+    int lds;
+    int B, H, W, C;
+    const float* w;  // [9][C]
+    const float* b;
+    half_t* dst;
+    int ldd;
+    int act;
+    const half_t* res;
+    int ldr;
+};
+int launch_dwconv(const DwArgs& a, hipStream_t s);
+int launch_sppf_pool(half_t* buf, int ld, int B, int H, int W, int C, hipStream_t s);
+
+struct AttnArgs {
+    const half_t* qkv;
+    int ld;
+    int B, N, heads, key_dim, head_dim;
+    float scale;
+    half_t* out;
+    int ldo;
+};
+int launch_attention(const AttnArgs& a, hipStream_t s);
+
+struct DecodeArgs {
+    const float* box[3];
+    const float* cls[3];
+    const float* msk[3];
+    int ldb[3], ldc[3], ldm[3];
+    int h[3], w[3];
+    float stride[3];
+    int nl, B, nc, nm, A;
+    void* y;
+    int y_dtype;
+};
+int launch_decode(const DecodeArgs& a, hipStream_t s);
+int launch_raw_nchw(const float* box, int ldb, const float* cls, int ldc, int B, int h, int w, int nc, void* out,
+                    int out_dtype, hipStream_t s);
+
+// SiLU in fp32: x * sigmoid(x)
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

@@ -1,0 +1,119 @@
+// HBM-bound helpers of the forward path, NHWC fp16, one 16-byte (8-channel) vector per thread.
+//   dwconv3x3_kernel : DWConv (nn/modules/conv.py:224-229) 3x3 s1 p1 + bias (+SiLU) (+residual)
+//                      used by Detect.cv3 (head.py:46-53) and Attention.pe (block.py:4264)
+//   sppf_pool_kernel : the three chained MaxPool2d(5,1,2) of SPPF.forward (block.py:3145-3149); chained 5x5 max
+//                      pools with -inf padding equal 5x5 / 9x9 / 13x13 window maxima, computed in one pass and
+//                      written into the channel slices of the (virtual) concat buffer
+#include "common.h"
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W,
+                                                        int C, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, half_t* __restrict__ dst,
+                                                        int ldd, int act, const half_t* __restrict__ res, int ldr) {
+    const int C8 = C >> 3;
+    const long long total = (long long)B * H * W * C8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8) * 8;
+    const long long pix = idx / C8;
+    const int x = (int)(pix % W);
+    const long long t = pix / W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[c + j];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int iy = y + kh - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ix = x + kw - 1;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const half8 v = *reinterpret_cast<const half8*>(src + ((size_t)(n * H + iy) * W + ix) * lds_ + c);
+            const float* wp = w + (kh * 3 + kw) * C + c;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = fmaf((float)v[j], w0[j], acc[j]);
+                acc[4 + j] = fmaf((float)v[4 + j], w1[j], acc[4 + j]);
+            }
+        }
+    }
+    half8 o;
+    if (res) {
+        const half8 r = *reinterpret_cast<const half8*>(res + (size_t)pix * ldr + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((act ? silu_f(acc[j]) : acc[j]) + (float)r[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(act ? silu_f(acc[j]) : acc[j]);
+    }
+    *reinterpret_cast<half8*>(dst + (size_t)pix * ldd + c) = o;
+}
+
+int launch_dwconv(const DwArgs& a, hipStream_t s) {
+    if ((a.C & 7) || (a.lds & 7) || (a.ldd & 7) || (a.res && (a.ldr & 7)) || ((uintptr_t)a.src & 15) ||
+        ((uintptr_t)a.dst & 15) || ((uintptr_t)a.res & 15) || ((uintptr_t)a.w & 15))
+        BSY_FAIL(BSY_ERR_ARG, "dwconv: channels/strides must be multiples of 8 and pointers 16-byte aligned");
+    const long long total = (long long)a.B * a.H * a.W * (a.C / 8);
+    if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "dwconv: empty");
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H,
+                       a.W, a.C, a.w, a.b, a.dst, a.ldd, a.act, a.res, a.ldr);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+__device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
+    half8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j] > b[j] ? a[j] : b[j];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void sppf_pool_kernel(half_t* __restrict__ buf, int ld, int B, int H, int W, int C) {
+    const int C8 = C >> 3;
+    const long long total = (long long)B * H * W * C8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8) * 8;
+    const long long pix = idx / C8;
+    const int x = (int)(pix % W);
+    const long long t = pix / W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const half_t NEG = (half_t)(-65504.0f);
+    half8 m5, m9, m13;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m5[j] = m9[j] = m13[j] = NEG;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int iy = y + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int ix = x + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const int adx = dx < 0 ? -dx : dx;
+            const int r = ady > adx ? ady : adx;
+            const half8 v = *reinterpret_cast<const half8*>(buf + ((size_t)(n * H + iy) * W + ix) * ld + c);
+            m13 = hmax8(m13, v);
+            if (r <= 4) m9 = hmax8(m9, v);
+            if (r <= 2) m5 = hmax8(m5, v);
+        }
+    }
+    half_t* op = buf + (size_t)pix * ld + c;
+    *reinterpret_cast<half8*>(op + C) = m5;
+    *reinterpret_cast<half8*>(op + 2 * C) = m9;
+    *reinterpret_cast<half8*>(op + 3 * C) = m13;
+}
+
+int launch_sppf_pool(half_t* buf, int ld, int B, int H, int W, int C, hipStream_t s) {
+    if ((C & 7) || (ld & 7) || ld < 4 * C || ((uintptr_t)buf & 15)) BSY_FAIL(BSY_ERR_ARG, "sppf_pool: bad layout");
+    const long long total = (long long)B * H * W * (C / 8);
+    if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "sppf_pool: empty");
+    hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf, ld, B, H, W, C);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}

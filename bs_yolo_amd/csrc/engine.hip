@@ -1,0 +1,306 @@
+// Engine / plan objects behind the C ABI (include/bsyolo.h) and the stand-alone operator entry points.
+//
+// The host side (bs_yolo_amd/plan.py) flattens the model graph -- the work of BaseModel._predict_once
+// (nn/tasks.py:138-165) and of every module forward on the path -- into a list of bsy_op records that reference
+// workspace buffers by index.  A plan owns that workspace in HBM (one allocation, 256-byte aligned slices) and replays
+// the op list on the caller's stream; nothing here synchronises or allocates per call.
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+struct bsy_engine {
+    int device = 0;
+    void* weights = nullptr;
+    size_t weight_bytes = 0;
+};
+
+struct bsy_plan {
+    bsy_engine* eng = nullptr;
+    std::vector<bsy_op> ops;
+    std::vector<size_t> buf_off;
+    std::vector<size_t> buf_size;
+    char* workspace = nullptr;
+    size_t workspace_bytes = 0;
+    std::vector<hipEvent_t> events;
+};
+
+extern "C" int bsy_engine_create(int device, bsy_engine** out) {
+    if (!out) BSY_FAIL(BSY_ERR_ARG, "engine_create: null out");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) BSY_FAIL(BSY_ERR_ARG, "engine_create: device %d of %d", device, ndev);
+    bsy_engine* e = new bsy_engine();
+    e->device = device;
+    *out = e;
+    return BSY_OK;
+}
+
+extern "C" void bsy_engine_destroy(bsy_engine* e) {
+    if (!e) return;
+    if (e->weights) (void)hipFree(e->weights);
+    delete e;
+}
+
+extern "C" int bsy_engine_load_weights(bsy_engine* e, const void* host_blob, size_t bytes) {
+    if (!e || !host_blob || !bytes) BSY_FAIL(BSY_ERR_ARG, "load_weights: bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->weights) {
+        HIP_TRY(hipFree(e->weights));
+        e->weights = nullptr;
+    }
+    if (hipMalloc(&e->weights, bytes + 256) != hipSuccess) BSY_FAIL(BSY_ERR_ALLOC, "load_weights: hipMalloc(%zu) failed", bytes);
+    HIP_TRY(hipMemcpy(e->weights, host_blob, bytes, hipMemcpyHostToDevice));
+    e->weight_bytes = bytes;
+    return BSY_OK;
+}
+
+extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, const int64_t* buf_bytes, int n_bufs,
+                               bsy_plan** out) {
+    if (!e || !ops || n_ops <= 0 || !out || n_bufs < 0 || (n_bufs && !buf_bytes)) BSY_FAIL(BSY_ERR_ARG, "plan_create: bad argument");
+    if (!e->weights) BSY_FAIL(BSY_ERR_STATE, "plan_create: load weights first");
+    HIP_TRY(hipSetDevice(e->device));
+    bsy_plan* p = new bsy_plan();
+    p->eng = e;
+    p->ops.assign(ops, ops + n_ops);
+    size_t off = 0;
+    for (int i = 0; i < n_bufs; ++i) {
+        if (buf_bytes[i] < 0) { delete p; BSY_FAIL(BSY_ERR_ARG, "plan_create: negative buffer size"); }
+        p->buf_off.push_back(off);
+        p->buf_size.push_back((size_t)buf_bytes[i]);
+        off += ((size_t)buf_bytes[i] + 255) & ~(size_t)255;
+    }
+    p->workspace_bytes = off + 256;
+    if (hipMalloc((void**)&p->workspace, p->workspace_bytes) != hipSuccess) {
+        delete p;
+        BSY_FAIL(BSY_ERR_ALLOC, "plan_create: hipMalloc(%zu) failed", off + 256);
+    }
+    // zero once so that padding channels nobody writes are finite
+    if (hipMemset(p->workspace, 0, p->workspace_bytes) != hipSuccess) {
+        (void)hipFree(p->workspace);
+        delete p;
+        BSY_FAIL(BSY_ERR_HIP, "plan_create: hipMemset failed");
+    }
+    *out = p;
+    return BSY_OK;
+}
+
+extern "C" void bsy_plan_destroy(bsy_plan* p) {
+    if (!p) return;
+    for (auto ev : p->events) (void)hipEventDestroy(ev);
+    if (p->workspace) (void)hipFree(p->workspace);
+    delete p;
+}
+
+namespace {
+struct Resolver {
+    const bsy_plan* p;
+    void* const* ext;
+    int n_ext;
+    bool ok = true;
+    // returns base pointer of the buffer (no channel offset) or nullptr when the view is absent
+    char* base(const bsy_view& v) {
+        if (v.buf < 0) return nullptr;
+        if (v.buf >= BSY_EXT_BASE) {
+            const int s = v.buf - BSY_EXT_BASE;
+            if (s >= n_ext || !ext[s]) { ok = false; bsy_set_error("plan_run: external slot %d not bound", s); return nullptr; }
+            return (char*)ext[s];
+        }
+        if ((size_t)v.buf >= p->buf_off.size()) { ok = false; bsy_set_error("plan_run: buffer %d out of range", v.buf); return nullptr; }
+        return p->workspace + p->buf_off[v.buf];
+    }
+    half_t* h(const bsy_view& v) { char* b = base(v); return b ? (half_t*)b + v.coff : nullptr; }
+    float* f(const bsy_view& v) { char* b = base(v); return b ? (float*)b + v.coff : nullptr; }
+};
+
+int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s) {
+    const char* wb = (const char*)p->eng->weights;
+    switch (op.kind) {
+        case BSY_OP_CONV_FIRST: {
+            ConvFirstArgs a;
+            a.img = R.base(op.src0); a.img_dtype = op.in_dtype;
+            a.B = op.B; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW;
+            a.ksize = op.ksize; a.stride = op.stride; a.pad = op.pad;
+            a.w = (const float*)(wb + op.w_off); a.b = (const float*)(wb + op.b_off);
+            a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.Cout = op.dst.C; a.act = op.act;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_conv_first(a, s);
+        }
+        case BSY_OP_CONV: {
+            ConvArgs a;
+            a.src0 = R.h(op.src0); a.src1 = R.h(op.src1);
+            a.ld0 = op.src0.ld; a.ld1 = op.src1.buf >= 0 ? op.src1.ld : 0;
+            a.C0 = op.src0.C; a.C1 = op.src1.buf >= 0 ? op.src1.C : 0;
+            a.up0 = op.up0; a.up1 = op.up1;
+            a.B = op.B; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW;
+            a.ksize = op.ksize; a.stride = op.stride; a.pad = op.pad;
+            a.wgt = (const half_t*)(wb + op.w_off); a.bias = (const float*)(wb + op.b_off);
+            a.dst = op.out_f32 ? (void*)R.f(op.dst) : (void*)R.h(op.dst);
+            a.ldd = op.dst.ld; a.Cout = op.dst.C; a.out_f32 = op.out_f32;
+            a.res = R.h(op.res); a.ldr = op.res.buf >= 0 ? op.res.ld : 0;
+            a.act = op.act; a.dst_scale = op.dst_scale; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_conv(a, s);
+        }
+        case BSY_OP_DWCONV: {
+            DwArgs a;
+            a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C;
+            a.w = (const float*)(wb + op.w_off); a.b = (const float*)(wb + op.b_off);
+            a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.act = op.act;
+            a.res = R.h(op.res); a.ldr = op.res.buf >= 0 ? op.res.ld : 0;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_dwconv(a, s);
+        }
+        case BSY_OP_SPPF_POOL: {
+            half_t* b = R.h(op.src0);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_sppf_pool(b, op.src0.ld, op.B, op.H, op.W, op.src0.C, s);
+        }
+        case BSY_OP_ATTN: {
+            AttnArgs a;
+            a.qkv = R.h(op.src0); a.ld = op.src0.ld; a.B = op.B; a.N = op.H * op.W; a.heads = op.heads;
+            a.key_dim = op.key_dim; a.head_dim = op.head_dim; a.scale = op.scale;
+            a.out = R.h(op.dst); a.ldo = op.dst.ld;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_attention(a, s);
+        }
+        case BSY_OP_DECODE: {
+            DecodeArgs a;
+            memset(&a, 0, sizeof(a));
+            a.nl = op.nl; a.B = op.B; a.nc = op.nc; a.nm = op.nm; a.A = op.A;
+            for (int l = 0; l < op.nl && l < 3; ++l) {
+                a.box[l] = R.f(op.box[l]); a.cls[l] = R.f(op.cls[l]); a.msk[l] = op.nm ? R.f(op.msk[l]) : nullptr;
+                a.ldb[l] = op.box[l].ld; a.ldc[l] = op.cls[l].ld; a.ldm[l] = op.nm ? op.msk[l].ld : 0;
+                a.h[l] = op.lvl_h[l]; a.w[l] = op.lvl_w[l]; a.stride[l] = op.lvl_stride[l];
+            }
+            a.y = R.base(op.dst); a.y_dtype = op.out_dtype;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_decode(a, s);
+        }
+        case BSY_OP_RAW_NCHW: {
+            const int l = op.level;
+            if (l < 0 || l > 2) BSY_FAIL(BSY_ERR_ARG, "raw_nchw: level %d", l);
+            // optional output: silently skipped when the slot is not bound
+            if (op.dst.buf >= BSY_EXT_BASE && (op.dst.buf - BSY_EXT_BASE >= R.n_ext || !R.ext[op.dst.buf - BSY_EXT_BASE]))
+                return BSY_OK;
+            const float* box = R.f(op.box[l]);
+            const float* cls = R.f(op.cls[l]);
+            void* out = R.base(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_raw_nchw(box, op.box[l].ld, cls, op.cls[l].ld, op.B, op.lvl_h[l], op.lvl_w[l], op.nc, out,
+                                   op.out_dtype, s);
+        }
+        default:
+            BSY_FAIL(BSY_ERR_ARG, "plan_run: unknown op kind %d", op.kind);
+    }
+}
+}  // namespace
+
+extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream) {
+    if (!p || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_run: bad argument");
+    Resolver R{p, ext, n_ext};
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const int rc = run_op(p, p->ops[i], R, (hipStream_t)stream);
+        if (rc != BSY_OK) return rc;
+    }
+    return BSY_OK;
+}
+
+extern "C" int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes) {
+    if (!p || !host_dst || buf < 0 || (size_t)buf >= p->buf_off.size()) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: bad argument");
+    if (bytes > p->buf_size[buf]) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: %zu > buffer size %zu", bytes, p->buf_size[buf]);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_dst, p->workspace + p->buf_off[buf], bytes, hipMemcpyDeviceToHost));
+    return BSY_OK;
+}
+
+extern "C" int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, float* ms_per_op) {
+    if (!p || !ms_per_op || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_profile: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = p->ops.size();
+    while (p->events.size() < n + 1) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        p->events.push_back(ev);
+    }
+    Resolver R{p, ext, n_ext};
+    HIP_TRY(hipEventRecord(p->events[0], s));
+    for (size_t i = 0; i < n; ++i) {
+        const int rc = run_op(p, p->ops[i], R, s);
+        if (rc != BSY_OK) return rc;
+        HIP_TRY(hipEventRecord(p->events[i + 1], s));
+    }
+    HIP_TRY(hipEventSynchronize(p->events[n]));
+    for (size_t i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms_per_op[i], p->events[i], p->events[i + 1]));
+    return BSY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stand-alone operators
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, const void* w, const float* b, void* y,
+                          int ldy, int C2, int ksize, int stride, int act, const void* res, int ldr, int y_f32,
+                          bsy_stream stream) {
+    if (!x || !w || !b || !y) BSY_FAIL(BSY_ERR_ARG, "conv2d: null pointer");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = (const half_t*)x; a.ld0 = ldx; a.C0 = C1; a.B = B; a.H = H; a.W = W;
+    a.ksize = ksize; a.stride = stride; a.pad = ksize / 2;  // autopad (nn/modules/conv.py:29-35)
+    a.OH = (H + 2 * a.pad - ksize) / stride + 1; a.OW = (W + 2 * a.pad - ksize) / stride + 1;
+    a.wgt = (const half_t*)w; a.bias = b; a.dst = y; a.ldd = ldy; a.Cout = C2; a.out_f32 = y_f32;
+    a.res = (const half_t*)res; a.ldr = ldr; a.act = act; a.dst_scale = 1;
+    return launch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b,
+                              void* y, int ldy, int C2, int ksize, int stride, int act, bsy_stream stream) {
+    if (!img || !w || !b || !y) BSY_FAIL(BSY_ERR_ARG, "conv_first: null pointer");
+    ConvFirstArgs a;
+    a.img = img; a.img_dtype = img_dtype; a.B = B; a.H = H; a.W = W; a.ksize = ksize; a.stride = stride; a.pad = ksize / 2;
+    a.OH = (H + 2 * a.pad - ksize) / stride + 1; a.OW = (W + 2 * a.pad - ksize) / stride + 1;
+    a.w = w; a.b = b; a.dst = (half_t*)y; a.ldd = ldy; a.Cout = C2; a.act = act;
+    return launch_conv_first(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y,
+                             int ldy, int act, const void* res, int ldr, bsy_stream stream) {
+    if (!x || !w || !b || !y) BSY_FAIL(BSY_ERR_ARG, "dwconv3x3: null pointer");
+    DwArgs a;
+    a.src = (const half_t*)x; a.lds = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.w = w; a.b = b;
+    a.dst = (half_t*)y; a.ldd = ldy; a.act = act; a.res = (const half_t*)res; a.ldr = ldr;
+    return launch_dwconv(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_sppf_pool(void* buf, int ld, int B, int H, int W, int C, bsy_stream stream) {
+    if (!buf) BSY_FAIL(BSY_ERR_ARG, "sppf_pool: null pointer");
+    return launch_sppf_pool((half_t*)buf, ld, B, H, W, C, (hipStream_t)stream);
+}
+
+extern "C" int bsy_attention(const void* qkv, int ld, int B, int N, int heads, int key_dim, int head_dim, float scale,
+                             void* out, int ldo, bsy_stream stream) {
+    if (!qkv || !out) BSY_FAIL(BSY_ERR_ARG, "attention: null pointer");
+    AttnArgs a;
+    a.qkv = (const half_t*)qkv; a.ld = ld; a.B = B; a.N = N; a.heads = heads; a.key_dim = key_dim; a.head_dim = head_dim;
+    a.scale = scale; a.out = (half_t*)out; a.ldo = ldo;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_detect_decode(const float* const* box, const int* ldb, const float* const* cls, const int* ldc,
+                                 const float* const* msk, const int* ldm, const int* lvl_h, const int* lvl_w,
+                                 const float* lvl_stride, int nl, int B, int nc, int nm, void* y, int y_dtype,
+                                 bsy_stream stream) {
+    if (!box || !ldb || !cls || !ldc || !lvl_h || !lvl_w || !lvl_stride || !y || nl < 1 || nl > 3)
+        BSY_FAIL(BSY_ERR_ARG, "detect_decode: bad argument");
+    if (nm && (!msk || !ldm)) BSY_FAIL(BSY_ERR_ARG, "detect_decode: mask inputs missing");
+    DecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nl = nl; a.B = B; a.nc = nc; a.nm = nm; a.A = 0;
+    for (int l = 0; l < nl; ++l) {
+        a.box[l] = box[l]; a.cls[l] = cls[l]; a.msk[l] = nm ? msk[l] : nullptr;
+        a.ldb[l] = ldb[l]; a.ldc[l] = ldc[l]; a.ldm[l] = nm ? ldm[l] : 0;
+        a.h[l] = lvl_h[l]; a.w[l] = lvl_w[l]; a.stride[l] = lvl_stride[l];
+    }
+    a.y = y; a.y_dtype = y_dtype;
+    return launch_decode(a, (hipStream_t)stream);
+}

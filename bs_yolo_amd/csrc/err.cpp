@@ -1,0 +1,17 @@
+// Thread-local error message + version for the C ABI.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void bsy_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* bsy_last_error(void) { return g_err; }
+extern "C" int bsy_version(void) { return 1; }

@@ -1,0 +1,121 @@
+"""Engine wrapper: owns a bsy_engine (weights in HBM) and one bsy_plan per input shape.
+
+`YoloEngine.__call__(im)` has the calling convention AutoBackend expects from an in-memory model
+(nn/autobackend.py:524: ``self.model(im, augment=, visualize=, embed=)`` -> ``(y, x_list)``, head.py:74), with
+``im`` a contiguous BCHW fp16/fp32 tensor on the engine's device.  PyTorch is only used for device memory and
+the current stream; all compute goes through libbsyolo_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Mapping, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from .plan import Plan
+from .weights import BN_EPS, adopt_offsets, pack_plan_weights
+
+
+class YoloEngine:
+    def __init__(self, cfg: dict, state_dict: Mapping[str, torch.Tensor], device: int = 0, bn_eps: float = BN_EPS):
+        if not torch.cuda.is_available():
+            raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self._h = C.c_void_p()
+        L.check(L.lib.bsy_engine_create(device, C.byref(self._h)))
+        self._plans: Dict[Tuple, Tuple] = {}
+        # pack once with a throw-away plan (op list structure does not depend on the input size)
+        self._packed = Plan(cfg, 1, 64, 64)
+        blob = pack_plan_weights(self._packed, state_dict, bn_eps)
+        self.weight_bytes = len(blob)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        L.check(L.lib.bsy_engine_load_weights(self._h, buf, len(blob)))
+        self.meta = dict(self._packed.meta)
+        self.nc = self.meta["nc"]
+        self.stride = torch.tensor(self.meta["strides"])
+        self.names = {i: f"{i}" for i in range(self.nc)}
+
+    # -- plans --------------------------------------------------------------------------------------------------
+    def plan_for(self, B: int, H: int, W: int, in_dtype: torch.dtype, out_dtype: torch.dtype):
+        key = (B, H, W, in_dtype, out_dtype)
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit
+        if H % 32 or W % 32:
+            raise ValueError(f"input {H}x{W} must be a multiple of the max stride 32 (utils/checks.py:120-172)")
+        plan = Plan(self.cfg, B, H, W, L.dtype_code(in_dtype), L.dtype_code(out_dtype))
+        adopt_offsets(plan, self._packed)
+        ops = plan.c_ops()
+        sizes = (C.c_int64 * len(plan.buf_bytes))(*plan.buf_bytes)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib.bsy_plan_create(self._h, ops, len(plan.ops), sizes, len(plan.buf_bytes), C.byref(h)))
+        self._plans[key] = (plan, h)
+        return plan, h
+
+    def _ext(self, im, y, raws):
+        ptrs = [im.data_ptr(), y.data_ptr()] + [r.data_ptr() if r is not None else None for r in raws]
+        return (C.c_void_p * len(ptrs))(*ptrs), len(ptrs)
+
+    def forward(self, im: torch.Tensor, want_raw: bool = True):
+        if im.device != self.device:
+            raise ValueError(f"input on {im.device}, engine on {self.device}")
+        if im.dtype not in (torch.float16, torch.float32):
+            raise TypeError("input must be fp16 or fp32 (BCHW, 0..1)")
+        im = im.contiguous()
+        B, Cc, H, W = im.shape
+        if Cc != 3:
+            raise ValueError("expected 3 input channels")
+        plan, h = self.plan_for(B, H, W, im.dtype, im.dtype)
+        m = plan.meta
+        y = torch.empty((B, 4 + m["nc"] + m["nm"], m["A"]), dtype=im.dtype, device=self.device)
+        raws: List[Optional[torch.Tensor]] = [None, None, None]
+        if want_raw:
+            raws = [torch.empty((B, m["no"], lh, lw), dtype=im.dtype, device=self.device) for lh, lw in m["levels"]]
+        ext, n = self._ext(im, y, raws)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
+        return y, raws
+
+    def __call__(self, im, augment=False, visualize=False, embed=None, want_raw=True):
+        if augment or visualize or embed:
+            raise NotImplementedError("augment/visualize/embed fall back to the reference graph (tasks.py:134-164)")
+        return self.forward(im, want_raw)
+
+    def profile(self, im: torch.Tensor):
+        """Per-op device time (ms) of one forward, measured with HIP events on the current stream."""
+        im = im.contiguous()
+        B, _, H, W = im.shape
+        plan, h = self.plan_for(B, H, W, im.dtype, im.dtype)
+        m = plan.meta
+        y = torch.empty((B, 4 + m["nc"] + m["nm"], m["A"]), dtype=im.dtype, device=self.device)
+        ext, n = self._ext(im, y, [None, None, None])
+        ms = (C.c_float * len(plan.ops))()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(L.lib.bsy_plan_profile(h, ext, n, C.c_void_p(stream), ms))
+        return [(o["name"], o["kind"], float(t)) for o, t in zip(plan.ops, ms)], plan
+
+    def read_view(self, plan, h, t) -> torch.Tensor:
+        """Debug/test aid: copy an activation view back as a (B, C, H, W) fp32 CPU tensor."""
+        hs, ws = (t.H // 2, t.W // 2) if t.up else (t.H, t.W)
+        n = plan.B * hs * ws * t.ld
+        host = torch.empty(n, dtype=torch.float32 if t.f32 else torch.float16)
+        L.check(L.lib.bsy_plan_copy_buffer(h, t.buf, C.c_void_p(host.data_ptr()), n * host.element_size()))
+        v = host.view(plan.B, hs, ws, t.ld)[..., t.coff:t.coff + t.C].permute(0, 3, 1, 2).float()
+        return torch.nn.functional.interpolate(v, scale_factor=2.0, mode="nearest") if t.up else v.contiguous()
+
+    def close(self):
+        for _, h in self._plans.values():
+            L.lib.bsy_plan_destroy(h)
+        self._plans.clear()
+        if self._h:
+            L.lib.bsy_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,67 @@
+"""Stock model descriptions in the reference's yaml-dict schema (what ``model.yaml`` holds on a live reference model).
+
+The reference ships these graphs as cfg/models/11/yolo11-seg.yaml:15-47 (stock YOLO11 backbone+neck; note that
+cfg/models/11/yolo11.yaml is the modified BS-YOLO graph) and cfg/models/v8/yolov8-seg.yaml:15-46.  They are
+restated here as data so the engine can be built where the reference is not installed (benchmarks, GPU box).
+"""
+from __future__ import annotations
+
+import copy
+
+_UP = [-1, 1, "nn.Upsample", [None, 2, "nearest"]]
+
+
+def _cat(j):
+    return [[-1, j], 1, "Concat", [1]]
+
+
+_YOLO11 = {
+    "scales": {"n": [0.50, 0.25, 1024], "s": [0.50, 0.50, 1024], "m": [0.50, 1.00, 512], "l": [1.00, 1.00, 512],
+               "x": [1.00, 1.50, 512]},
+    "backbone": [
+        [-1, 1, "Conv", [64, 3, 2]], [-1, 1, "Conv", [128, 3, 2]], [-1, 2, "C3k2", [256, False, 0.25]],
+        [-1, 1, "Conv", [256, 3, 2]], [-1, 2, "C3k2", [512, False, 0.25]], [-1, 1, "Conv", [512, 3, 2]],
+        [-1, 2, "C3k2", [512, True]], [-1, 1, "Conv", [1024, 3, 2]], [-1, 2, "C3k2", [1024, True]],
+        [-1, 1, "SPPF", [1024, 5]], [-1, 2, "C2PSA", [1024]],
+    ],
+    "head": [
+        _UP, _cat(6), [-1, 2, "C3k2", [512, False]],
+        _UP, _cat(4), [-1, 2, "C3k2", [256, False]],
+        [-1, 1, "Conv", [256, 3, 2]], _cat(13), [-1, 2, "C3k2", [512, False]],
+        [-1, 1, "Conv", [512, 3, 2]], _cat(10), [-1, 2, "C3k2", [1024, True]],
+    ],
+    "detect_from": [16, 19, 22],
+}
+
+_YOLOV8 = {
+    "scales": {"n": [0.33, 0.25, 1024], "s": [0.33, 0.50, 1024], "m": [0.67, 0.75, 768], "l": [1.00, 1.00, 512],
+               "x": [1.00, 1.25, 512]},
+    "backbone": [
+        [-1, 1, "Conv", [64, 3, 2]], [-1, 1, "Conv", [128, 3, 2]], [-1, 3, "C2f", [128, True]],
+        [-1, 1, "Conv", [256, 3, 2]], [-1, 6, "C2f", [256, True]], [-1, 1, "Conv", [512, 3, 2]],
+        [-1, 6, "C2f", [512, True]], [-1, 1, "Conv", [1024, 3, 2]], [-1, 3, "C2f", [1024, True]],
+        [-1, 1, "SPPF", [1024, 5]],
+    ],
+    "head": [
+        _UP, _cat(6), [-1, 3, "C2f", [512]],
+        _UP, _cat(4), [-1, 3, "C2f", [256]],
+        [-1, 1, "Conv", [256, 3, 2]], _cat(12), [-1, 3, "C2f", [512]],
+        [-1, 1, "Conv", [512, 3, 2]], _cat(9), [-1, 3, "C2f", [1024]],
+    ],
+    "detect_from": [15, 18, 21],
+}
+
+_FAMILIES = {"yolo11": _YOLO11, "yolov8": _YOLOV8}
+
+
+def stock_cfg(family: str = "yolo11", scale: str = "s", nc: int = 80, task: str = "detect") -> dict:
+    """e.g. stock_cfg("yolo11", "s") == what the reference builds for 'yolo11s.yaml' upstream."""
+    fam = copy.deepcopy(_FAMILIES[family])
+    head = list(fam["head"])
+    if task == "detect":
+        head.append([fam["detect_from"], 1, "Detect", ["nc"]])
+    elif task == "segment":
+        head.append([fam["detect_from"], 1, "Segment", ["nc", 32, 256]])
+    else:
+        raise ValueError(task)
+    return {"nc": nc, "scale": scale, "scales": fam["scales"], "backbone": fam["backbone"], "head": head}

@@ -1,0 +1,121 @@
+"""Tensor-level wrappers over the stand-alone C entry points (same kernels the engine launches).
+
+Used by the per-module hooks (plugin.py) and by the parity tests.  Activations are NHWC fp16 torch tensors
+(``x.permute(0, 2, 3, 1).contiguous()`` of the reference's BCHW tensors); every call runs on the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def pack_conv_weight(w: torch.Tensor, b: Optional[torch.Tensor], device) -> tuple:
+    """(Cout, Cin, k, k) fp32 [+ bias] -> packed fp16 [CoutPad][Kpad] + fp32 [CoutPad] on `device`."""
+    cout, cin, k, _ = w.shape
+    cp, kp = C.c_int(), C.c_int()
+    L.check(L.lib.bsy_conv_packed_dims(cout, cin, k, C.byref(cp), C.byref(kp)))
+    K = k * k * cin
+    wp = torch.zeros(cp.value, kp.value, dtype=torch.float16)
+    wp[:cout, :K] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, K).half()
+    bp = torch.zeros(cp.value, dtype=torch.float32)
+    if b is not None:
+        bp[:cout] = b.detach().float().cpu()
+    return wp.to(device), bp.to(device)
+
+
+def conv2d_nhwc(x: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, cout: int, k: int, s: int = 1, act: bool = True,
+                res: Optional[torch.Tensor] = None, out_f32: bool = False, cin: Optional[int] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B,H,W,ld) fp16 (uses the first `cin` channels) -> (B,OH,OW,cout).  Conv.forward_fuse (conv.py:149-151)."""
+    assert x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 4
+    B, H, W, ld = x.shape
+    cin = ld if cin is None else cin
+    p = k // 2
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    if out is None:
+        ldy = (cout + 3) // 4 * 4 if out_f32 else (cout + 7) // 8 * 8
+        out = torch.zeros((B, OH, OW, ldy), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+    L.check(L.lib.bsy_conv2d(_p(x), ld, B, H, W, cin, _p(wp), _p(bp), _p(out), out.shape[-1], cout, k, s, int(act),
+                             _p(res), res.shape[-1] if res is not None else 0, int(out_f32), _stream(x)))
+    return out
+
+
+def conv_first(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int = 3, s: int = 2, act: bool = True):
+    """img BCHW fp16/fp32; w (Cout,3,k,k) fp32; -> NHWC fp16."""
+    assert img.is_contiguous() and img.shape[1] == 3
+    B, _, H, W = img.shape
+    cout = w.shape[0]
+    wp = w.detach().float().cpu().permute(2, 3, 1, 0).reshape(k * k * 3, cout).contiguous().to(img.device)
+    bp = b.detach().float().contiguous().to(img.device)
+    p = k // 2
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    out = torch.empty((B, OH, OW, cout), dtype=torch.float16, device=img.device)
+    L.check(L.lib.bsy_conv_first(_p(img), L.dtype_code(img.dtype), B, H, W, _p(wp), _p(bp), _p(out), cout, cout, k, s,
+                                 int(act), _stream(img)))
+    return out
+
+
+def dwconv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: bool = True,
+                   res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B,H,W,C) fp16; w (C,1,3,3) fp32.  DWConv (conv.py:224-229)."""
+    B, H, W, Cc = x.shape
+    wp = w.detach().float().cpu().view(Cc, 9).t().contiguous().to(x.device)
+    bp = b.detach().float().contiguous().to(x.device)
+    out = torch.empty_like(x)
+    L.check(L.lib.bsy_dwconv3x3(_p(x), Cc, B, H, W, Cc, _p(wp), _p(bp), _p(out), Cc, int(act), _p(res),
+                                res.shape[-1] if res is not None else 0, _stream(x)))
+    return out
+
+
+def sppf_pool_nhwc(x1: torch.Tensor) -> torch.Tensor:
+    """x1 (B,H,W,C) -> (B,H,W,4C) = cat[x1, m(x1), m(m(x1)), m(m(m(x1)))], m = MaxPool2d(5,1,2) (block.py:3145-3149)."""
+    B, H, W, Cc = x1.shape
+    buf = torch.zeros((B, H, W, 4 * Cc), dtype=torch.float16, device=x1.device)
+    buf[..., :Cc] = x1
+    L.check(L.lib.bsy_sppf_pool(_p(buf), 4 * Cc, B, H, W, Cc, _stream(x1)))
+    return buf
+
+
+def attention_nhwc(qkv: torch.Tensor, heads: int, key_dim: int, head_dim: int, scale: float) -> torch.Tensor:
+    """qkv (B,N,heads*(2kd+hd)) fp16 in [q|k|v] (all-heads-contiguous) order -> (B,N,heads*hd) (block.py:4279-4286)."""
+    B, N, ld = qkv.shape
+    out = torch.empty((B, N, heads * head_dim), dtype=torch.float16, device=qkv.device)
+    L.check(L.lib.bsy_attention(_p(qkv), ld, B, N, heads, key_dim, head_dim, float(scale), _p(out), heads * head_dim,
+                                _stream(qkv)))
+    return out
+
+
+def detect_decode(box: Sequence[torch.Tensor], cls: Sequence[torch.Tensor], hw: Sequence[tuple],
+                  strides: Sequence[float], nc: int, out_dtype=torch.float32,
+                  msk: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+    """box[l] (B*h*w, 64) f32, cls[l] (B*h*w, ldc) f32 -> (B, 4+nc+nm, A) (head.py:100-131)."""
+    nl = len(box)
+    B = box[0].shape[0] // (hw[0][0] * hw[0][1])
+    nm = msk[0].shape[-1] if msk else 0
+    A = sum(h * w for h, w in hw)
+    y = torch.empty((B, 4 + nc + nm, A), dtype=out_dtype, device=box[0].device)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    bp = (vp * nl)(*[t.data_ptr() for t in box])
+    cp = (vp * nl)(*[t.data_ptr() for t in cls])
+    mp = (vp * nl)(*[t.data_ptr() for t in msk]) if msk else None
+    ldb = (i32 * nl)(*[t.shape[-1] for t in box])
+    ldc = (i32 * nl)(*[t.shape[-1] for t in cls])
+    ldm = (i32 * nl)(*[t.shape[-1] for t in msk]) if msk else None
+    hh = (i32 * nl)(*[h for h, _ in hw])
+    ww = (i32 * nl)(*[w for _, w in hw])
+    st = (f32 * nl)(*[float(s) for s in strides])
+    L.check(L.lib.bsy_detect_decode(bp, ldb, cp, ldc, mp, ldm, hh, ww, st, nl, B, nc, nm, _p(y), L.dtype_code(out_dtype),
+                                    _stream(y)))
+    return y

@@ -1,0 +1,353 @@
+"""Host-side graph flattening: model description -> flat list of device ops (include/bsyolo.h `bsy_op`).
+
+Mirrors what the reference does at run time in Python:
+  * nn/tasks.py:940-1105 parse_model  -- channel scaling ``make_divisible(min(c2, max_ch) * width, 8)`` (:1016),
+    repeat scaling ``max(round(n * depth), 1)`` (:972), ``c3k=True`` for m/l/x (:1046-1049), ``legacy`` Detect head
+    for graphs without C3k2 (:1048, head.py:44-56);
+  * nn/tasks.py:138-165 _predict_once -- the ``f`` / save routing between top-level layers;
+  * the forward of every module on the path (conv.py:133-151; block.py:3114-3149, 3295-3334, 3405-3419, 3796-3815,
+    4235-4288, 4348-4383, 4429-4468; head.py:64-131).
+Instead of executing modules, every forward is expanded into device ops over NHWC buffers:
+  chunk/split/cat -> channel-slice views of one buffer; nn.Upsample -> `up` flag on the consumer's source;
+  Concat -> two-source conv; shortcut adds -> conv epilogue residual.
+
+The model description is the reference's own yaml dict schema (``model.yaml`` of a live reference model, or the
+stock tables in graphs.py), so a reference model drops in without translation.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+from . import lib as L
+
+
+def make_divisible(x, d):  # utils/ops.py:130-143
+    return math.ceil(x / d) * d
+
+
+@dataclass
+class T:
+    """A logical NHWC activation: channel slice [coff, coff+C) of buffer `buf` (row stride `ld`), H x W pixels.
+    up=True: stored at (H/2, W/2), read through nearest x2 (virtual nn.Upsample)."""
+    buf: int
+    ld: int
+    coff: int
+    C: int
+    H: int
+    W: int
+    up: bool = False
+    f32: bool = False
+
+    def slice(self, c0: int, c: int) -> "T":
+        assert 0 <= c0 and c0 + c <= self.C
+        return T(self.buf, self.ld, self.coff + c0, c, self.H, self.W, self.up, self.f32)
+
+    def view(self):
+        return (self.buf, self.ld, self.coff, self.C)
+
+
+@dataclass
+class WRec:
+    """How to pack one op's parameters into the weight blob (weights.py)."""
+    name: str          # state_dict prefix, e.g. "model.2.m.0.cv1"  (Conv: .conv.weight + .bn.*; plain: .weight/.bias)
+    kind: str          # conv | plain | dw | first | deconv
+    cout: int
+    cin: int
+    k: int
+    perm: Optional[List[int]] = None   # output-channel permutation (qkv)
+    tap: Optional[Tuple[int, int]] = None  # deconv: (dy, dx)
+    w_off: int = -1
+    b_off: int = -1
+
+
+class Plan:
+    """Flat op list + workspace buffer table for one (B, H, W)."""
+
+    EXT_IMG, EXT_Y, EXT_RAW0 = 0, 1, 2  # external slots: image, prediction, raw level maps (2,3,4), proto (5)
+    EXT_PROTO = 5
+
+    def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16):
+        self.cfg, self.B, self.H, self.W = cfg, B, H, W
+        self.in_dtype, self.out_dtype = in_dtype, out_dtype
+        self.buf_bytes: List[int] = []
+        self.ops: List[dict] = []
+        self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
+        self.flops = 0  # 2*MAC of every dense/depthwise conv + attention matmuls, whole batch
+        self.meta: Dict = {}
+        self._build()
+
+    # ---- buffers -------------------------------------------------------------------------------------------
+    def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
+        ld = make_divisible(C, 4) if f32 else make_divisible(C, 8)
+        self.buf_bytes.append(self.B * H * W * ld * (4 if f32 else 2))
+        return T(len(self.buf_bytes) - 1, ld, 0, C, H, W, False, f32)
+
+    # ---- op emitters -----------------------------------------------------------------------------------------
+    def _wrec(self, key: str, **kw) -> str:
+        if key not in self.wrecs:
+            self.wrecs[key] = WRec(**kw)
+        return key
+
+    def conv(self, name: str, src: Union[T, Sequence[T]], cout: int, k: int = 1, s: int = 1, act: bool = True,
+             dst: Optional[T] = None, res: Optional[T] = None, plain: bool = False, out_f32: bool = False,
+             perm: Optional[List[int]] = None) -> T:
+        srcs = [src] if isinstance(src, T) else list(src)
+        assert 1 <= len(srcs) <= 2, "at most two concat operands per conv"
+        H, W = srcs[0].H, srcs[0].W
+        assert all(t.H == H and t.W == W and not t.f32 for t in srcs)
+        cin = sum(t.C for t in srcs)
+        p = k // 2
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        if dst is None:
+            dst = self.alloc(cout, OH, OW, out_f32)
+        assert dst.C == cout and dst.H == OH and dst.W == OW and dst.f32 == out_f32 and not dst.up
+        if res is not None:
+            assert res.C == cout and res.H == OH and res.W == OW and not res.up
+        key = self._wrec(name, name=name, kind="plain" if plain else "conv", cout=cout, cin=cin, k=k, perm=perm)
+        self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
+                             src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
+                             act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name))
+        self.flops += 2 * self.B * OH * OW * cout * cin * k * k
+        return dst
+
+    def conv_first(self, name: str, cout: int, k: int, s: int) -> T:
+        p = k // 2
+        OH, OW = (self.H + 2 * p - k) // s + 1, (self.W + 2 * p - k) // s + 1
+        dst = self.alloc(cout, OH, OW)
+        key = self._wrec(name, name=name, kind="first", cout=cout, cin=3, k=k)
+        self.ops.append(dict(kind=L.OP_CONV_FIRST, H=self.H, W=self.W, OH=OH, OW=OW,
+                             src0=T(L.BSY_EXT_BASE + self.EXT_IMG, 0, 0, 3, self.H, self.W), dst=dst, ksize=k, stride=s,
+                             pad=p, act=1, wkey=key, in_dtype=self.in_dtype, name=name))
+        self.flops += 2 * self.B * OH * OW * cout * 3 * k * k
+        return dst
+
+    def dwconv(self, name: str, src: T, act: bool, dst: Optional[T] = None, res: Optional[T] = None) -> T:
+        assert not src.up
+        if dst is None:
+            dst = self.alloc(src.C, src.H, src.W)
+        key = self._wrec(name, name=name, kind="dw", cout=src.C, cin=1, k=3)
+        self.ops.append(dict(kind=L.OP_DWCONV, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, dst=dst, res=res,
+                             ksize=3, stride=1, pad=1, act=int(act), wkey=key, name=name))
+        self.flops += 2 * self.B * src.H * src.W * src.C * 9
+        return dst
+
+    # ---- module expansions -----------------------------------------------------------------------------------
+    def bottleneck(self, name: str, x: T, dst: T, shortcut: bool, k=(3, 3), e=0.5):
+        """block.py:3405-3419: x + cv2(cv1(x))."""
+        c_ = int(dst.C * e)
+        t = self.conv(name + ".cv1", x, c_, k[0], 1)
+        self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=x if (shortcut and x.C == dst.C) else None)
+
+    def c3k(self, name: str, x: T, dst: T, n: int, shortcut: bool):
+        """block.py:3320-3334 + :3807-3815: cv3(cat(m(cv1 x), cv2 x)), m = n x Bottleneck(c_, c_, k=(3,3), e=1)."""
+        c_ = int(dst.C * 0.5)
+        cat = self.alloc(2 * c_, x.H, x.W)
+        cur = self.conv(name + ".cv1", x, c_, 1, 1)
+        self.conv(name + ".cv2", x, c_, 1, 1, dst=cat.slice(c_, c_))
+        for i in range(n):
+            out = cat.slice(0, c_) if i == n - 1 else self.alloc(c_, x.H, x.W)
+            self.bottleneck(f"{name}.m.{i}", cur, out, shortcut, (3, 3), 1.0)
+            cur = out
+        self.conv(name + ".cv3", cat, dst.C, 1, 1, dst=dst)
+
+    def c2f(self, name: str, x, c2: int, n: int, shortcut: bool, e: float, inner: str) -> T:
+        """block.py:3295-3317 (C2f) / :3796-3804 (C3k2).  inner: 'c2f' | 'bottleneck' | 'c3k'."""
+        xs = [x] if isinstance(x, T) else list(x)
+        c = int(c2 * e)
+        cat = self.alloc((2 + n) * c, xs[0].H, xs[0].W)
+        self.conv(name + ".cv1", xs, 2 * c, 1, 1, dst=cat.slice(0, 2 * c))
+        for i in range(n):
+            src, dst = cat.slice((1 + i) * c, c), cat.slice((2 + i) * c, c)
+            if inner == "c3k":
+                self.c3k(f"{name}.m.{i}", src, dst, 2, shortcut)
+            elif inner == "c2f":
+                self.bottleneck(f"{name}.m.{i}", src, dst, shortcut, (3, 3), 1.0)
+            else:
+                self.bottleneck(f"{name}.m.{i}", src, dst, shortcut, (3, 3), 0.5)
+        return self.conv(name + ".cv2", cat, c2, 1, 1)
+
+    def sppf(self, name: str, x: T, c2: int) -> T:
+        """block.py:3114-3149."""
+        c_ = x.C // 2
+        cat = self.alloc(4 * c_, x.H, x.W)
+        self.conv(name + ".cv1", x, c_, 1, 1, dst=cat.slice(0, c_))
+        self.ops.append(dict(kind=L.OP_SPPF_POOL, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=cat.slice(0, c_), name=name + ".m"))
+        return self.conv(name + ".cv2", cat, c2, 1, 1)
+
+    def c2psa(self, name: str, x: T, c2: int, n: int) -> T:
+        """block.py:4429-4468 with PSABlock :4348-4383 and Attention :4235-4288."""
+        assert x.C == c2
+        c = int(c2 * 0.5)
+        nh = c // 64
+        hd = c // nh
+        kd = int(hd * 0.5)
+        ab = self.alloc(2 * c, x.H, x.W)
+        self.conv(name + ".cv1", x, 2 * c, 1, 1, dst=ab)
+        b = ab.slice(c, c)
+        # qkv rows are emitted per head as [q(kd) k(kd) v(hd)] by the reference (block.py:4274-4276); reorder to
+        # [q(all heads) | k(all heads) | v(all heads)] so that v is one channel slice and heads are contiguous
+        per = 2 * kd + hd
+        perm = [h * per + i for h in range(nh) for i in range(kd)] + \
+               [h * per + kd + i for h in range(nh) for i in range(kd)] + \
+               [h * per + 2 * kd + i for h in range(nh) for i in range(hd)]
+        for i in range(n):
+            pn = f"{name}.m.{i}"
+            qkv = self.conv(pn + ".attn.qkv", b, nh * per, 1, 1, act=False, perm=perm)
+            att = self.alloc(c, x.H, x.W)
+            self.ops.append(dict(kind=L.OP_ATTN, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=qkv, dst=att, heads=nh, key_dim=kd,
+                                 head_dim=hd, scale=float(kd ** -0.5), name=pn + ".attn"))
+            N = x.H * x.W
+            self.flops += 2 * self.B * nh * N * N * (kd + hd)
+            xo = self.dwconv(pn + ".attn.pe", qkv.slice(2 * nh * kd, c), act=False, res=att)  # v@attn^T + pe(v)
+            self.conv(pn + ".attn.proj", xo, c, 1, 1, act=False, dst=b, res=b)                # b = b + proj(.)
+            f = self.conv(pn + ".ffn.0", b, 2 * c, 1, 1)
+            self.conv(pn + ".ffn.1", f, c, 1, 1, act=False, dst=b, res=b)                     # b = b + ffn(b)
+        return self.conv(name + ".cv2", ab, c2, 1, 1)
+
+    def detect(self, name: str, xs: List[T], nc: int, legacy: bool, nm: int = 0, npr: int = 0):
+        """head.py:21-148 (+ Segment :175-197)."""
+        ch = [t.C for t in xs]
+        c2, c3 = max(16, ch[0] // 4, 64), max(ch[0], min(nc, 100))
+        boxes, clss, msks = [], [], []
+        for i, x in enumerate(xs):
+            assert not x.up
+            t = self.conv(f"{name}.cv2.{i}.0", x, c2, 3, 1)
+            t = self.conv(f"{name}.cv2.{i}.1", t, c2, 3, 1)
+            boxes.append(self.conv(f"{name}.cv2.{i}.2", t, 64, 1, 1, act=False, plain=True, out_f32=True))
+            if legacy:
+                t = self.conv(f"{name}.cv3.{i}.0", x, c3, 3, 1)
+                t = self.conv(f"{name}.cv3.{i}.1", t, c3, 3, 1)
+            else:
+                t = self.dwconv(f"{name}.cv3.{i}.0.0", x, act=True)
+                t = self.conv(f"{name}.cv3.{i}.0.1", t, c3, 1, 1)
+                t = self.dwconv(f"{name}.cv3.{i}.1.0", t, act=True)
+                t = self.conv(f"{name}.cv3.{i}.1.1", t, c3, 1, 1)
+            clss.append(self.conv(f"{name}.cv3.{i}.2", t, nc, 1, 1, act=False, plain=True, out_f32=True))
+            if nm:
+                c4 = max(ch[0] // 4, nm)
+                t = self.conv(f"{name}.cv4.{i}.0", x, c4, 3, 1)
+                t = self.conv(f"{name}.cv4.{i}.1", t, c4, 3, 1)
+                msks.append(self.conv(f"{name}.cv4.{i}.2", t, nm, 1, 1, act=False, plain=True, out_f32=True))
+        A = sum(t.H * t.W for t in xs)
+        strides = [float(self.H // t.H) for t in xs]
+        self.ops.append(dict(kind=L.OP_DECODE, H=self.H, W=self.W, OH=0, OW=0, nl=len(xs), nc=nc, nm=nm, A=A, box=boxes,
+                             cls=clss, msk=msks, lvl_h=[t.H for t in xs], lvl_w=[t.W for t in xs], lvl_stride=strides,
+                             dst=T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc + nm, 0, 0), out_dtype=self.out_dtype,
+                             name=name + ".decode"))
+        for i in range(len(xs)):
+            self.ops.append(dict(kind=L.OP_RAW_NCHW, H=self.H, W=self.W, OH=0, OW=0, nl=len(xs), nc=nc, nm=0, A=A,
+                                 box=boxes, cls=clss, msk=[], lvl_h=[t.H for t in xs], lvl_w=[t.W for t in xs],
+                                 lvl_stride=strides, level=i,
+                                 dst=T(L.BSY_EXT_BASE + self.EXT_RAW0 + i, 0, 0, 64 + nc, 0, 0),
+                                 out_dtype=self.out_dtype, name=f"{name}.raw{i}"))
+        self.meta.update(A=A, nc=nc, nm=nm, no=64 + nc, strides=strides, levels=[(t.H, t.W) for t in xs])
+
+    # ---- graph walk (nn/tasks.py:138-165 + :940-1105) -----------------------------------------------------------
+    def _build(self):
+        d = self.cfg
+        scales = d.get("scales")
+        depth, width, max_ch = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0), float("inf")
+        scale = d.get("scale")
+        if scales:
+            if not scale:
+                scale = next(iter(scales))
+            depth, width, max_ch = scales[scale]
+        nc = d["nc"]
+        if d.get("activation"):
+            raise NotImplementedError("custom activation (tasks.py:956-957) is not accelerated")
+        legacy = True
+        outs: List = []   # per layer: T, or list[T] for a lazy Concat
+        chans: List[int] = []
+        x = None
+        layers = list(d["backbone"]) + list(d["head"])
+        for i, (f, n, m, args) in enumerate(layers):
+            name = f"model.{i}"
+            args = [nc if a == "nc" else a for a in args]
+            n = max(round(n * depth), 1) if n > 1 else n
+            if f != -1:
+                x = outs[f] if isinstance(f, int) else [x if j == -1 else outs[j] for j in f]
+            if m in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA"):
+                c2 = make_divisible(min(args[0], max_ch) * width, 8)
+                if m == "Conv":
+                    k = args[1] if len(args) > 1 else 1
+                    s = args[2] if len(args) > 2 else 1
+                    if i == 0:
+                        y = self.conv_first(name, c2, k, s)
+                    else:
+                        assert isinstance(x, T)
+                        y = self.conv(name, x, c2, k, s)
+                elif m == "C3k2":
+                    legacy = False
+                    c3k = bool(args[1]) if len(args) > 1 else False
+                    e = args[2] if len(args) > 2 else 0.5
+                    if scale and scale in "mlx":
+                        c3k = True
+                    y = self.c2f(name, x, c2, n, True, e, "c3k" if c3k else "bottleneck")
+                elif m == "C2f":
+                    shortcut = bool(args[1]) if len(args) > 1 else False
+                    y = self.c2f(name, x, c2, n, shortcut, 0.5, "c2f")
+                elif m == "SPPF":
+                    assert isinstance(x, T) and (len(args) < 2 or args[1] == 5)
+                    y = self.sppf(name, x, c2)
+                else:
+                    assert isinstance(x, T)
+                    y = self.c2psa(name, x, c2, n)
+                cout = c2
+            elif m == "nn.Upsample":
+                assert isinstance(x, T) and not x.up and args[1] == 2 and args[2] == "nearest"
+                y = T(x.buf, x.ld, x.coff, x.C, x.H * 2, x.W * 2, True)
+                cout = x.C
+            elif m == "Concat":
+                assert isinstance(x, list) and len(x) == 2 and all(isinstance(t, T) for t in x), \
+                    "only two-operand Concat feeding a conv is accelerated"
+                y = list(x)
+                cout = sum(t.C for t in x)
+            elif m in ("Detect", "Segment"):
+                xs = x if isinstance(x, list) else [x]
+                assert all(isinstance(t, T) for t in xs)
+                if m == "Segment":
+                    raise NotImplementedError("Segment head: next round (SURVEY 8 a10)")
+                self.detect(name, xs, args[0], legacy)
+                y, cout = None, 0
+            else:
+                raise NotImplementedError(f"module {m} is not on the accelerated path")
+            outs.append(y)
+            chans.append(cout)
+            x = y
+        self.layer_out = outs
+        self.meta.update(scale=scale, n_layers=len(layers), legacy=legacy)
+
+    # ---- serialisation ------------------------------------------------------------------------------------------
+    def c_ops(self):
+        arr = (L.Op * len(self.ops))()
+        for o, d in zip(arr, self.ops):
+            def v(t):
+                return L.View(*(t.view() if t is not None else L.NO_VIEW))
+            o.kind = d["kind"]
+            o.B, o.H, o.W, o.OH, o.OW = self.B, d["H"], d["W"], d["OH"], d["OW"]
+            o.src0, o.src1 = v(d.get("src0")), v(d.get("src1"))
+            o.up0 = int(bool(d.get("src0") and d["src0"].up))
+            o.up1 = int(bool(d.get("src1") and d["src1"].up))
+            o.dst, o.res = v(d.get("dst")), v(d.get("res"))
+            o.ksize, o.stride, o.pad = d.get("ksize", 0), d.get("stride", 0), d.get("pad", 0)
+            o.act, o.out_f32 = d.get("act", 0), d.get("out_f32", 0)
+            o.dst_scale, o.dst_dy, o.dst_dx = d.get("dst_scale", 1), d.get("dst_dy", 0), d.get("dst_dx", 0)
+            if "wkey" in d:
+                w = self.wrecs[d["wkey"]]
+                assert w.w_off >= 0, "pack weights before serialising"
+                o.w_off, o.b_off = w.w_off, w.b_off
+            o.heads, o.key_dim, o.head_dim, o.scale = d.get("heads", 0), d.get("key_dim", 0), d.get("head_dim", 0), \
+                d.get("scale", 0.0)
+            o.nl, o.nc, o.nm, o.A = d.get("nl", 0), d.get("nc", 0), d.get("nm", 0), d.get("A", 0)
+            for j in range(3):
+                o.box[j] = v(d["box"][j] if j < len(d.get("box", [])) else None)
+                o.cls[j] = v(d["cls"][j] if j < len(d.get("cls", [])) else None)
+                o.msk[j] = v(d["msk"][j] if j < len(d.get("msk", [])) else None)
+                o.lvl_h[j] = d["lvl_h"][j] if j < len(d.get("lvl_h", [])) else 0
+                o.lvl_w[j] = d["lvl_w"][j] if j < len(d.get("lvl_w", [])) else 0
+                o.lvl_stride[j] = d["lvl_stride"][j] if j < len(d.get("lvl_stride", [])) else 0.0
+            o.in_dtype, o.out_dtype, o.level = d.get("in_dtype", 0), d.get("out_dtype", 0), d.get("level", 0)
+        return arr

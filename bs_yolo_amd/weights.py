@@ -1,0 +1,127 @@
+"""Weight preparation: BN folding + packing into the engine's device blob.
+
+  * fold_conv_bn  -- the arithmetic of utils/torch_utils.py:242-269 fuse_conv_and_bn (called per Conv by
+                     BaseModel.fuse, nn/tasks.py:209-215): W' = diag(g / sqrt(var + eps)) W,  b' = beta - g mu / sqrt(var + eps).
+                     Accepts either an un-fused state_dict (conv.weight + bn.*) or an already fused one
+                     (conv.weight + conv.bias), which is what a reference model holds after AutoBackend's fuse().
+  * pack layouts  -- conv   : fp16 [CoutPad128][Kpad32], K order (kh, kw, cin)  (conv_mfma.hip), bias fp32 [CoutPad128]
+                     first  : fp32 [k*k*3][Cout] tap-major (conv_first.hip)
+                     dw     : fp32 [9][C] (elementwise.hip)
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping
+
+import numpy as np
+import torch
+
+from .plan import Plan, WRec
+
+BN_EPS = 1e-3  # utils/torch_utils.py:424
+
+
+def _f32(t) -> torch.Tensor:
+    return torch.as_tensor(t).detach().to("cpu", torch.float32)
+
+
+def fold_conv_bn(sd: Mapping[str, torch.Tensor], prefix: str, eps: float = BN_EPS):
+    """(weight, bias) fp32 of `prefix` (a reference Conv module) with BatchNorm folded in."""
+    w = _f32(sd[prefix + ".conv.weight"])
+    if prefix + ".bn.weight" in sd:
+        g, beta = _f32(sd[prefix + ".bn.weight"]), _f32(sd[prefix + ".bn.bias"])
+        mu, var = _f32(sd[prefix + ".bn.running_mean"]), _f32(sd[prefix + ".bn.running_var"])
+        scale = g / torch.sqrt(var + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = beta - g * mu / torch.sqrt(var + eps)
+        if prefix + ".conv.bias" in sd:
+            b = b + scale * _f32(sd[prefix + ".conv.bias"])
+    else:
+        b = _f32(sd[prefix + ".conv.bias"])
+    return w, b
+
+
+def _align(n: int, a: int = 256) -> int:
+    return (n + a - 1) // a * a
+
+
+def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
+    """-> (weight bytes, bias bytes) for one op."""
+    if r.kind == "plain":
+        w, b = _f32(sd[r.name + ".weight"]), _f32(sd[r.name + ".bias"])
+    else:
+        w, b = fold_conv_bn(sd, r.name, eps)
+    if r.kind in ("conv", "plain"):
+        cout, cin, k = r.cout, r.cin, r.k
+        assert tuple(w.shape) == (cout, cin, k, k), (r.name, tuple(w.shape), (cout, cin, k, k))
+        if r.perm is not None:
+            idx = torch.as_tensor(r.perm, dtype=torch.long)
+            w, b = w[idx], b[idx]
+        K = k * k * cin
+        cp, kp = (cout + 127) // 128 * 128, (K + 31) // 32 * 32
+        wp = torch.zeros(cp, kp, dtype=torch.float16)
+        wp[:cout, :K] = w.permute(0, 2, 3, 1).reshape(cout, K).to(torch.float16)
+        bp = torch.zeros(cp, dtype=torch.float32)
+        bp[:cout] = b
+        return wp.numpy().tobytes(), bp.numpy().tobytes()
+    if r.kind == "first":
+        assert tuple(w.shape) == (r.cout, 3, r.k, r.k), (r.name, tuple(w.shape))
+        wp = w.permute(2, 3, 1, 0).reshape(r.k * r.k * 3, r.cout).contiguous()
+        return wp.numpy().tobytes(), b.contiguous().numpy().tobytes()
+    if r.kind == "dw":
+        assert tuple(w.shape) == (r.cout, 1, 3, 3), (r.name, tuple(w.shape))
+        wp = w.view(r.cout, 9).t().contiguous()
+        return wp.numpy().tobytes(), b.contiguous().numpy().tobytes()
+    raise ValueError(r.kind)
+
+
+def pack_plan_weights(plan: Plan, sd: Mapping[str, torch.Tensor], eps: float = BN_EPS) -> bytes:
+    """Packs every record of `plan` (sets w_off / b_off on the records) -> host blob."""
+    chunks, off = [], 0
+    for r in plan.wrecs.values():
+        wb, bb = pack_record(sd, r, eps)
+        r.w_off = off
+        chunks.append(wb)
+        pad = _align(len(wb)) - len(wb)
+        chunks.append(b"\0" * pad)
+        off += len(wb) + pad
+        r.b_off = off
+        chunks.append(bb)
+        pad = _align(len(bb)) - len(bb)
+        chunks.append(b"\0" * pad)
+        off += len(bb) + pad
+    return b"".join(chunks)
+
+
+def adopt_offsets(plan: Plan, packed: Plan) -> None:
+    """Copy blob offsets from an already packed plan of the same model (other input shape)."""
+    for k, r in plan.wrecs.items():
+        src = packed.wrecs[k]
+        assert (src.kind, src.cout, src.cin, src.k) == (r.kind, r.cout, r.cin, r.k)
+        r.w_off, r.b_off = src.w_off, src.b_off
+
+
+def synth_state_dict(plan: Plan, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded random parameters for benchmarking without a checkpoint (no weights ship with the reference:
+    .MISSING_LARGE_BLOBS).  He-normal conv weights, randomised BN statistics, class bias shifted negative so that
+    O(1 %) of the anchors pass conf 0.25."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for r in plan.wrecs.values():
+        if r.kind == "plain":
+            fan = r.cin * r.k * r.k
+            sd[r.name + ".weight"] = torch.randn(r.cout, r.cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
+            if ".cv3." in r.name:
+                sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) - 6.5
+            elif ".cv2." in r.name:
+                sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) + 0.5
+            else:
+                sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) * 0.4 - 0.2
+            continue
+        cin = 1 if r.kind == "dw" else r.cin
+        fan = cin * r.k * r.k
+        sd[r.name + ".conv.weight"] = torch.randn(r.cout, cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
+        sd[r.name + ".bn.weight"] = torch.rand(r.cout, generator=g) * 0.6 + 0.7
+        sd[r.name + ".bn.bias"] = torch.rand(r.cout, generator=g) * 0.6 - 0.3
+        sd[r.name + ".bn.running_mean"] = torch.rand(r.cout, generator=g) * 0.6 - 0.3
+        sd[r.name + ".bn.running_var"] = torch.rand(r.cout, generator=g) + 0.5
+    return sd

@@ -1,0 +1,182 @@
+/*
+ * bsyolo.h -- C ABI of libbsyolo_hip.so, the MI355X (gfx950) YOLO detection forward path.
+ *
+ * Drop-in boundary for feiyeha/BS-YOLO (Ultralytics 8.3.56 fork, pure Python/PyTorch).  The reference has no
+ * native code on this path, so there is no existing FFI to mirror; each entry point below names the reference
+ * Python interface it replaces (paths relative to /root/reference/ultralytics).  All pointers are raw device
+ * pointers unless marked HOST; no torch types cross this boundary.  Every function returns 0 on success or a
+ * negative bsy_status; bsy_last_error() returns a thread-local message.  No function synchronises the stream
+ * or allocates user-visible memory (engine/plan handles own their weights and workspace).
+ *
+ * Activation layout inside the library is NHWC fp16 ("pixel rows of channels"); the boundary tensors keep the
+ * reference's layouts: input image BCHW (fp16/fp32), prediction (B, 4+nc+nm, A) channel-major, raw feature maps
+ * BCHW, detections (B, max_det, 6+nm) row-major.
+ */
+#ifndef BSYOLO_H
+#define BSYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bsy_stream; /* hipStream_t */
+
+enum bsy_status {
+    BSY_OK = 0,
+    BSY_ERR_ARG = -1,     /* bad argument / unsupported shape */
+    BSY_ERR_HIP = -2,     /* a HIP runtime call failed        */
+    BSY_ERR_ALLOC = -3,   /* device allocation failed         */
+    BSY_ERR_STATE = -4    /* call order (e.g. weights not loaded) */
+};
+
+enum bsy_dtype { BSY_F16 = 0, BSY_F32 = 1, BSY_U8 = 2 };
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Graph engine: replaces BaseModel._predict_once (nn/tasks.py:138-165) + the forward of every module on the
+ * path (nn/modules/conv.py:133-151,224-229,445-455; block.py:58-97,3114-3149,3295-3334,3405-3419,3796-3815,
+ * 4235-4288,4348-4383,4429-4468; head.py:21-197) for a model already parsed by the host side into a flat
+ * list of device ops (bs_yolo_amd/plan.py).  Hook on the reference side: AutoBackend's in-memory nn.Module
+ * branch, nn/autobackend.py:136-147 / :524.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct bsy_engine bsy_engine;
+typedef struct bsy_plan bsy_plan;
+
+/* A view of `C` channels starting at channel `coff` inside an NHWC buffer whose pixel rows have `ld` channels.
+ * buf <  BSY_EXT_BASE : index into the plan's workspace buffers
+ * buf >= BSY_EXT_BASE : external pointer slot (buf - BSY_EXT_BASE) supplied to bsy_plan_run
+ * buf <  0            : absent                                                                          */
+#define BSY_EXT_BASE 0x100000
+typedef struct bsy_view {
+    int32_t buf, ld, coff, C;
+} bsy_view;
+
+enum bsy_op_kind {
+    BSY_OP_CONV_FIRST = 0, /* image (BCHW f16/f32, C=3) -> conv kxk s2 + bias + act -> NHWC f16            */
+    BSY_OP_CONV = 1,       /* implicit-GEMM conv k in {1,3}, s in {1,2}, MFMA f16, fused bias/SiLU/residual   */
+    BSY_OP_DWCONV = 2,     /* depthwise 3x3 s1 + bias (+SiLU) (+residual)                                     */
+    BSY_OP_SPPF_POOL = 3,  /* three chained MaxPool2d(5,1,2) -> channel slices of the SPPF concat buffer      */
+    BSY_OP_ATTN = 4,       /* softmax(q^T k * scale) v, per (image, head); MFMA flash-style                   */
+    BSY_OP_DECODE = 5,     /* Detect._inference: DFL + dist2bbox + sigmoid -> (B, 4+nc+nm, A)                 */
+    BSY_OP_RAW_NCHW = 6    /* raw per-level head maps NHWC f32 -> BCHW (the `x` list Detect.forward returns)  */
+};
+
+typedef struct bsy_op {
+    int32_t kind;
+    int32_t B, H, W;        /* logical input height/width (after any folded upsample) */
+    int32_t OH, OW;
+    bsy_view src0, src1;    /* src1: second concat operand (virtual Concat), buf<0 if none */
+    int32_t up0, up1;       /* 1: that source is stored at (H/2, W/2) and read through nearest-x2 (virtual Upsample) */
+    bsy_view dst;           /* dst.C = Cout */
+    bsy_view res;           /* residual added AFTER the activation (Bottleneck / PSABlock shortcut); buf<0 if none */
+    int32_t ksize, stride, pad;
+    int32_t act;            /* 0 identity, 1 SiLU */
+    int32_t out_f32;        /* dst holds f32 instead of f16 (final head convs) */
+    int32_t dst_scale, dst_dy, dst_dx; /* ConvTranspose2d(2,2,s2) as 4 scattered 1x1 convs: out pixel (s*oh+dy, s*ow+dx); scale 1 = plain */
+    int64_t w_off, b_off;   /* byte offsets into the engine's weight blob (packed f16 weights / f32 bias) */
+    int32_t heads, key_dim, head_dim; /* ATTN */
+    float scale;            /* ATTN softmax scale */
+    /* DECODE / RAW_NCHW: per-level inputs */
+    int32_t nl, nc, nm, A;  /* levels, classes, mask coeffs, total anchors */
+    bsy_view box[3], cls[3], msk[3];
+    int32_t lvl_h[3], lvl_w[3];
+    float lvl_stride[3];
+    int32_t in_dtype, out_dtype; /* CONV_FIRST input dtype; DECODE/RAW output dtype */
+    int32_t level;          /* RAW_NCHW: which level; output = external slot in dst.buf */
+    int32_t reserved[8];
+} bsy_op;
+
+int bsy_engine_create(int device, bsy_engine** out);
+void bsy_engine_destroy(bsy_engine* e);
+/* HOST blob: packed weights produced by bs_yolo_amd/weights.py (BN already folded: replaces
+ * utils/torch_utils.py:242-269 fuse_conv_and_bn as called from nn/tasks.py:209-215).  Copied to the device. */
+int bsy_engine_load_weights(bsy_engine* e, const void* host_blob, size_t bytes);
+
+/* ops: HOST array; buf_bytes: HOST array of workspace buffer sizes.  The plan owns its workspace. */
+int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, const int64_t* buf_bytes, int n_bufs, bsy_plan** out);
+void bsy_plan_destroy(bsy_plan* p);
+/* ext: HOST array of n_ext device pointers bound to the external slots (input image, y, raw maps ...). */
+int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
+/* Debug/test aid: synchronous copy of one workspace buffer to HOST memory (bytes <= the buffer's size). */
+int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes);
+/* Per-op device time of the last bsy_plan_profile call (ms, HIP events on `stream`); runs the plan once, syncs. */
+int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, float* ms_per_op /* n_ops */);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stand-alone operators (same kernels the engine launches), for per-module hooks and parity tests.
+ * --------------------------------------------------------------------------------------------------------- */
+
+/* Conv.forward_fuse (nn/modules/conv.py:149-151): y = act(conv2d(x, w) + b) [+ res], NHWC f16 in/out.
+ * x: (B,H,W,ldx) view of C1 channels; w: packed [CoutPad][Kpad] f16 (bsy_pack_conv_weight layout);
+ * b: f32 [CoutPad]; y: (B,OH,OW,ldy); res same geometry as y or NULL. */
+int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, const void* w, const float* b, void* y, int ldy,
+               int C2, int ksize, int stride, int act, const void* res, int ldr, int y_f32, bsy_stream stream);
+/* Packed sizes for a (C2, C1, k, k) conv: rows padded to 128 output channels, K = k*k*C1 padded to 32. */
+int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, int* k_pad);
+
+/* First conv from a BCHW image (f16 or f32): w f32 [k*k*3][C2] (tap-major), b f32 [C2] -> NHWC f16. */
+int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b, void* y,
+                   int ldy, int C2, int ksize, int stride, int act, bsy_stream stream);
+
+/* DWConv (conv.py:224-229) 3x3 s1: w f32 [9][C], b f32 [C]. */
+int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y, int ldy,
+                  int act, const void* res, int ldr, bsy_stream stream);
+
+/* SPPF pooling (block.py:3145-3149): x1 = buf[..., 0:C]; writes m(x1), m(m(x1)), m(m(m(x1))) to channel slices
+ * [C:2C], [2C:3C], [3C:4C] of the same NHWC buffer (ld >= 4C). */
+int bsy_sppf_pool(void* buf, int ld, int B, int H, int W, int C, bsy_stream stream);
+
+/* Attention core (block.py:4267-4286): qkv NHWC f16 with channel order [q(all heads) | k(all heads) | v(all heads)],
+ * out[pixel][head*head_dim + d] = sum_j softmax_j(q_i . k_j * scale) v_j[d].  key_dim must be 32, head_dim 64. */
+int bsy_attention(const void* qkv, int ld, int B, int N, int heads, int key_dim, int head_dim, float scale, void* out,
+                  int ldo, bsy_stream stream);
+
+/* Detect._inference (head.py:100-131) + DFL (block.py:58-77) + make_anchors/dist2bbox (utils/tal.py:371-395).
+ * box[l]: f32 (B*h*w, ldb) 64 DFL logits; cls[l]: f32 (B*h*w, ldc) nc logits; msk[l]: f32 nm coeffs or NULL.
+ * y: (B, 4+nc+nm, A) of y_dtype. */
+int bsy_detect_decode(const float* const* box, const int* ldb, const float* const* cls, const int* ldc,
+                      const float* const* msk, const int* ldm, const int* lvl_h, const int* lvl_w,
+                      const float* lvl_stride, int nl, int B, int nc, int nm, void* y, int y_dtype, bsy_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * non_max_suppression (utils/ops.py:167-316) incl. xywh2xyxy (:416-433) and the greedy IoU suppression the
+ * reference delegates to torchvision.ops.nms (:296).  One call handles the whole batch with no host sync.
+ *   pred      : (B, 4+nc+nm, A) f16/f32, xywh boxes; when in_place != 0 channels 0..3 are rewritten as xyxy
+ *               exactly as the reference mutates its input (:243-244)
+ *   classes   : optional DEVICE int32 list of class ids to keep (:278-279), n_classes = 0 -> all
+ *   out       : (B, max_det, 6+nm) f32 rows [x1,y1,x2,y2,conf,cls,masks...], rows >= counts[b] are zero
+ *   counts    : (B) int32 kept detections per image
+ *   workspace : DEVICE scratch of at least bsy_nms_workspace_bytes(...) bytes
+ * Arithmetic is fp32 whatever the input dtype (matches the fp32 CPU reference); ties in score are broken by
+ * ascending candidate index.  The reference's wall-clock bail-out (:238,:312-314) is deliberately absent.
+ * --------------------------------------------------------------------------------------------------------- */
+size_t bsy_nms_workspace_bytes(int B, int A, int nc, int multi_label, int max_nms);
+int bsy_nms(void* pred, int pred_dtype, int B, int nc, int nm, int A, float conf_thres, float iou_thres,
+            const int32_t* classes, int n_classes, int agnostic, int multi_label, int max_det, int max_nms,
+            float max_wh, int in_place, float* out, int32_t* counts, void* workspace, size_t workspace_bytes,
+            bsy_stream stream);
+
+/* scale_boxes + clip_boxes (utils/ops.py:92-127, :319-337) applied to all rows of `out` in place:
+ * per image b: gain[b], pad_x[b], pad_y[b] (HOST-computed with Python round()), orig shape (h0[b], w0[b]). */
+int bsy_scale_boxes(float* det, const int32_t* counts, int B, int max_det, int row, const float* gain,
+                    const float* pad_x, const float* pad_y, const float* h0, const float* w0, bsy_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LetterBox + BasePredictor.preprocess (data/augment.py:1535-1601, engine/predictor.py:116-134): device images
+ * (HWC BGR u8, each with its own (h,w)) -> one (B,3,H2,W2) RGB tensor scaled by 1/255.
+ *   imgs      : DEVICE array of B device pointers;  hw: DEVICE int32 (B,2)
+ *   geom      : DEVICE int32 (B,4) = new_unpad_w, new_unpad_h, left, top  (HOST-computed with Python round())
+ * Bilinear arithmetic is OpenCV's 8-bit fixed point (INTER_LINEAR) incl. the exact-2x box shortcut.
+ * --------------------------------------------------------------------------------------------------------- */
+int bsy_letterbox(const uint8_t* const* imgs, const int32_t* hw, const int32_t* geom, int B, int H2, int W2, void* out,
+                  int out_dtype, bsy_stream stream);
+
+const char* bsy_last_error(void);
+int bsy_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSYOLO_H */

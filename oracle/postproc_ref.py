@@ -65,7 +65,7 @@ def xywh2xyxy(x):  # utils/ops.py:416-433
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
                         multi_label=False, max_det=300, nc=0, max_nms=30000, max_wh=7680, in_place=True,
-                        nms_fn=greedy_nms):
+                        nms_fn=greedy_nms, boxes_xyxy=False):
     """utils/ops.py:167-316 without the wall-clock bail-out (:238,:312-314)."""
     assert 0 <= conf_thres <= 1 and 0 <= iou_thres <= 1
     if isinstance(prediction, (list, tuple)):
@@ -79,7 +79,9 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     xc = prediction[:, 4:mi].amax(1) > conf_thres
     multi_label &= nc > 1
     prediction = prediction.transpose(-1, -2)
-    if in_place:
+    if boxes_xyxy:  # test hook: the caller already converted the boxes (fp16 parity case)
+        pass
+    elif in_place:
         prediction[..., :4] = xywh2xyxy(prediction[..., :4])
     else:
         prediction = torch.cat((xywh2xyxy(prediction[..., :4]), prediction[..., 4:]), dim=-1)

@@ -1,0 +1,438 @@
+"""GPU parity: every HIP kernel, called through the C ABI (libbsyolo_hip.so), against the CPU oracle.
+
+Run on the MI355X box with ``pytest -m gpu``.  Float kernels: tolerance stated per test (fp16 storage, fp32
+accumulation).  Integer / control-flow work (NMS decisions, letterbox pixels) is compared bit-exactly.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from bs_yolo_amd import lib as L  # noqa: F401  (fails loudly when the .so is missing)
+    from bs_yolo_amd import letterbox as HLB
+    from bs_yolo_amd import nms as HN
+    from bs_yolo_amd import ops as O
+    from bs_yolo_amd.engine import YoloEngine
+    from bs_yolo_amd.graphs import stock_cfg
+
+from oracle import letterbox_ref as LB
+from oracle import postproc_ref as PP
+from oracle import yolo_ref as R
+
+DEV = "cuda:0"
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def h16(t):
+    """fp16-round a fp32 tensor (what the kernels see)."""
+    return t.half().float()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# implicit-GEMM conv (conv_mfma.hip)
+# ------------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, W, cin, cout, k, s, act, res, f32
+    (2, 12, 10, 16, 32, 1, 1, True, False, False),
+    (2, 12, 10, 16, 24, 3, 1, True, False, False),
+    (1, 13, 11, 8, 16, 3, 2, True, False, False),      # odd extents, thin K (Cin=8 -> K=72)
+    (2, 20, 20, 64, 64, 3, 1, True, True, False),      # Bottleneck.cv2 with shortcut
+    (2, 16, 16, 96, 128, 1, 1, True, False, False),    # C3k2.cv2 over a 3-way cat
+    (1, 40, 40, 128, 256, 3, 2, True, False, False),   # stride-2 downsample, 2 cout tiles
+    (3, 9, 7, 32, 80, 1, 1, False, False, True),       # Detect cls conv: nc=80, bias, fp32 out, no act
+    (2, 8, 8, 64, 5, 1, 1, False, False, True),        # nc=5: ragged cout (not a multiple of 4)
+    (1, 7, 5, 256, 512, 1, 1, True, False, False),     # 4 cout tiles, tiny M
+    (2, 33, 31, 32, 64, 3, 1, True, False, False),     # M tail inside a 256-pixel tile
+    (1, 20, 20, 512, 256, 3, 1, True, True, False),    # deep K = 4608
+    (2, 10, 10, 16, 16, 3, 1, True, True, False),      # yolo11n bottleneck widths
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_oracle(case):
+    B, H, W, cin, cout, k, s, act, use_res, f32 = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = h16(torch.randn(B, cin, H, W, generator=g))
+    w = h16(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.5
+    y = F.conv2d(x, w, b, s, k // 2)
+    if act:
+        y = F.silu(y)
+    res = None
+    if use_res:
+        res = h16(torch.randn(y.shape, generator=g))
+        y = y + res
+    wp, bp = O.pack_conv_weight(w, b, DEV)
+    out = O.conv2d_nhwc(nhwc(x).half().to(DEV), wp, bp, cout, k, s, act,
+                        res=nhwc(res).half().to(DEV) if use_res else None, out_f32=f32)
+    torch.cuda.synchronize()
+    got = nchw(out[..., :cout].float().cpu())
+    # fp16 operands are exact on both sides; differences = fp32 summation order (+ one fp16 rounding of the output)
+    tol = dict(rtol=1e-4, atol=1e-4) if f32 else dict(rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(got.numpy(), y.numpy(), **tol)
+
+
+def test_conv_two_sources_and_upsample():
+    """Virtual Concat + virtual nn.Upsample: cv1(cat(upsample(a), b)) (yolo11 head layers 11-13)."""
+    g = torch.Generator().manual_seed(3)
+    a = h16(torch.randn(2, 64, 5, 6, generator=g))
+    b = h16(torch.randn(2, 32, 10, 12, generator=g))
+    w = h16(torch.randn(48, 96, 1, 1, generator=g) * 0.15)
+    bias = torch.randn(48, generator=g) * 0.1
+    ref = F.silu(F.conv2d(torch.cat((F.interpolate(a, scale_factor=2.0, mode="nearest"), b), 1), w, bias))
+    # through the engine's op interface: a tiny hand-built plan
+    import ctypes as C
+    from bs_yolo_amd import lib as L
+    wp, bp = O.pack_conv_weight(w, bias, "cpu")
+    blob = wp.numpy().tobytes()
+    boff = (len(blob) + 255) // 256 * 256
+    blob = blob + b"\0" * (boff - len(blob)) + bp.numpy().tobytes()
+    eng = C.c_void_p()
+    L.check(L.lib.bsy_engine_create(0, C.byref(eng)))
+    L.check(L.lib.bsy_engine_load_weights(eng, (C.c_char * len(blob)).from_buffer_copy(blob), len(blob)))
+    op = L.Op()
+    op.kind = L.OP_CONV
+    op.B, op.H, op.W, op.OH, op.OW = 2, 10, 12, 10, 12
+    op.src0, op.src1 = L.View(L.BSY_EXT_BASE + 0, 64, 0, 64), L.View(L.BSY_EXT_BASE + 1, 32, 0, 32)
+    op.up0, op.up1 = 1, 0
+    op.dst, op.res = L.View(L.BSY_EXT_BASE + 2, 48, 0, 48), L.View(*L.NO_VIEW)
+    op.ksize, op.stride, op.pad, op.act, op.out_f32, op.dst_scale = 1, 1, 0, 1, 0, 1
+    op.w_off, op.b_off = 0, boff
+    plan = C.c_void_p()
+    L.check(L.lib.bsy_plan_create(eng, (L.Op * 1)(op), 1, None, 0, C.byref(plan)))
+    ta, tb = nhwc(a).half().to(DEV), nhwc(b).half().to(DEV)
+    out = torch.zeros(2, 10, 12, 48, dtype=torch.float16, device=DEV)
+    ext = (C.c_void_p * 3)(ta.data_ptr(), tb.data_ptr(), out.data_ptr())
+    L.check(L.lib.bsy_plan_run(plan, ext, 3, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    L.lib.bsy_plan_destroy(plan)
+    L.lib.bsy_engine_destroy(eng)
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_conv_rejects_bad_arguments():
+    x = torch.zeros(1, 4, 4, 12, dtype=torch.float16, device=DEV)  # 12 channels: not a multiple of 8
+    wp, bp = O.pack_conv_weight(torch.zeros(8, 12, 1, 1), torch.zeros(8), DEV)
+    with pytest.raises(L.BsyError, match="multiples of 8"):
+        O.conv2d_nhwc(x, wp, bp, 8, 1)
+    x = torch.zeros(1, 4, 4, 16, dtype=torch.float16, device=DEV)
+    wp, bp = O.pack_conv_weight(torch.zeros(8, 16, 5, 5)[:, :, :1, :1], torch.zeros(8), DEV)
+    with pytest.raises(L.BsyError, match="ksize"):
+        O.conv2d_nhwc(x, wp, bp, 8, 5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_conv_first_matches_oracle(dtype):
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(2, 3, 64, 96, generator=g)
+    img = img.half().float() if dtype == torch.float16 else img
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(32, generator=g) * 0.2
+    ref = F.silu(F.conv2d(img, w, b, 2, 1))
+    out = O.conv_first(img.to(dtype).to(DEV), w, b)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("act,use_res", [(True, False), (False, True)])
+def test_dwconv_matches_oracle(act, use_res):
+    g = torch.Generator().manual_seed(5)
+    x = h16(torch.randn(2, 64, 9, 7, generator=g))
+    w = torch.randn(64, 1, 3, 3, generator=g) * 0.4
+    b = torch.randn(64, generator=g) * 0.2
+    ref = F.conv2d(x, w, b, 1, 1, 1, 64)
+    if act:
+        ref = F.silu(ref)
+    res = h16(torch.randn(ref.shape, generator=g)) if use_res else None
+    if use_res:
+        ref = ref + res
+    out = O.dwconv3x3_nhwc(nhwc(x).half().to(DEV), w, b, act, nhwc(res).half().to(DEV) if use_res else None)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_sppf_pool_exact():
+    g = torch.Generator().manual_seed(6)
+    x1 = h16(torch.randn(2, 32, 20, 13, generator=g))
+    y = [x1]
+    for _ in range(3):
+        y.append(F.max_pool2d(y[-1], 5, 1, 2))
+    ref = torch.cat(y, 1)
+    out = O.sppf_pool_nhwc(nhwc(x1).half().to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(out.float().cpu()), ref)  # max of fp16 values is exact
+
+
+@pytest.mark.parametrize("B,heads,N", [(2, 2, 100), (1, 4, 400), (1, 2, 37)])
+def test_attention_matches_oracle(B, heads, N):
+    kd, hd = 32, 64
+    g = torch.Generator().manual_seed(7)
+    q = h16(torch.randn(B, heads, kd, N, generator=g))
+    k = h16(torch.randn(B, heads, kd, N, generator=g))
+    v = h16(torch.randn(B, heads, hd, N, generator=g))
+    scale = kd ** -0.5
+    attn = ((q.transpose(-2, -1) @ k) * scale).softmax(-1)      # block.py:4284-4285
+    ref = (v @ attn.transpose(-2, -1)).reshape(B, heads * hd, N)  # (B, C, N)
+    qkv = torch.cat((q.reshape(B, heads * kd, N), k.reshape(B, heads * kd, N), v.reshape(B, heads * hd, N)), 1)
+    out = O.attention_nhwc(qkv.transpose(1, 2).contiguous().half().to(DEV), heads, kd, hd, scale)
+    torch.cuda.synchronize()
+    got = out.float().cpu().transpose(1, 2)
+    # P is rounded to fp16 before the PV product (like any fp16 attention): 2^-11 relative on the weights
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
+
+
+def test_detect_decode_golden():
+    z = np.load(GOLDEN / "modules.npz")
+    raws = [torch.from_numpy(z[f"decode.raw{i}"]) for i in range(3)]  # (2, 69, h, w): 64 box + 5 cls
+    box = [nhwc(r[:, :64]).reshape(-1, 64).contiguous().to(DEV) for r in raws]
+    cls = [F.pad(nhwc(r[:, 64:]).reshape(-1, 5), (0, 3)).contiguous().to(DEV) for r in raws]
+    hw = [tuple(r.shape[2:]) for r in raws]
+    y = O.detect_decode(box, cls, hw, [8.0, 16.0, 32.0], 5, torch.float32)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().numpy(), z["decode.y"], rtol=1e-5, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# whole graph through the engine
+# ------------------------------------------------------------------------------------------------------------
+def _engine_vs_oracle(tag, dtype):
+    z = np.load(GOLDEN / f"graph_{tag}.npz")
+    meta = json.loads(str(z["meta"]))
+    m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
+    P = R.synth_params(m, meta["seed"])
+    eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), P)
+    stats = []
+    si = 0
+    while f"x{si}" in z:
+        x = torch.from_numpy(z[f"x{si}"])
+        y, raws = eng(x.to(dtype).to(DEV))
+        torch.cuda.synchronize()
+        stats.append((y.float().cpu().numpy(), z[f"y{si}"], [r.float().cpu().numpy() for r in raws],
+                      [z[f"raw{si}_{l}"] for l in range(3)], x.shape))
+        si += 1
+    eng.close()
+    return stats
+
+
+@pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect"])
+def test_engine_matches_reference_golden(tag):
+    """Engine (fp16 activations, fp32 accumulate, fp32 head/decoder) vs the REFERENCE's own fp32 CPU outputs.
+    Tolerance: scores within 5e-3 absolute, boxes within 5e-3 of the image size (see DESIGN.md 'Parity')."""
+    for y, yref, raws, rawref, shape in _engine_vs_oracle(tag, torch.float32):
+        size = float(max(shape[2], shape[3]))
+        assert np.abs(y[:, 4:] - yref[:, 4:]).max() < 5e-3
+        assert np.abs(y[:, :4] - yref[:, :4]).max() / size < 5e-3
+        for r, rr in zip(raws, rawref):
+            scale = np.abs(rr).max()
+            assert np.abs(r - rr).max() / scale < 2e-2
+
+
+def test_engine_batch_independence_and_determinism():
+    """Images are independent units: a batch equals its images run one by one; reruns are bit-identical."""
+    m = R.Model("yolo11", "n", 80, "detect")
+    P = R.synth_params(m, 0)
+    eng = YoloEngine(stock_cfg("yolo11", "n"), P)
+    x = torch.rand(3, 3, 96, 64, generator=torch.Generator().manual_seed(1)).half().to(DEV)
+    y, _ = eng(x)
+    y2, _ = eng(x)
+    assert torch.equal(y, y2)
+    for i in range(3):
+        yi, _ = eng(x[i:i + 1])
+        assert torch.equal(yi[0], y[i])
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# NMS: bit-exact against the oracle (and the reference's golden outputs)
+# ------------------------------------------------------------------------------------------------------------
+def _nms_compare(pred, kw):
+    ref_in = pred.clone()
+    ref = PP.non_max_suppression(ref_in, **kw)
+    dpred = pred.clone().to(DEV)
+    got = HN.non_max_suppression(dpred, **kw)
+    torch.cuda.synchronize()
+    assert len(got) == len(ref)
+    if kw.get("in_place", True):
+        assert torch.equal(dpred[:, :4].cpu(), ref_in[:, :4])  # same in-place xywh->xyxy mutation
+    for b, (g_, r_) in enumerate(zip(got, ref)):
+        assert tuple(g_.shape) == tuple(r_.shape), (b, g_.shape, r_.shape)
+        assert torch.equal(g_.cpu(), r_), f"image {b}"
+
+
+def test_nms_golden_cases():
+    z = np.load(GOLDEN / "nms.npz")
+    for tag, kw, n_out in json.loads(str(z["cases"])):
+        pred = torch.from_numpy(z[tag + ".pred"].copy())
+        dpred = pred.clone().to(DEV)
+        got = HN.non_max_suppression(dpred, **kw)
+        torch.cuda.synchronize()
+        assert len(got) == n_out
+        assert np.array_equal(dpred[:, :4].cpu().numpy(), z[tag + ".pred_after"]), tag
+        for i, r in enumerate(got):
+            exp = z[f"{tag}.out{i}"]
+            assert tuple(r.shape) == exp.shape, (tag, i, r.shape, exp.shape)
+            assert np.array_equal(r.cpu().numpy(), exp), f"{tag}[{i}]"
+
+
+def _rand_pred(B, nc, A, nm, seed, dup=True):
+    g = torch.Generator().manual_seed(seed)
+    base = max(A // 6, 1)
+    c = torch.rand(B, 2, base, generator=g) * 600 + 20
+    wh = torch.rand(B, 2, base, generator=g) * 120 + 8
+    rep = (A + base - 1) // base
+    box = torch.cat((c, wh), 1).repeat(1, 1, rep)[:, :, :A] + torch.randn(B, 4, A, generator=g) * (3.0 if dup else 50.0)
+    box[:, 2:] = box[:, 2:].abs() + 1
+    cls = torch.rand(B, nc, A, generator=g) ** 4
+    parts = [box, cls] + ([torch.randn(B, nm, A, generator=g)] if nm else [])
+    return torch.cat(parts, 1)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(conf_thres=0.25, iou_thres=0.7),
+    dict(conf_thres=0.001, iou_thres=0.7, multi_label=True),
+    dict(conf_thres=0.3, iou_thres=0.45, agnostic=True, max_det=17),
+    dict(conf_thres=0.2, iou_thres=0.5, classes=[0, 2], in_place=False),
+])
+def test_nms_random_bit_exact(kw):
+    _nms_compare(_rand_pred(3, 12, 3000, 0, 21), kw)
+
+
+def test_nms_edge_cases():
+    _nms_compare(_rand_pred(2, 6, 1, 0, 1), dict(conf_thres=0.0, iou_thres=0.5))        # a single anchor
+    _nms_compare(_rand_pred(2, 6, 257, 0, 2), dict(conf_thres=0.99999, iou_thres=0.5))  # nothing passes
+    p = _rand_pred(1, 3, 600, 0, 3)
+    p[:, 4:] = 0.5                                                                      # every score ties
+    _nms_compare(p, dict(conf_thres=0.25, iou_thres=0.6))
+    p = _rand_pred(1, 2, 900, 0, 4)
+    p[:, :4] = torch.tensor([100.0, 100.0, 50.0, 50.0]).view(1, 4, 1)                   # all boxes identical
+    _nms_compare(p, dict(conf_thres=0.01, iou_thres=0.5, multi_label=True))
+    _nms_compare(_rand_pred(2, 4, 700, 32, 5), dict(conf_thres=0.3, iou_thres=0.7, nc=4))  # mask coefficients ride along
+    with pytest.raises(AssertionError, match="Invalid Confidence"):
+        HN.non_max_suppression(torch.zeros(1, 6, 8, device=DEV), conf_thres=1.5)
+
+
+def test_nms_large_candidate_set_and_cap():
+    """> 8192 candidates (global-memory sort path) and the max_nms cap (ops.py:285-286)."""
+    pred = _rand_pred(2, 10, 8400, 0, 9, dup=False)
+    _nms_compare(pred, dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_nms=30000))
+    _nms_compare(pred, dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_nms=5000))
+
+
+def test_nms_fp16_prediction():
+    """fp16 predictions: boxes are converted in fp16 (as the reference's in-place op does), decisions in fp32."""
+    pred = _rand_pred(2, 12, 2000, 0, 13).half()
+    kw = dict(conf_thres=0.25, iou_thres=0.7)
+    dpred = pred.clone().to(DEV)
+    got = HN.non_max_suppression(dpred, **kw)
+    torch.cuda.synchronize()
+    ref_in = pred.clone()
+    tp = ref_in.transpose(-1, -2)
+    tp[..., :4] = PP.xywh2xyxy(tp[..., :4])  # fp16 arithmetic on the CPU
+    assert torch.equal(dpred[:, :4].cpu(), ref_in[:, :4])
+    ref = PP.non_max_suppression(ref_in.float(), boxes_xyxy=True, **kw)
+    for g_, r_ in zip(got, ref):
+        assert g_.dtype == torch.float16
+        assert torch.equal(g_.float().cpu(), r_.half().float())
+
+
+def test_nms_properties_at_full_size():
+    """BASELINE config sizes (B=64, nc=80, A=8400): size-independent properties instead of an O(n^2) CPU run."""
+    pred = _rand_pred(64, 80, 8400, 0, 17)
+    pred[:, 4:] = pred[:, 4:] ** 3  # ~1-2 % of anchors above 0.25
+    det, counts = HN.nms_batched(pred.to(DEV), 0.25, 0.7)
+    det2, counts2 = HN.nms_batched(pred.to(DEV), 0.25, 0.7)
+    torch.cuda.synchronize()
+    assert torch.equal(det, det2) and torch.equal(counts, counts2)  # deterministic
+    det, counts = det.cpu(), counts.cpu()
+    assert int(counts.max()) <= 300 and int(counts.min()) >= 0
+    for b in range(0, 64, 7):
+        n = int(counts[b])
+        d = det[b, :n]
+        assert torch.all(d[:-1, 4] >= d[1:, 4])            # sorted by confidence
+        assert torch.all(d[:, 4] > 0.25)
+        assert torch.all(det[b, n:] == 0)                   # padding rows are zero
+        off = d[:, :4] + d[:, 5:6] * 7680
+        lt = torch.max(off[:, None, :2], off[None, :, :2])
+        rb = torch.min(off[:, None, 2:], off[None, :, 2:])
+        inter = (rb - lt).clamp(min=0).prod(-1)
+        area = (off[:, 2] - off[:, 0]) * (off[:, 3] - off[:, 1])
+        iou = inter / (area[:, None] + area[None] - inter)
+        iou.fill_diagonal_(0)
+        assert float(iou.max()) <= 0.7                      # survivors of one class do not overlap above the threshold
+        # idempotence: NMS of the survivors keeps all of them
+        again = PP.greedy_nms(off, d[:, 4], 0.7)
+        assert again.tolist() == list(range(n))
+
+
+def test_scale_boxes_matches_oracle():
+    g = torch.Generator().manual_seed(2)
+    B, max_det = 3, 20
+    det = torch.rand(B, max_det, 6, generator=g) * 700 - 30
+    counts = torch.tensor([20, 7, 0], dtype=torch.int32)
+    shapes = [(1080, 810), (720, 1280), (333, 500)]
+    ref = det.clone()
+    for b in range(B):
+        n = int(counts[b])
+        ref[b, :n, :4] = PP.scale_boxes((640, 640), ref[b, :n, :4].clone(), shapes[b])
+    d = det.clone().to(DEV)
+    HN.scale_boxes_batched(d, counts.to(DEV), (640, 640), shapes)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# letterbox: bit-exact pixels against the oracle's OpenCV restatement
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shapes,imgsz", [
+    ([(100, 37), (100, 37)], (160, 160)),          # equal shapes -> auto (minimal rectangle)
+    ([(75, 120), (64, 64), (256, 192)], (128, 128)),  # ragged -> pad to imgsz; 64->128 upscale; exact-2x downscale
+    ([(333, 500)], (160, 224)),
+    ([(1080, 810)], (640, 640)),                   # bus.jpg geometry (BASELINE config 1)
+    ([(720, 1280), (720, 1280)], (640, 640)),
+])
+@pytest.mark.parametrize("half", [False, True])
+def test_letterbox_bit_exact(shapes, imgsz, half):
+    rng = np.random.default_rng(4)
+    ims = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    ref = LB.preprocess(ims, imgsz, half=half)
+    got = HLB.preprocess(ims, imgsz, half=half, device=DEV)
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_letterbox_golden_pixels():
+    z = np.load(GOLDEN / "letterbox.npz")
+    for k, c in enumerate(json.loads(str(z["pixel_cases"]))):
+        kw = dict(c["kw"])
+        new_shape = tuple(kw.pop("new_shape"))
+        img = z[f"img{k}"]
+        lb = HLB.LetterBox(new_shape, **kw)
+        H2, W2, nw, nh, left, top, _ = lb.geometry(img.shape[:2])
+        assert [H2, W2, 3] == list(z[f"lb{k}"].shape)
+        import ctypes as C
+        d = torch.from_numpy(img).to(DEV)
+        ptrs = torch.tensor([d.data_ptr()], dtype=torch.int64, device=DEV)
+        hw = torch.tensor([[img.shape[0], img.shape[1]]], dtype=torch.int32, device=DEV)
+        geom = torch.tensor([[nw, nh, left, top]], dtype=torch.int32, device=DEV)
+        out = torch.empty((1, 3, H2, W2), dtype=torch.float32, device=DEV)
+        L.check(L.lib.bsy_letterbox(C.c_void_p(ptrs.data_ptr()), C.c_void_p(hw.data_ptr()), C.c_void_p(geom.data_ptr()),
+                                    1, H2, W2, C.c_void_p(out.data_ptr()), L.BSY_F32,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        exp = torch.from_numpy(np.ascontiguousarray(z[f"lb{k}"][..., ::-1].transpose(2, 0, 1))).float() / 255
+        assert torch.equal(out[0].cpu(), exp)

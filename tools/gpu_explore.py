@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""GPU-box exploration: per-layer error of the engine vs the oracle, per-op timings, quick throughput number."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from bs_yolo_amd import lib as L  # noqa: E402
+from bs_yolo_amd.engine import YoloEngine  # noqa: E402
+from bs_yolo_amd.graphs import stock_cfg  # noqa: E402
+from oracle import yolo_ref as R  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def per_layer(tag="yolo11n_detect"):
+    z = np.load(ROOT / "tests" / "golden" / f"graph_{tag}.npz")
+    meta = json.loads(str(z["meta"]))
+    m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
+    P = R.synth_params(m, meta["seed"])
+    eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), P)
+    for dt in (torch.float32, torch.float16):
+        x = torch.from_numpy(z["x0"])
+        y, raws = eng(x.to(dt).to(DEV))
+        torch.cuda.synchronize()
+        plan, h = eng.plan_for(x.shape[0], x.shape[2], x.shape[3], dt, dt)
+        print(f"== {tag} input {dt}")
+        if "layer0_0" in z:
+            for i, t in enumerate(plan.layer_out):
+                if t is None:
+                    continue
+                ref = z[f"layer0_{i}"]
+                if isinstance(t, list):
+                    got = torch.cat([eng.read_view(plan, h, v) for v in t], 1).numpy()
+                else:
+                    got = eng.read_view(plan, h, t).numpy()
+                err = np.abs(got - ref)
+                print(f"  layer {i:2d} max|ref| {np.abs(ref).max():8.3f} max err {err.max():.3e} rel-to-max {err.max() / np.abs(ref).max():.2e}")
+        yr = z["y0"]
+        yy = y.float().cpu().numpy()
+        print("  y box max err", np.abs(yy[:, :4] - yr[:, :4]).max(), " score max err", np.abs(yy[:, 4:] - yr[:, 4:]).max(),
+              " max score", yr[:, 4:].max())
+        for l in range(3):
+            rr = z[f"raw0_{l}"]
+            print(f"  raw{l} max err {np.abs(raws[l].float().cpu().numpy() - rr).max():.3e} (max |ref| {np.abs(rr).max():.2f})")
+    eng.close()
+
+
+def timing(scale="s", B=64, S=640, dt=torch.float16):
+    from bs_yolo_amd.plan import Plan
+    from bs_yolo_amd.weights import synth_state_dict
+    cfg = stock_cfg("yolo11", scale)
+    sd = synth_state_dict(Plan(cfg, 1, 64, 64), 0)
+    eng = YoloEngine(cfg, sd)
+    x = torch.rand(B, 3, S, S, device=DEV).to(dt)
+    for _ in range(3):
+        y, _ = eng(x, want_raw=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        y, _ = eng(x, want_raw=False)
+    torch.cuda.synchronize()
+    dtm = (time.perf_counter() - t0) / n
+    plan, _ = eng.plan_for(B, S, S, dt, dt)
+    print(f"yolo11{scale} B={B} {S}x{S}: {dtm * 1e3:.3f} ms/batch  {B / dtm:.0f} img/s  {plan.flops / dtm / 1e12:.1f} TFLOP/s")
+    ops, plan = eng.profile(x)
+    ops2, _ = eng.profile(x)
+    tot = sum(t for _, _, t in ops2)
+    print(f"sum of per-op times {tot:.3f} ms")
+    rows = []
+    for (name, kind, t), o in zip(ops2, plan.ops):
+        fl = 0
+        if kind == L.OP_CONV:
+            cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
+            fl = 2 * B * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2
+        rows.append((t, name, kind, fl))
+    for t, name, kind, fl in sorted(rows, reverse=True)[:40]:
+        print(f"  {t:8.4f} ms  kind {kind}  {name:28s} {fl / t / 1e9 if t > 0 else 0:9.1f} TFLOP/s" if fl else f"  {t:8.4f} ms  kind {kind}  {name}")
+    eng.close()
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("layers", "all"):
+        per_layer("yolo11n_detect")
+        per_layer("yolo11s_detect")
+    if what in ("time", "all"):
+        timing("s", 64, 640)
