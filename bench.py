@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the YOLO11s 640x640 fp16 detection hot path (forward + NMS) on MI355X.
+
+    python bench.py                                   # 1 GPU, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W        # N GPUs, one rank per GPU (RCCL)
+
+One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
+engine forward (all HIP kernels) -> batched HIP NMS (conf 0.25, iou 0.7, max_det 300) -> (N > 1) RCCL all-gather of
+the fixed-size detections over xGMI.  Images are independent units: each rank owns its own batch of 64 (weak scaling,
+no data-path collective besides the detection all-gather).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are taken).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scale", default="s")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-runs", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, cfg_sd):
+    """The oracle (torch-CPU fp32 restatement of the reference path, oracle/) timed on this host: forward + NMS."""
+    from oracle import postproc_ref as PP
+    from oracle import yolo_ref as R
+    m = R.Model("yolo11", args.scale, 80, "detect")
+    P = {k: v.float() for k, v in cfg_sd.items()}
+    P[f"model.{len(m.layers) - 1}.dfl.conv.weight"] = torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)
+    x = torch.rand(args.cpu_batch, 3, args.imgsz, args.imgsz, generator=torch.Generator().manual_seed(0))
+    cores = torch.get_num_threads()
+    with torch.inference_mode():
+        y, _ = m.forward(P, x)  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_runs):
+            y, _ = m.forward(P, x)
+            PP.non_max_suppression(y, 0.25, 0.7)
+        dt = time.perf_counter() - t0
+    return {"value": round(args.cpu_batch * args.cpu_runs / dt, 3), "unit": "images/sec", "cores": cores,
+            "kind": "port",
+            "sample": f"{args.cpu_runs} x batch {args.cpu_batch} YOLO11{args.scale} {args.imgsz}x{args.imgsz} fp32 "
+                      f"forward + NMS, torch CPU {cores} threads, after 1 warm-up ({dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bs_yolo_amd import lib as L
+    from bs_yolo_amd import nms as HN
+    from bs_yolo_amd.engine import YoloEngine
+    from bs_yolo_amd.graphs import stock_cfg
+    from bs_yolo_amd.plan import Plan
+    from bs_yolo_amd.weights import synth_state_dict
+
+    cfg = stock_cfg("yolo11", args.scale, 80, "detect")
+    sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
+    eng = YoloEngine(cfg, sd, device=local)
+    B, S = args.batch, args.imgsz
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(B, 3, S, S, generator=g).half().to(dev)
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        y, _ = eng(x, want_raw=False)
+        det, counts = HN.nms_batched(y, 0.25, 0.7, max_det=300)
+        if world > 1:
+            if gathered is None:
+                gathered = (torch.empty((world,) + det.shape, dtype=det.dtype, device=dev),
+                            torch.empty((world,) + counts.shape, dtype=counts.dtype, device=dev))
+            dist.all_gather_into_tensor(gathered[0], det)
+            dist.all_gather_into_tensor(gathered[1], counts)
+        return det, counts
+
+    for _ in range(args.warmup):
+        det, counts = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        det, counts = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (conv_mfma_kernel): HIP events around every op on the stream ----
+        prof = None
+        for _ in range(3):
+            prof, plan = eng.profile(x)
+        conv_ms = sum(t for (_, kind, t) in prof if kind == L.OP_CONV)
+        n_conv = sum(1 for (_, kind, _) in prof if kind == L.OP_CONV)
+        conv_flops = 0
+        for o in plan.ops:
+            if o["kind"] == L.OP_CONV:
+                cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
+                conv_flops += 2 * B * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        fwd_ms = sum(t for (_, _, t) in prof)
+        out = {
+            "metric": "images/sec YOLO11s 640x640 bs=64 (forward + NMS)", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"YOLO11{args.scale} detect {S}x{S} fp16, batch {B} per GPU, seeded random weights, "
+                                   f"engine forward + HIP NMS (conf 0.25, iou 0.7, max_det 300)"
+                                   + (" + RCCL all-gather of detections" if world > 1 else ""),
+                       "global_batch": world * B, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",
+                       "mean_detections_per_image": round(float(counts.float().mean().item()), 1),
+                       "model_gflop_per_image": round(plan.flops / B / 1e9, 2),
+                       "whole_path_tflops": round(plan.flops * world / (ms_step * 1e-3) / 1e12, 1)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": n_conv,
+                         "flops_per_launch_avg": round(conv_flops / n_conv), "avg_launch_ms": round(conv_ms / n_conv, 5),
+                         "conv_ms_per_step": round(conv_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

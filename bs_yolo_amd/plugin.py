@@ -1,0 +1,125 @@
+"""Reference-side installation: make an unmodified Ultralytics/BS-YOLO model dispatch its hot path to libbsyolo_hip.so.
+
+Three hooks, each using an extension point the reference already has:
+
+  accelerate(model)        whole-graph hook.  Rebinds ``model.forward`` on the instance -- the reference's own idiom
+                           (``m.forward = m.forward_fuse``, nn/tasks.py:215) -- so that AutoBackend's in-memory branch
+                           (nn/autobackend.py:136-147, call at :524) reaches the engine.  The graph comes from
+                           ``model.yaml`` (the dict parse_model consumed, nn/tasks.py:313-321) and the weights from
+                           ``model.state_dict()``.  Anything the engine does not cover (training mode, augment / visualize /
+                           embed (tasks.py:134-164), CPU tensors, unsupported modules) goes to the original forward.
+  install_nms(ops_module)  ``ultralytics.utils.ops.non_max_suppression`` is looked up as a module attribute on every
+                           call (models/yolo/detect/predict.py:25, detect/val.py:95): replacing the attribute suffices.
+  install_preprocess(p)    rebinds ``BasePredictor.preprocess`` (engine/predictor.py:116-134) on a predictor instance so
+                           lists of HWC BGR uint8 images are letterboxed on the device.
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional
+
+import torch
+
+from . import nms as _nms
+from .engine import YoloEngine
+from .plan import Plan
+from .weights import BN_EPS
+
+SUPPORTED_HEADS = ("Detect",)
+
+
+def model_bn_eps(model) -> float:
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            return float(m.eps)
+    return BN_EPS
+
+
+def cfg_of(model) -> dict:
+    """The yaml dict of a reference model (DetectionModel.yaml, nn/tasks.py:313) -- raises if the graph uses modules
+    outside the accelerated set, so callers can fall back."""
+    cfg = getattr(model, "yaml", None)
+    if not isinstance(cfg, dict) or "backbone" not in cfg or "head" not in cfg:
+        raise NotImplementedError("model has no yaml graph description")
+    Plan(cfg, 1, 64, 64)  # raises NotImplementedError / AssertionError on unsupported graphs
+    return cfg
+
+
+def accelerate(model, device: Optional[int] = None, verbose: bool = False):
+    """Install the engine behind ``model.forward``.  Returns the same model object."""
+    cfg = cfg_of(model)
+    orig_forward = model.forward
+    state = {"engine": None, "key": None}
+
+    def _engine_for(dev: torch.device) -> YoloEngine:
+        if state["engine"] is None or state["key"] != dev.index:
+            if state["engine"] is not None:
+                state["engine"].close()
+            # weights are read at this moment: after AutoBackend has called fuse()/half() (autobackend.py:139-145)
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+            state["engine"] = YoloEngine(cfg, sd, device=dev.index or 0, bn_eps=model_bn_eps(model))
+            state["key"] = dev.index
+        return state["engine"]
+
+    def forward(self, x, *args, **kwargs):
+        augment = kwargs.get("augment", False)
+        visualize = kwargs.get("visualize", False)
+        embed = kwargs.get("embed", None)
+        profile = kwargs.get("profile", False)
+        if (self.training or augment or visualize or embed or profile or args or not isinstance(x, torch.Tensor)
+                or not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float16, torch.float32)
+                or x.shape[2] % 32 or x.shape[3] % 32):
+            return orig_forward(x, *args, **kwargs)
+        y, raws = _engine_for(x.device)(x)
+        return y, raws
+
+    model.forward = types.MethodType(forward, model)
+    model._bsy_state = state
+    model._bsy_orig_forward = orig_forward
+    return model
+
+
+def restore(model):
+    if hasattr(model, "_bsy_orig_forward"):
+        model.forward = model._bsy_orig_forward
+        st = model._bsy_state
+        if st["engine"] is not None:
+            st["engine"].close()
+        del model._bsy_orig_forward, model._bsy_state
+    return model
+
+
+def install_nms(ops_module):
+    """ops_module = ultralytics.utils.ops.  GPU tensors go to the HIP NMS; everything else to the original."""
+    orig = ops_module.non_max_suppression
+    if getattr(orig, "_bsy", False):
+        return orig
+
+    def non_max_suppression(prediction, *args, **kwargs):
+        p = prediction[0] if isinstance(prediction, (list, tuple)) else prediction
+        rotated = kwargs.get("rotated", False) or (len(args) > 12 and args[12])
+        labels = kwargs.get("labels", ()) or (args[4] if len(args) > 4 else ())
+        if (not isinstance(p, torch.Tensor)) or (not p.is_cuda) or rotated or len(labels) or p.shape[-1] == 6 \
+                or p.dtype not in (torch.float16, torch.float32):
+            return orig(prediction, *args, **kwargs)
+        return _nms.non_max_suppression(prediction, *args, **kwargs)
+
+    non_max_suppression._bsy = True
+    non_max_suppression._bsy_orig = orig
+    ops_module.non_max_suppression = non_max_suppression
+    return non_max_suppression
+
+
+def install_preprocess(predictor):
+    """predictor = a BasePredictor instance whose model is already set up."""
+    from . import letterbox as _lb
+    orig = predictor.preprocess
+
+    def preprocess(self, im):
+        if isinstance(im, torch.Tensor) or not str(self.device).startswith("cuda"):
+            return orig(im)
+        return _lb.preprocess(list(im), tuple(self.imgsz), half=bool(self.model.fp16), pt=bool(self.model.pt),
+                              stride=int(self.model.stride), device=str(self.device))
+
+    predictor.preprocess = types.MethodType(preprocess, predictor)
+    return predictor

@@ -1,0 +1,275 @@
+"""CPU tests of the host side: C-ABI surface, graph flattening, weight packing, letterbox geometry, sharding."""
+import json
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, ROOT
+
+from bs_yolo_amd import lib as L
+from bs_yolo_amd.graphs import stock_cfg
+from bs_yolo_amd.letterbox import LetterBox
+from bs_yolo_amd.parallel import shard_bounds
+from bs_yolo_amd.plan import Plan
+from bs_yolo_amd.weights import fold_conv_bn, pack_plan_weights, pack_record, synth_state_dict
+from oracle import yolo_ref as R
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = (ROOT / "include" / "bsyolo.h").read_text()
+    declared = set(re.findall(r"\b(bsy_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    for s in declared:
+        assert hasattr(L.lib, s), s
+    assert L.lib.bsy_version() >= 1
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    import ctypes as C
+    cp, kp = C.c_int(), C.c_int()
+    assert L.lib.bsy_conv_packed_dims(80, 64, 3, C.byref(cp), C.byref(kp)) == 0
+    assert (cp.value, kp.value) == (128, 576)
+    assert L.lib.bsy_conv_packed_dims(16, 8, 3, C.byref(cp), C.byref(kp)) == 0
+    assert (cp.value, kp.value) == (128, 96)
+    assert L.lib.bsy_conv_packed_dims(16, 8, 5, C.byref(cp), C.byref(kp)) != 0
+    assert b"bad shape" in L.lib.bsy_last_error()
+    with pytest.raises(L.BsyError):
+        L.check(L.lib.bsy_nms(None, 0, 1, 1, 0, 1, 0.25, 0.45, None, 0, 0, 0, 300, 30000, 7680.0, 1, None, None, None, 0, None))
+    assert L.lib.bsy_nms_workspace_bytes(64, 8400, 80, 0, 30000) >= 64 * 16384 * 8
+    assert L.lib.bsy_nms_workspace_bytes(2, 8400, 80, 1, 30000) >= 2 * (1 << 20) * 8
+
+
+def test_op_struct_layout():
+    import ctypes as C
+    # mirrors include/bsyolo.h: the two int64 offsets sit on an 8-byte boundary after 32 int32 fields
+    assert L.Op.w_off.offset == 128 and L.Op.b_off.offset == 136
+    assert C.sizeof(L.View) == 16
+    assert C.sizeof(L.Op) % 8 == 0
+
+
+@pytest.mark.parametrize("scale,gflops,nconv", [("n", 6.48, 80), ("s", 21.47, 80), ("m", 67.98, 105)])
+def test_plan_work_matches_reference_counts(scale, gflops, nconv):
+    """Dense-conv FLOPs per 640x640 image equal the reference graph (BASELINE.md section 2 / SURVEY 8d); the
+    reference counts 81 dense convs for n/s because DFL is a 1x1 conv there (block.py:58-77), here it lives in decode."""
+    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640)
+    dense = 0
+    n = 0
+    for o in p.ops:
+        if o["kind"] in (L.OP_CONV, L.OP_CONV_FIRST):
+            cin = 3 if o["kind"] == L.OP_CONV_FIRST else o["src0"].C + (o["src1"].C if o.get("src1") else 0)
+            dense += 2 * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2
+            n += 1
+    assert n == nconv
+    assert abs(dense / 1e9 - gflops) < 0.01 * gflops
+    assert p.meta["A"] == 8400 and p.meta["strides"] == [8.0, 16.0, 32.0]
+
+
+def test_plan_consumes_exactly_the_reference_parameters():
+    for fam, scale in (("yolo11", "n"), ("yolo11", "x"), ("yolov8", "s")):
+        p = Plan(stock_cfg(fam, scale), 2, 96, 64)
+        m = R.Model(fam, scale, 80, "detect")
+        want = {n for n, _ in m.param_specs() if not n.endswith("dfl.conv.weight")}
+        used = set()
+        for r in p.wrecs.values():
+            if r.kind == "plain":
+                used |= {r.name + ".weight", r.name + ".bias"}
+            else:
+                used |= {r.name + ".conv.weight"} | {f"{r.name}.bn.{s}" for s in
+                                                     ("weight", "bias", "running_mean", "running_var")}
+        assert used == want
+        # every view stays inside its buffer and respects the kernels' alignment rules
+        for o in p.ops:
+            for key in ("src0", "src1", "dst", "res"):
+                t = o.get(key)
+                if t is None or t.buf >= L.BSY_EXT_BASE:
+                    continue
+                assert t.coff + t.C <= t.ld
+                assert t.coff % (4 if t.f32 else 8) == 0
+                hs, ws = (t.H // 2, t.W // 2) if t.up else (t.H, t.W)
+                assert p.buf_bytes[t.buf] == p.B * hs * ws * t.ld * (4 if t.f32 else 2)
+
+
+def test_plan_rejects_unsupported_graphs():
+    cfg = stock_cfg("yolo11", "n")
+    cfg["backbone"] = list(cfg["backbone"])
+    cfg["backbone"][2] = [-1, 2, "C3k2_gai", [256, False, 0.25]]  # the BS-YOLO block: not accelerated yet
+    with pytest.raises(NotImplementedError):
+        Plan(cfg, 1, 64, 64)
+    with pytest.raises(NotImplementedError):
+        Plan(stock_cfg("yolo11", "n", task="segment"), 1, 64, 64)
+
+
+def test_fold_matches_reference_known_answer():
+    z = np.load(GOLDEN / "modules.npz")
+    c = R.Conv("m", 8, 12, 3, 1)
+    sd = {n: R.synth_param(n, s, 11) for n, s in c.specs()}
+    w, b = fold_conv_bn(sd, "m")
+    np.testing.assert_allclose(w.numpy(), z["fuse.w"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(b.numpy(), z["fuse.b"], rtol=1e-6, atol=1e-7)
+    # an already-fused state_dict (what the model holds after BaseModel.fuse) gives the same
+    fused = {"m.conv.weight": torch.from_numpy(z["fuse.w"]), "m.conv.bias": torch.from_numpy(z["fuse.b"])}
+    w2, b2 = fold_conv_bn(fused, "m")
+    assert torch.equal(w2, fused["m.conv.weight"]) and torch.equal(b2, fused["m.conv.bias"])
+
+
+def test_packed_weight_layout_is_the_gemm_the_kernel_runs():
+    """[CoutPad][Kpad] with K = (kh, kw, cin): im2col rows in the kernel's K order times the packed matrix == conv2d."""
+    from bs_yolo_amd.plan import WRec
+    g = torch.Generator().manual_seed(0)
+    cin, cout, k = 16, 24, 3
+    sd = {"c.conv.weight": torch.randn(cout, cin, k, k, generator=g), "c.conv.bias": torch.randn(cout, generator=g)}
+    wb, bb = pack_record(sd, WRec("c", "conv", cout, cin, k))
+    wp = torch.frombuffer(bytearray(wb), dtype=torch.float16).view(128, 160).float()
+    bp = torch.frombuffer(bytearray(bb), dtype=torch.float32)
+    assert torch.all(wp[cout:] == 0) and torch.all(wp[:, 144:] == 0) and torch.all(bp[cout:] == 0)
+    x = torch.randn(1, cin, 6, 5, generator=g)
+    xp = F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1)  # NHWC
+    rows = []
+    for oh in range(6):
+        for ow in range(5):
+            rows.append(torch.cat([xp[0, oh + kh, ow + kw] for kh in range(3) for kw in range(3)]))
+    got = torch.stack(rows) @ wp[:cout, :144].t() + bp[:cout]
+    ref = F.conv2d(x, sd["c.conv.weight"].half().float(), sd["c.conv.bias"], 1, 1)[0].permute(1, 2, 0).reshape(30, cout)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_qkv_permutation_groups_heads():
+    p = Plan(stock_cfg("yolo11", "s"), 1, 64, 64)
+    r = p.wrecs["model.10.m.0.attn.qkv"]
+    nh, kd, hd = 4, 32, 64
+    assert sorted(r.perm) == list(range(nh * (2 * kd + hd)))
+    assert r.perm[:kd] == list(range(0, kd))                       # head 0 q
+    assert r.perm[kd:2 * kd] == list(range(128, 128 + kd))         # head 1 q (reference row 1*128 + 0..31)
+    assert r.perm[nh * kd] == kd                                   # first k row of head 0
+    assert r.perm[2 * nh * kd] == 2 * kd                           # first v row of head 0
+    assert r.perm[2 * nh * kd + hd] == 128 + 2 * kd                # first v row of head 1
+
+
+def test_pack_blob_offsets_are_aligned_and_disjoint():
+    p = Plan(stock_cfg("yolo11", "n"), 1, 64, 64)
+    blob = pack_plan_weights(p, synth_state_dict(p, 0))
+    spans = []
+    for r in p.wrecs.values():
+        assert r.w_off % 256 == 0 and r.b_off % 256 == 0 and 0 <= r.w_off < r.b_off < len(blob)
+        spans.append((r.w_off, r.b_off))
+    assert spans == sorted(spans)
+
+
+def test_letterbox_geometry_matches_reference_golden():
+    z = np.load(GOLDEN / "letterbox.npz")
+    for c in json.loads(str(z["cases"])):
+        kw = dict(c["kw"])
+        new_shape = tuple(kw.pop("new_shape"))
+        H2, W2, nw, nh, left, top, _ = LetterBox(new_shape, **kw).geometry(tuple(c["shape"]))
+        assert [H2, W2, 3] == c["out_shape"], c
+        assert [top, top + nh, left, left + nw] == c["box"], c
+
+
+def test_shard_bounds():
+    assert [e - s for s, e in shard_bounds(70, 8)] == [9, 9, 9, 9, 9, 9, 8, 8]  # SAHI config 5
+    assert [e - s for s, e in shard_bounds(256, 8)] == [32] * 8                 # config 3
+    b = shard_bounds(5, 8)
+    assert b[0] == (0, 1) and b[-1] == (5, 5) and sum(e - s for s, e in b) == 5
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from bs_yolo_amd.parallel import gather_detections, shard_bounds
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+n_items = int(sys.argv[3])
+s, e = shard_bounds(n_items, world)[rank]
+det = torch.zeros(e - s, 4, 6)
+counts = torch.zeros(e - s, dtype=torch.int32)
+for i in range(s, e):
+    det[i - s, :, 0] = i          # item id in column 0
+    det[i - s, :, 4] = rank
+    counts[i - s] = i % 5
+d, c = gather_detections(det, counts, n_items)
+assert d.shape == (n_items, 4, 6) and c.shape == (n_items,)
+assert torch.equal(d[:, 0, 0], torch.arange(n_items, dtype=torch.float32)), d[:, 0, 0]
+assert torch.equal(c, (torch.arange(n_items) % 5).to(torch.int32))
+exp_rank = torch.cat([torch.full((b - a,), float(k)) for k, (a, b) in enumerate(shard_bounds(n_items, world))])
+assert torch.equal(d[:, 0, 4], exp_rank)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("n_items", [8, 7])
+def test_gather_detections_gloo_world2(tmp_path, n_items):
+    """world_size-2 rehearsal of the N>1 path on CPU (gloo): even and uneven shards come back in global order."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + os.getpid() % 1000 + n_items)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script), str(ROOT), port, str(n_items)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+REF = Path("/root/reference")
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference tree only exists in the build container")
+def test_plugin_reads_a_live_reference_model():
+    """accelerate()'s inputs -- model.yaml + state_dict() of a live reference DetectionModel, before and after
+    BaseModel.fuse() -- produce the same packed weights as the oracle's parameters."""
+    code = r'''
+import sys, types, os, importlib.metadata as md
+os.environ.update(YOLO_OFFLINE="true", YOLO_AUTOINSTALL="false", YOLO_CONFIG_DIR="/tmp/yolocfg", YOLO_VERBOSE="false")
+sys.dont_write_bytecode = True
+os.makedirs("/tmp/yolocfg", exist_ok=True)
+class D(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"): raise AttributeError(k)
+        return D(self.__name__ + "." + k)
+    def __call__(self, *a, **k): return None
+for n in ("cv2", "pywt", "pywt.data", "seaborn", "cpuinfo"): sys.modules[n] = D(n)
+v = md.version; md.version = lambda n: "0.20.0" if n == "torchvision" else v(n)
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, "/root/reference")
+import torch, yaml
+from ultralytics.nn.tasks import DetectionModel
+from bs_yolo_amd.plugin import cfg_of, model_bn_eps
+from bs_yolo_amd.plan import Plan
+from bs_yolo_amd.weights import pack_plan_weights
+from oracle.yolo_ref import synth_param, Model, synth_params
+d = yaml.safe_load(open("/root/reference/ultralytics/cfg/models/11/yolo11-seg.yaml"))
+d["head"][-1] = [[16, 19, 22], 1, "Detect", ["nc"]]; d["scale"] = "n"; d["nc"] = 80
+m = DetectionModel(d, ch=3, nc=80, verbose=False).eval()
+for k, t in m.state_dict().items():
+    if not k.endswith("num_batches_tracked"): t.copy_(synth_param(k, t.shape, 0))
+cfg = cfg_of(m)
+assert abs(model_bn_eps(m) - 1e-3) < 1e-12
+p1 = Plan(cfg, 1, 64, 64); b1 = pack_plan_weights(p1, {k: v for k, v in m.state_dict().items()}, model_bn_eps(m))
+po = Plan(cfg, 1, 64, 64); bo = pack_plan_weights(po, synth_params(Model("yolo11", "n", 80, "detect"), 0))
+assert b1 == bo, "unfused reference state_dict packs differently from the oracle parameters"
+m.fuse(verbose=False)
+p2 = Plan(cfg, 1, 64, 64); b2 = pack_plan_weights(p2, {k: v for k, v in m.state_dict().items()})
+import numpy as np
+a1 = np.frombuffer(b1, dtype=np.float16).astype(np.float32); a2 = np.frombuffer(b2, dtype=np.float16).astype(np.float32)
+assert len(b1) == len(b2) and np.nanmax(np.abs(a1 - a2)) < 2e-3, "fused state_dict packs differently"
+# the BS-YOLO graph itself (cfg/models/11/yolo11.yaml) is reported as unsupported, so callers fall back
+bs = yaml.safe_load(open("/root/reference/ultralytics/cfg/models/11/yolo11.yaml")); bs["scale"] = "n"
+try:
+    Plan(bs, 1, 64, 64); raise SystemExit("BS-YOLO graph unexpectedly accepted")
+except NotImplementedError:
+    pass
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code, str(ROOT)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
