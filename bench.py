@@ -51,7 +51,9 @@ def cpu_baseline(args, cfg_sd):
     P = {k: v.float() for k, v in cfg_sd.items()}
     P[f"model.{len(m.layers) - 1}.dfl.conv.weight"] = torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)
     x = torch.rand(args.cpu_batch, 3, args.imgsz, args.imgsz, generator=torch.Generator().manual_seed(0))
-    cores = torch.get_num_threads()
+    # the GPU box shares its host: use this job's CPU share (16 threads per GPU), not every visible core
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
     with torch.inference_mode():
         y, _ = m.forward(P, x)  # warm-up
         t0 = time.perf_counter()

@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import torch  # noqa: F401  -- FIRST: the process must hold ONE HIP runtime (torch's libamdhip64); loading ours before
+#                               torch would bring in a second copy that sees no device
+
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libbsyolo_hip.so"
 
