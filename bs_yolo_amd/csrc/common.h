@@ -55,8 +55,8 @@ struct ConvFirstArgs {
     const void* img;
     int img_dtype;
     int B, H, W, OH, OW, ksize, stride, pad;
-    const float* w;  // [k*k*3][Cout]
-    const float* b;
+    const void* w;   // packed f16 [CoutPad][32], k = (kh, kw, c)  (same layout as every other conv)
+    const float* b;  // [CoutPad]
     half_t* dst;
     int ldd, Cout, act;
 };

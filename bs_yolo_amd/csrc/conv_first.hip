@@ -1,78 +1,145 @@
-// First convolution of the graph: image BCHW (fp16 or fp32, 3 channels) -> conv 3x3 stride 2 + bias + SiLU -> NHWC fp16.
+// First convolution of the graph: image BCHW (fp16 or fp32, 3 channels) -> conv 3x3 stride 2 pad 1 + bias + SiLU -> NHWC fp16.
 //
 // Replaces model.0 Conv.forward_fuse (nn/modules/conv.py:149-151; layer 0 of cfg/models/11/yolo11-seg.yaml:17) and
-// absorbs the NCHW->NHWC layout change.  K = 27 is too thin for MFMA and the layer is HBM-bound (reads 3*H*W, writes
-// Cout*H*W/4 halves), so this is a direct fp32 VALU kernel: one thread per output pixel, weights read through the
-// scalar path (wave-uniform addresses -> s_load + SGPR operand FMAs), 16 output channels per register pass, and each
-// thread stores its pixel's channels as contiguous 16-byte vectors so a wave writes one contiguous span.
+// absorbs the NCHW->NHWC layout change.  HBM-bound (reads 3*H*W, writes Cout*H*W/4 elements per image), so the job is
+// to touch every input byte ~once, coalesced, and keep the 27-deep contraction off the VALU:
+//   * a workgroup owns a 4 x 64 output tile; its 9 x 129 x 3 input patch is read plane by plane (consecutive lanes ->
+//     consecutive x, the NCHW-contiguous axis) and parked in LDS as fp16;
+//   * the contraction runs on v_mfma_f32_32x32x16_f16 with K = 27 padded to 32 -- the weights use the SAME packed layout
+//     as every other conv ([CoutPad][Kpad], k = (kh, kw, c)), held in registers as the A operand; the B operand
+//     (pixel on the lane) is gathered from the LDS patch: lane stride 2 pixels = 1 dword -> conflict-free 16-bit reads;
+//   * epilogue as conv_mfma.hip: lane = pixel, 4 consecutive channels per 8-byte store.
 #include "common.h"
 
-template <typename T>
-__global__ __launch_bounds__(256) void conv_first_kernel(const T* __restrict__ img, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, half_t* __restrict__ dst,
-                                                         int B, int H, int W, int OH, int OW, int stride, int pad,
-                                                         int ldd, int Cout, int act) {
-    const long long total = (long long)B * OH * OW;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int ow = (int)(idx % OW);
-    const long long t = idx / OW;
-    const int oh = (int)(t % OH);
-    const int n = (int)(t / OH);
-    float x[27];
-    const size_t plane = (size_t)H * W;
-    const T* ip = img + (size_t)n * 3 * plane;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int iy = oh * stride - pad + kh;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int ix = ow * stride - pad + kw;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                x[(kh * 3 + kw) * 3 + c] = ok ? (float)ip[c * plane + (size_t)iy * W + ix] : 0.f;
-        }
+#define CF_TH 4
+#define CF_TW 64
+#define CF_PR (2 * CF_TH + 1)   // 9 patch rows
+#define CF_PC (2 * CF_TW + 1)   // 129 patch cols
+#define CF_ROW 132              // padded row stride (halves)
+#define CF_PLANE (CF_PR * CF_ROW)
+#define CF_ZERO (3 * CF_PLANE)  // one zero element for the K padding
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restrict__ img, const half_t* __restrict__ wgt,
+                                                              const float* __restrict__ bias, half_t* __restrict__ dst,
+                                                              int H, int W, int OH, int OW, int ldd, int Cout, int act,
+                                                              int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) half_t patch[3 * CF_PLANE + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int iy0 = ty * CF_TH * 2 - 1, ix0 = tx * CF_TW * 2 - 1;
+    const T* ip = img + (size_t)n * 3 * H * W;
+    for (int idx = tid; idx < 3 * CF_PR * CF_PC; idx += 256) {
+        const int c = idx / (CF_PR * CF_PC);
+        const int rem = idx - c * (CF_PR * CF_PC);
+        const int r = rem / CF_PC;
+        const int col = rem - r * CF_PC;
+        const int iy = iy0 + r, ix = ix0 + col;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = (float)ip[((size_t)c * H + iy) * W + ix];
+        patch[c * CF_PLANE + r * CF_ROW + col] = (half_t)v;
     }
-    half_t* dp = dst + (size_t)idx * ldd;
-    for (int c0 = 0; c0 < Cout; c0 += 16) {
-        float acc[16];
+    if (tid < 8) patch[CF_ZERO + tid] = (half_t)0.f;
+
+    // weights: A operand, rows = output channels
+    half8 afr[NT][2];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = bias[c0 + j];
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            const float xv = x[k];
+        for (int s = 0; s < 2; ++s)
+            afr[a][s] = *reinterpret_cast<const half8*>(wgt + (size_t)(a * 32 + lrow) * 32 + 16 * s + 8 * lh);
+    // LDS offsets of this lane's 16 k-values relative to its pixel's patch origin
+    int koff[2][8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = fmaf(xv, w[k * Cout + c0 + j], acc[j]);
-        }
-        half8 o0, o1;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float a = act ? silu_f(acc[j]) : acc[j];
-            const float b = act ? silu_f(acc[8 + j]) : acc[8 + j];
-            o0[j] = (half_t)a;
-            o1[j] = (half_t)b;
+            const int k = 16 * s + 8 * lh + j;
+            const int tap = k / 3, c = k - tap * 3;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            koff[s][j] = k < 27 ? c * CF_PLANE + kh * CF_ROW + kw : -1;
         }
-        *reinterpret_cast<half8*>(dp + c0) = o0;
-        *reinterpret_cast<half8*>(dp + c0 + 8) = o1;
+    __syncthreads();
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int pixbase = (2 * wave) * CF_ROW + 2 * (b * 32 + lrow);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            half8 bf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[j] = patch[koff[s][j] >= 0 ? pixbase + koff[s][j] : CF_ZERO];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[a][s], bf, acc[a][b], 0, 0, 0);
+        }
+    }
+    const int oy = ty * CF_TH + wave;
+    if (oy >= OH) return;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int ox = tx * CF_TW + b * 32 + lrow;
+        if (ox >= OW) continue;
+        half_t* dp = dst + ((size_t)(n * OH + oy) * OW + ox) * ldd;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = a * 32 + 8 * g + 4 * lh;
+                if (c >= Cout) continue;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[a][b][4 * g + e] + bv[e];
+                    o[e] = (half_t)(act ? silu_f(t) : t);
+                }
+                *reinterpret_cast<half4*>(dp + c) = o;
+            }
     }
 }
 
-int launch_conv_first(const ConvFirstArgs& a, hipStream_t s) {
-    if (a.ksize != 3) BSY_FAIL(BSY_ERR_ARG, "conv_first: ksize %d unsupported", a.ksize);
-    if (a.Cout % 16 || a.ldd % 8 || ((uintptr_t)a.dst & 15)) BSY_FAIL(BSY_ERR_ARG, "conv_first: Cout %% 16 / alignment");
-    if (a.OH != (a.H + 2 * a.pad - 3) / a.stride + 1 || a.OW != (a.W + 2 * a.pad - 3) / a.stride + 1)
-        BSY_FAIL(BSY_ERR_ARG, "conv_first: output extent mismatch");
-    const long long total = (long long)a.B * a.OH * a.OW;
-    const unsigned grid = (unsigned)((total + 255) / 256);
-    if (a.img_dtype == BSY_F16)
-        hipLaunchKernelGGL(conv_first_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)a.img, a.w, a.b, a.dst,
-                           a.B, a.H, a.W, a.OH, a.OW, a.stride, a.pad, a.ldd, a.Cout, a.act);
-    else if (a.img_dtype == BSY_F32)
-        hipLaunchKernelGGL(conv_first_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a.img, a.w, a.b, a.dst,
-                           a.B, a.H, a.W, a.OH, a.OW, a.stride, a.pad, a.ldd, a.Cout, a.act);
+template <typename T>
+static int launch_t(const ConvFirstArgs& a, hipStream_t s) {
+    const int tiles_x = ceil_div(a.OW, CF_TW), tiles_y = ceil_div(a.OH, CF_TH);
+    const long long nblk = (long long)a.B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv_first: grid too large");
+    dim3 grid((unsigned)nblk);
+    const T* img = (const T*)a.img;
+    const half_t* w = (const half_t*)a.w;
+    if (a.Cout <= 32)
+        hipLaunchKernelGGL((conv_first_mfma_kernel<T, 1>), grid, dim3(256), 0, s, img, w, a.b, a.dst, a.H, a.W, a.OH, a.OW,
+                           a.ldd, a.Cout, a.act, tiles_x, tiles_y);
+    else if (a.Cout <= 64)
+        hipLaunchKernelGGL((conv_first_mfma_kernel<T, 2>), grid, dim3(256), 0, s, img, w, a.b, a.dst, a.H, a.W, a.OH, a.OW,
+                           a.ldd, a.Cout, a.act, tiles_x, tiles_y);
+    else if (a.Cout <= 96)
+        hipLaunchKernelGGL((conv_first_mfma_kernel<T, 3>), grid, dim3(256), 0, s, img, w, a.b, a.dst, a.H, a.W, a.OH, a.OW,
+                           a.ldd, a.Cout, a.act, tiles_x, tiles_y);
     else
-        BSY_FAIL(BSY_ERR_ARG, "conv_first: image dtype %d unsupported", a.img_dtype);
+        hipLaunchKernelGGL((conv_first_mfma_kernel<T, 4>), grid, dim3(256), 0, s, img, w, a.b, a.dst, a.H, a.W, a.OH, a.OW,
+                           a.ldd, a.Cout, a.act, tiles_x, tiles_y);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
+}
+
+int launch_conv_first(const ConvFirstArgs& a, hipStream_t s) {
+    if (a.ksize != 3 || a.stride != 2 || a.pad != 1) BSY_FAIL(BSY_ERR_ARG, "conv_first: only 3x3 stride 2 pad 1 (got k=%d s=%d p=%d)", a.ksize, a.stride, a.pad);
+    if (a.Cout % 4 || a.Cout > 128 || a.ldd % 4 || ((uintptr_t)a.dst & 7) || ((uintptr_t)a.w & 15) || ((uintptr_t)a.b & 15))
+        BSY_FAIL(BSY_ERR_ARG, "conv_first: Cout must be a multiple of 4 and <= 128; aligned pointers");
+    if (a.OH != (a.H + 2 - 3) / 2 + 1 || a.OW != (a.W + 2 - 3) / 2 + 1) BSY_FAIL(BSY_ERR_ARG, "conv_first: output extent mismatch");
+    if (a.img_dtype == BSY_F16) return launch_t<half_t>(a, s);
+    if (a.img_dtype == BSY_F32) return launch_t<float>(a, s);
+    BSY_FAIL(BSY_ERR_ARG, "conv_first: image dtype %d unsupported", a.img_dtype);
 }

@@ -6,59 +6,85 @@
 //                      written into the channel slices of the (virtual) concat buffer
 #include "common.h"
 
+__device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
+    half8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j] > b[j] ? a[j] : b[j];
+    return r;
+}
+
+#define DW_PX 4  // output pixels per thread along x: 3 x 6 input vectors serve 4 outputs (4.5 loads/output instead of 9)
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W,
                                                         int C, const float* __restrict__ w,
                                                         const float* __restrict__ bias, half_t* __restrict__ dst,
                                                         int ldd, int act, const half_t* __restrict__ res, int ldr) {
     const int C8 = C >> 3;
-    const long long total = (long long)B * H * W * C8;
+    const int WG = (W + DW_PX - 1) / DW_PX;
+    const long long total = (long long)B * H * WG * C8;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % C8) * 8;
-    const long long pix = idx / C8;
-    const int x = (int)(pix % W);
-    const long long t = pix / W;
+    const int c = (int)(idx % C8) * 8;  // channel chunk fastest: a pixel's channels are contiguous -> coalesced
+    long long t = idx / C8;
+    const int x0 = (int)(t % WG) * DW_PX;
+    t /= WG;
     const int y = (int)(t % H);
     const int n = (int)(t / H);
-    float acc[8];
+    float acc[DW_PX][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias[c + j];
+    for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[p][j] = bias[c + j];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int iy = y + kh - 1;
         if ((unsigned)iy >= (unsigned)H) continue;
+        float wk[3][8];
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int ix = x + kw - 1;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            const half8 v = *reinterpret_cast<const half8*>(src + ((size_t)(n * H + iy) * W + ix) * lds_ + c);
             const float* wp = w + (kh * 3 + kw) * C + c;
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp);
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[j] = fmaf((float)v[j], w0[j], acc[j]);
-                acc[4 + j] = fmaf((float)v[4 + j], w1[j], acc[4 + j]);
+            for (int j = 0; j < 4; ++j) { wk[kw][j] = w0[j]; wk[kw][4 + j] = w1[j]; }
+        }
+        const half_t* rowp = src + ((size_t)(n * H + iy) * W) * lds_ + c;
+#pragma unroll
+        for (int q = 0; q < DW_PX + 2; ++q) {
+            const int ix = x0 + q - 1;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const half8 v = *reinterpret_cast<const half8*>(rowp + (size_t)ix * lds_);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int p = q - kw;  // output pixel this input column feeds through tap kw
+                if (p < 0 || p >= DW_PX) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[p][j] = fmaf((float)v[j], wk[kw][j], acc[p][j]);
             }
         }
     }
-    half8 o;
-    if (res) {
-        const half8 r = *reinterpret_cast<const half8*>(res + (size_t)pix * ldr + c);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)((act ? silu_f(acc[j]) : acc[j]) + (float)r[j]);
-    } else {
+    for (int p = 0; p < DW_PX; ++p) {
+        const int x = x0 + p;
+        if (x >= W) continue;
+        const size_t pix = (size_t)(n * H + y) * W + x;
+        half8 o;
+        if (res) {
+            const half8 r = *reinterpret_cast<const half8*>(res + pix * ldr + c);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(act ? silu_f(acc[j]) : acc[j]);
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)((act ? silu_f(acc[p][j]) : acc[p][j]) + (float)r[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)(act ? silu_f(acc[p][j]) : acc[p][j]);
+        }
+        *reinterpret_cast<half8*>(dst + pix * ldd + c) = o;
     }
-    *reinterpret_cast<half8*>(dst + (size_t)pix * ldd + c) = o;
 }
 
 int launch_dwconv(const DwArgs& a, hipStream_t s) {
     if ((a.C & 7) || (a.lds & 7) || (a.ldd & 7) || (a.res && (a.ldr & 7)) || ((uintptr_t)a.src & 15) ||
         ((uintptr_t)a.dst & 15) || ((uintptr_t)a.res & 15) || ((uintptr_t)a.w & 15))
         BSY_FAIL(BSY_ERR_ARG, "dwconv: channels/strides must be multiples of 8 and pointers 16-byte aligned");
-    const long long total = (long long)a.B * a.H * a.W * (a.C / 8);
+    const long long total = (long long)a.B * a.H * ((a.W + DW_PX - 1) / DW_PX) * (a.C / 8);
     if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "dwconv: empty");
     hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H,
                        a.W, a.C, a.w, a.b, a.dst, a.ldd, a.act, a.res, a.ldr);
@@ -66,12 +92,6 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
     return BSY_OK;
 }
 
-__device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
-    half8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = a[j] > b[j] ? a[j] : b[j];
-    return r;
-}
 
 __global__ __launch_bounds__(256) void sppf_pool_kernel(half_t* __restrict__ buf, int ld, int B, int H, int W, int C) {
     const int C8 = C >> 3;
@@ -109,10 +129,54 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(half_t* __restrict__ buf
     *reinterpret_cast<half8*>(op + 3 * C) = m13;
 }
 
+// LDS version: one workgroup owns the whole H x W map of one (image, 8-channel chunk); each MaxPool2d(5,1,2) is a row
+// pass + a column pass (10 LDS reads instead of 25 global ones), chained three times without leaving the CU.
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(half_t* __restrict__ buf, int ld, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) half8 sp[];
+    const int HW = H * W;
+    half8* A = sp;        // current map
+    half8* R = sp + HW;   // row-pooled map
+    const int c = blockIdx.x * 8;
+    const int n = blockIdx.y;
+    half_t* base = buf + (size_t)n * HW * ld + c;
+    for (int i = threadIdx.x; i < HW; i += 256) A[i] = *reinterpret_cast<const half8*>(base + (size_t)i * ld);
+    __syncthreads();
+    for (int pass = 1; pass <= 3; ++pass) {
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int y = i / W, x = i - y * W;
+            half8 m = A[i];
+#pragma unroll
+            for (int d = 1; d <= 2; ++d) {
+                if (x - d >= 0) m = hmax8(m, A[i - d]);
+                if (x + d < W) m = hmax8(m, A[i + d]);
+            }
+            R[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int y = i / W;
+            half8 m = R[i];
+#pragma unroll
+            for (int d = 1; d <= 2; ++d) {
+                if (y - d >= 0) m = hmax8(m, R[i - d * W]);
+                if (y + d < H) m = hmax8(m, R[i + d * W]);
+            }
+            A[i] = m;
+            *reinterpret_cast<half8*>(base + (size_t)i * ld + pass * C) = m;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_sppf_pool(half_t* buf, int ld, int B, int H, int W, int C, hipStream_t s) {
     if ((C & 7) || (ld & 7) || ld < 4 * C || ((uintptr_t)buf & 15)) BSY_FAIL(BSY_ERR_ARG, "sppf_pool: bad layout");
     const long long total = (long long)B * H * W * (C / 8);
     if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "sppf_pool: empty");
+    if ((size_t)H * W * 32 <= 64 * 1024) {  // both LDS maps fit: the usual 20x20 .. 40x40 P5 maps
+        hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(C / 8, B), dim3(256), (size_t)H * W * 32, s, buf, ld, H, W, C);
+        HIP_TRY(hipGetLastError());
+        return BSY_OK;
+    }
     hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf, ld, B, H, W, C);
     HIP_TRY(hipGetLastError());
     return BSY_OK;

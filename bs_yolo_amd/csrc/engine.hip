@@ -122,7 +122,7 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s) {
             a.img = R.base(op.src0); a.img_dtype = op.in_dtype;
             a.B = op.B; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW;
             a.ksize = op.ksize; a.stride = op.stride; a.pad = op.pad;
-            a.w = (const float*)(wb + op.w_off); a.b = (const float*)(wb + op.b_off);
+            a.w = (const void*)(wb + op.w_off); a.b = (const float*)(wb + op.b_off);
             a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.Cout = op.dst.C; a.act = op.act;
             if (!R.ok) return BSY_ERR_ARG;
             return launch_conv_first(a, s);
@@ -253,7 +253,7 @@ extern "C" int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, c
     return launch_conv(a, (hipStream_t)stream);
 }
 
-extern "C" int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b,
+extern "C" int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const void* w, const float* b,
                               void* y, int ldy, int C2, int ksize, int stride, int act, bsy_stream stream) {
     if (!img || !w || !b || !y) BSY_FAIL(BSY_ERR_ARG, "conv_first: null pointer");
     ConvFirstArgs a;

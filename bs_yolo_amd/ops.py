@@ -53,12 +53,11 @@ def conv2d_nhwc(x: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, cout: int, 
 
 
 def conv_first(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int = 3, s: int = 2, act: bool = True):
-    """img BCHW fp16/fp32; w (Cout,3,k,k) fp32; -> NHWC fp16."""
+    """img BCHW fp16/fp32; w (Cout,3,3,3) fp32; -> NHWC fp16."""
     assert img.is_contiguous() and img.shape[1] == 3
     B, _, H, W = img.shape
     cout = w.shape[0]
-    wp = w.detach().float().cpu().permute(2, 3, 1, 0).reshape(k * k * 3, cout).contiguous().to(img.device)
-    bp = b.detach().float().contiguous().to(img.device)
+    wp, bp = pack_conv_weight(w, b, img.device)
     p = k // 2
     OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     out = torch.empty((B, OH, OW, cout), dtype=torch.float16, device=img.device)

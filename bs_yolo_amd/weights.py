@@ -5,7 +5,7 @@
                      Accepts either an un-fused state_dict (conv.weight + bn.*) or an already fused one
                      (conv.weight + conv.bias), which is what a reference model holds after AutoBackend's fuse().
   * pack layouts  -- conv   : fp16 [CoutPad128][Kpad32], K order (kh, kw, cin)  (conv_mfma.hip), bias fp32 [CoutPad128]
-                     first  : fp32 [k*k*3][Cout] tap-major (conv_first.hip)
+                     first  : same as conv with cin = 3 (K = 27 -> 32)  (conv_first.hip)
                      dw     : fp32 [9][C] (elementwise.hip)
 """
 from __future__ import annotations
@@ -50,7 +50,7 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
         w, b = _f32(sd[r.name + ".weight"]), _f32(sd[r.name + ".bias"])
     else:
         w, b = fold_conv_bn(sd, r.name, eps)
-    if r.kind in ("conv", "plain"):
+    if r.kind in ("conv", "plain", "first"):
         cout, cin, k = r.cout, r.cin, r.k
         assert tuple(w.shape) == (cout, cin, k, k), (r.name, tuple(w.shape), (cout, cin, k, k))
         if r.perm is not None:
@@ -63,10 +63,6 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
         bp = torch.zeros(cp, dtype=torch.float32)
         bp[:cout] = b
         return wp.numpy().tobytes(), bp.numpy().tobytes()
-    if r.kind == "first":
-        assert tuple(w.shape) == (r.cout, 3, r.k, r.k), (r.name, tuple(w.shape))
-        wp = w.permute(2, 3, 1, 0).reshape(r.k * r.k * 3, r.cout).contiguous()
-        return wp.numpy().tobytes(), b.contiguous().numpy().tobytes()
     if r.kind == "dw":
         assert tuple(w.shape) == (r.cout, 1, 3, 3), (r.name, tuple(w.shape))
         wp = w.view(r.cout, 9).t().contiguous()

@@ -116,8 +116,9 @@ int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, const void* 
 /* Packed sizes for a (C2, C1, k, k) conv: rows padded to 128 output channels, K = k*k*C1 padded to 32. */
 int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, int* k_pad);
 
-/* First conv from a BCHW image (f16 or f32): w f32 [k*k*3][C2] (tap-major), b f32 [C2] -> NHWC f16. */
-int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b, void* y,
+/* First conv (3x3, stride 2) from a BCHW image (f16 or f32): w packed like bsy_conv2d's ([CoutPad][32] f16,
+ * k = (kh, kw, c)), b f32 [CoutPad] -> NHWC f16. */
+int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const void* w, const float* b, void* y,
                    int ldy, int C2, int ksize, int stride, int act, bsy_stream stream);
 
 /* DWConv (conv.py:224-229) 3x3 s1: w f32 [9][C], b f32 [C]. */

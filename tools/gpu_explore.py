@@ -74,14 +74,28 @@ def timing(scale="s", B=64, S=640, dt=torch.float16):
     tot = sum(t for _, _, t in ops2)
     print(f"sum of per-op times {tot:.3f} ms")
     rows = []
+    bykind = {}
     for (name, kind, t), o in zip(ops2, plan.ops):
-        fl = 0
+        fl = by = 0
+        if kind in (L.OP_CONV, L.OP_DWCONV):
+            cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
+            fl = 2 * B * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2 if kind == L.OP_CONV else 0
+            ins = B * o["H"] * o["W"] * o["src0"].C * 2 // (4 if o["src0"].up else 1)
+            if o.get("src1"):
+                ins += B * o["H"] * o["W"] * o["src1"].C * 2 // (4 if o["src1"].up else 1)
+            outs = B * o["OH"] * o["OW"] * o["dst"].C * (4 if o.get("out_f32") else 2)
+            if o.get("res"):
+                ins += outs
+            by = ins + outs
+        bykind[kind] = bykind.get(kind, 0.0) + t
+        rows.append((t, name, kind, fl, by, o))
+    print("time by kind (ms):", {k: round(v, 3) for k, v in bykind.items()})
+    for t, name, kind, fl, by, o in rows:
+        shape = ""
         if kind == L.OP_CONV:
             cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
-            fl = 2 * B * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2
-        rows.append((t, name, kind, fl))
-    for t, name, kind, fl in sorted(rows, reverse=True)[:40]:
-        print(f"  {t:8.4f} ms  kind {kind}  {name:28s} {fl / t / 1e9 if t > 0 else 0:9.1f} TFLOP/s" if fl else f"  {t:8.4f} ms  kind {kind}  {name}")
+            shape = f"{o['ksize']}x{o['ksize']}s{o['stride']} {cin:4d}->{o['dst'].C:4d} @{o['OH']}x{o['OW']}"
+        print(f"  {t:8.4f} ms kind {kind} {name:26s} {shape:30s} {fl / t / 1e9 if t > 0 else 0:7.1f} TF/s {by / t / 1e6 if t > 0 else 0:8.1f} GB/s")
     eng.close()
 
 
