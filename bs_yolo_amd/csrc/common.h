@@ -102,5 +102,8 @@ int launch_decode(const DecodeArgs& a, hipStream_t s);
 int launch_raw_nchw(const float* box, int ldb, const float* cls, int ldc, int B, int h, int w, int nc, void* out,
                     int out_dtype, hipStream_t s);
 
-// SiLU in fp32: x * sigmoid(x)
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU in fp32: x * sigmoid(x) = x / (1 + 2^(-x*log2 e)); v_exp_f32 + v_rcp_f32 (1 ulp each) -- the result is rounded
+// to fp16 right after, so the IEEE-division expansion (~10 VALU) would buy nothing.  exp2 overflow -> inf -> rcp -> 0.
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}

@@ -11,12 +11,20 @@
 // GEMM view: D[cout][pixel] = sum_k Wt[cout][k] * P[pixel][k], k = (kh, kw, cin) with cin fastest, so both MFMA
 // operands are K-contiguous 16-byte fragments: NHWC gives P, the host packs Wt as [CoutPad][Kpad].
 // MFMA: v_mfma_f32_32x32x16_f16, A operand = weights (rows = cout), B operand = pixels (cols = pixel).  The
-// accumulator then holds, per lane, ONE pixel and groups of 4 consecutive output channels -> 8-byte NHWC stores.
+// accumulator then holds, per lane, ONE pixel and groups of 4 consecutive output channels.
 //
 // Tile: 256 threads = 4 waves (WAVES_M x WAVES_N), wave tile (MT*32 pixels) x (NT*32 couts), BK = 32.
 // LDS rows are 64 B (32 halves) with the 16-B chunk index XOR-swizzled by (row>>2)&3 so that ds_read_b128 of 16
-// consecutive rows hits 16 distinct slots of the 256-B bank row (guide T2).  Global->LDS staging is register
-// prefetch (loads for step t+1 issued before the MFMAs of step t, written after them; one barrier per step).
+// consecutive rows hits 16 distinct slots of the 256-B bank row (guide T2).
+//
+// Staging (v2): LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction = 16 rows x 64 B, lane-linear LDS image;
+// the swizzle is applied to the per-lane SOURCE chunk, guide rule 21) into a ring of STAGES K-steps.  A conv K-step is
+// only 8 MFMAs per wave (~0.1-0.3 us) while a fetch takes 1-3 us under load, so the ring keeps STAGES-1 K-steps in
+// flight behind a COUNTED `s_waitcnt vmcnt(N)` and one raw `s_barrier` per K-step (never `__syncthreads()`, which would
+// drain the DMA queue).  Out-of-image taps / K padding read a zero page instead of branching.
+// The epilogue pairs lanes l and l+32 with v_permlane32_swap so each lane stores 16 B (8 consecutive channels).
+#include <stdlib.h>
+
 #include "common.h"
 
 struct ConvK {
@@ -27,7 +35,7 @@ struct ConvK {
     int M;            // B*OH*OW
     int Cin8;         // (C0+C1)/8
     int ntaps;        // ks*ks
-    int nk;           // Kpad/32
+    int nk;           // Kpad/32 (informational; the kernel uses Kpad / BK)
     int Kpad;
     const half_t* wgt;
     const float* bias;
@@ -38,166 +46,62 @@ struct ConvK {
     int act;
     int dst_scale, dst_dy, dst_dx;
     int ntn;  // number of cout tiles
+    unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
+    int dbg;  // ablation switches for profiling (BSY_CONV_DBG): 1 = no DMA, 4 = no epilogue
 };
 
-template <int KS, int WAVES_M, int WAVES_N, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
-    constexpr int TM = WAVES_M * MT * 32;
-    constexpr int TN = WAVES_N * NT * 32;
-    constexpr int PI = TM / 64;             // pixel rows staged per thread
-    constexpr int WI = (TN + 63) / 64;      // weight rows staged per thread
-    constexpr int STAGE = (TM + TN) * 32;   // halves per LDS stage
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
+__device__ __attribute__((aligned(16))) unsigned int bsy_zero_page[16];  // zero-initialised; source of padded taps
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+// 16-byte LDS-DMA: the wave's 64 lanes land at lds_wave_base + 16*lane (lds_wave_base must be wave-uniform).
+// Guarded so that the host pass (which only needs the launch stub) never type-checks the LDS address-space builtin.
+__device__ __forceinline__ void dma16(const void* g, half_t* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(g, lds_wave_base, 16, 0, 0);
+#else
+    (void)g;
+    (void)lds_wave_base;
+#endif
+}
 
+// Same through a buffer descriptor: address = base(rsrc) + voff + soff, lanes whose voff is out of range (>= num_records)
+// write ZEROS to LDS -- that is how padded taps / rows past M / K padding are filled, with no zero page and no 64-bit
+// per-lane pointer arithmetic (the scalar K-step displacement rides in soff).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t bsy_rsrc_t;
+__device__ __forceinline__ bsy_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma16_buf(bsy_rsrc_t r, unsigned voff, unsigned soff, half_t* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+#else
+typedef int bsy_rsrc_t;
+__device__ __forceinline__ bsy_rsrc_t make_rsrc(const void*, unsigned) { return 0; }
+__device__ __forceinline__ void dma16_buf(bsy_rsrc_t, unsigned, unsigned, half_t*) {}
+#endif
+#define BSY_OOB 0xFFFFFFF0u  // voffset that is out of range for every descriptor (num_records < 2^32 - 16)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
     // XCD-aware, bijective block remap: blocks that share an XCD (bid % 8) get consecutive logical tiles, so the
     // cout tiles of one pixel tile re-read the pixel operand from that XCD's L2.
-    int wg;
-    {
-        const int nb = gridDim.x, bid = blockIdx.x;
-        const int q = nb >> 3, r = nb & 7, x = bid & 7;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
-    const int tn_idx = wg % p.ntn;
-    const int tm_idx = wg / p.ntn;
-    const int m0 = tm_idx * TM;
-    const int n0 = tn_idx * TN;
+    const int q = nb >> 3, r = nb & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 
-    // ---- per-thread staging coordinates ----
-    const int kc = tid & 3;   // which 16-B chunk of the 64-B K row
-    const int r0 = tid >> 2;  // 0..63
-    int img[PI], iy0[PI], ix0[PI];
-    bool rvalid[PI];
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
+                                              int lrow, int lh) {
     const int ohw = p.OH * p.OW;
-#pragma unroll
-    for (int i = 0; i < PI; ++i) {
-        const int m = m0 + r0 + 64 * i;
-        rvalid[i] = m < p.M;
-        const int mm = rvalid[i] ? m : 0;
-        const int n = mm / ohw;
-        const int rem = mm - n * ohw;
-        const int oh = rem / p.OW;
-        const int ow = rem - oh * p.OW;
-        img[i] = n;
-        iy0[i] = oh * p.stride - p.pad;
-        ix0[i] = ow * p.stride - p.pad;
-    }
-    // K position of this thread's chunk: tap index and channel-chunk index inside the (concatenated) Cin
-    int tap = kc / p.Cin8;
-    int c8 = kc - tap * p.Cin8;
-
-    half8 pre_p[PI];
-    half8 pre_w[WI];
-    const half_t* wrow[WI];
-#pragma unroll
-    for (int j = 0; j < WI; ++j) wrow[j] = p.wgt + (size_t)(n0 + r0 + 64 * j) * p.Kpad + kc * 8;
-
-    auto load_global = [&](int kt) {
-        const bool kvalid = tap < p.ntaps;
-        const int kh = (KS == 1) ? 0 : tap / KS;
-        const int kw = (KS == 1) ? 0 : tap - kh * KS;
-        const int cc = c8 * 8;
-        const bool s1 = cc >= p.C0;
-        const half_t* base = s1 ? p.src1 : p.src0;
-        const int ld = s1 ? p.ld1 : p.ld0;
-        const int up = s1 ? p.up1 : p.up0;
-        const int c = s1 ? cc - p.C0 : cc;
-        const int Hs = p.H >> up, Ws = p.W >> up;
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int iy = iy0[i] + kh, ix = ix0[i] + kw;
-            const bool ok = rvalid[i] && kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                const size_t pix = (size_t)(img[i] * Hs + (iy >> up)) * Ws + (ix >> up);
-                v = *reinterpret_cast<const half8*>(base + pix * ld + c);
-            }
-            pre_p[i] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < WI; ++j) {
-            if (TN >= 64 || r0 < TN) pre_w[j] = *reinterpret_cast<const half8*>(wrow[j] + (size_t)kt * 32);
-        }
-        // advance to the next K step (4 chunks further)
-        c8 += 4;
-        while (c8 >= p.Cin8) {
-            c8 -= p.Cin8;
-            ++tap;
-        }
-    };
-    auto store_lds = [&](int buf) {
-        half_t* sP = smem + buf * STAGE;
-        half_t* sW = sP + TM * 32;
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int row = r0 + 64 * i;
-            *reinterpret_cast<half8*>(sP + row * 32 + ((kc ^ ((row >> 2) & 3)) << 3)) = pre_p[i];
-        }
-#pragma unroll
-        for (int j = 0; j < WI; ++j) {
-            const int row = r0 + 64 * j;
-            if (TN >= 64 || r0 < TN) *reinterpret_cast<half8*>(sW + row * 32 + ((kc ^ ((row >> 2) & 3)) << 3)) = pre_w[j];
-        }
-    };
-
-    f32x16 acc[NT][MT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int lrow = lane & 31;
-    const int lh = lane >> 5;
-
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < p.nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < p.nk;
-        if (more) load_global(kt + 1);
-        const half_t* sP = smem + cur * STAGE;
-        const half_t* sW = sP + TM * 32;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 2 * ks + lh;
-            half8 bfr[MT], afr[NT];
-#pragma unroll
-            for (int b = 0; b < MT; ++b) {
-                const int row = (wm * MT + b) * 32 + lrow;
-                bfr[b] = *reinterpret_cast<const half8*>(sP + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3));
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a) {
-                const int row = (wn * NT + a) * 32 + lrow;
-                afr[a] = *reinterpret_cast<const half8*>(sW + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3));
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-                for (int b = 0; b < MT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-        }
-        if (more) store_lds(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias + SiLU (+ residual) -> NHWC store, 4 consecutive couts per 8-byte (f16) / 16-byte (f32) store
+    const bool wide = !p.out_f32 && !(p.Cout & 15) && !(p.ldd & 7) && !((uintptr_t)p.dst & 15);
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
         const int m = m0 + (wm * MT + b) * 32 + lrow;
-        if (m >= p.M) continue;
-        size_t dpix = (size_t)m;
+        const bool mvalid = m < p.M;
+        size_t dpix = (size_t)(mvalid ? m : 0);
         if (p.dst_scale != 1) {
-            const int n = m / ohw;
-            const int rem = m - n * ohw;
+            const int mm = mvalid ? m : 0;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
             const int oh = rem / p.OW;
             const int ow = rem - oh * p.OW;
             dpix = ((size_t)n * (p.OH * p.dst_scale) + (oh * p.dst_scale + p.dst_dy)) * (size_t)(p.OW * p.dst_scale) +
@@ -205,9 +109,49 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
         }
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
+            const int cbase = n0 + (wn * NT + a) * 32;
+            if (cbase >= p.Cout) continue;  // wave-uniform
+            if (wide) {
+                // all 32 couts of this MFMA tile exist (Cout % 16 == 0 and cbase + 16 <= Cout; second half checked below)
+                unsigned pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = cbase + 8 * g + 4 * lh;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (c < p.Cout) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = acc[a][b][4 * g + e] + bv[e];
+                            v[e] = p.act ? silu_f(t) : t;
+                        }
+                        if (p.res && mvalid) {
+                            const half4 rv = *reinterpret_cast<const half4*>(p.res + dpix * p.ldr + c);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+                    }
+                    half2v h0 = {(half_t)v[0], (half_t)v[1]}, h1 = {(half_t)v[2], (half_t)v[3]};
+                    pk[g][0] = __builtin_bit_cast(unsigned, h0);
+                    pk[g][1] = __builtin_bit_cast(unsigned, h1);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    // lanes l / l+32 hold couts 8g+{0..3} / 8g+{4..7}: swap so each lane owns 8 consecutive couts
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    const int c = cbase + 8 * (g + lh);
+                    if (mvalid && c < p.Cout) {
+                        uint4 o = {r0[0], r1[0], r0[1], r1[1]};
+                        *reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(p.dst) + dpix * p.ldd + c) = o;
+                    }
+                }
+                continue;
+            }
+            if (!mvalid) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = n0 + (wn * NT + a) * 32 + 8 * g + 4 * lh;
+                const int c = cbase + 8 * g + 4 * lh;
                 if (c >= p.Cout) continue;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);  // bias is padded to CoutPad
                 float v[4];
@@ -256,19 +200,289 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
     }
 }
 
-template <int KS, int WM, int WN, int MT, int NT>
+// Coalesced epilogue (fp16 outputs, Cout % 8 == 0): the accumulator layout (lane = pixel, 4 channels per register
+// group) makes every direct store touch 32 different pixel rows; for the HBM-bound 1x1 layers that store pattern was
+// the whole kernel (3x).  Instead: bias + SiLU in registers -> fp16 tile [TM][TN] in LDS (the DMA ring is free after
+// the K loop) -> every thread moves 16-byte pieces with consecutive lanes on consecutive channels of one pixel row,
+// adding the residual (also read coalesced) on the way.
+template <int TM, int TN, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvK& p, f32x16 (&acc)[NT][MT], half_t* stile, int m0, int n0,
+                                                  int wm, int wn, int lrow, int lh, int tid) {
+    constexpr int LDT = TN + 8;  // padded tile row (halves)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int prow = (wm * MT + b) * 32 + lrow;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int cl = (wn * NT + a) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cl + 8 * g + 4 * lh;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[a][b][4 * g + e] + bv[e];
+                    o[e] = (half_t)(p.act ? silu_f(t) : t);
+                }
+                *reinterpret_cast<half4*>(stile + prow * LDT + c) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPRW = TN / 8;                 // 16-byte pieces per tile row
+    constexpr int ITER = TM * CPRW / 256;
+    half_t* dst = reinterpret_cast<half_t*>(p.dst);
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id / CPRW, cc = (id % CPRW) * 8;
+        const int m = m0 + row, c = n0 + cc;
+        if (m >= p.M || c >= p.Cout) continue;
+        half8 v = *reinterpret_cast<const half8*>(stile + row * LDT + cc);
+        if (p.res) {
+            const half8 r = *reinterpret_cast<const half8*>(p.res + (size_t)m * p.ldr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r[e]);
+        }
+        *reinterpret_cast<half8*>(dst + (size_t)m * p.ldd + c) = v;
+    }
+}
+
+// BK = channels per K-step (32 or 64).  LDS rows hold BK halves (64 / 128 B); a 1-KiB DMA wave-instruction fills
+// RPI = 512/BK rows.  BK = 64 needs Cin % 64 == 0: every staged row is then a full 128-B line of its source, which halves
+// the L2 request count per byte (the LDS-DMA gather rate from L2 is request-bound: ~35 GB/s/CU with 64-B pieces).
+// ALIGNED: Cin % BK == 0 and C0 % BK == 0, so every K-step lies inside ONE tap of ONE source: all of the K bookkeeping
+// (tap, source, channel base, tap displacement) is wave-uniform scalar work and a DMA address is row_offset + scalar,
+// issued through a buffer descriptor (out-of-range lanes -> zeros).  The generic variant (thin layers: Cin = 8 / 16 /
+// 48 ..., BK = 32 only) keeps it per lane and uses flat LDS-DMA + a zero page.
+template <int KS, int WAVES_M, int WAVES_N, int MT, int NT, int STAGES, bool ALIGNED, int BK>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
+    static_assert(BK == 32 || (BK == 64 && ALIGNED), "BK = 64 only for aligned layers");
+    constexpr int TM = WAVES_M * MT * 32;
+    constexpr int TN = WAVES_N * NT * 32;
+    constexpr int TNS = TN < 64 ? 64 : TN;  // weight rows staged (>= 64 so that every wave issues the same DMA count;
+                                            // the packed weights have >= 128 rows, the extra rows are simply unused)
+    constexpr int CPR = BK / 8;             // 16-byte chunks per LDS row
+    constexpr int RPI = 64 / CPR;           // rows filled by one DMA wave-instruction
+    constexpr int PIW = TM / (RPI * 4);     // pixel-tile DMA instructions per wave
+    constexpr int WIW = TNS / (RPI * 4);    // weight-tile DMA instructions per wave
+    constexpr int STAGE = (TM + TNS) * BK;  // halves per LDS stage
+    constexpr int NDMA = PIW + WIW;         // DMA instructions per thread per K-step (identical for all waves)
+    constexpr int SWS = BK == 32 ? 2 : 1;   // read-side swizzle: chunk ^ ((row >> SWS) & (CPR - 1))
+    constexpr int OTILE = TM * (TN + 8);    // fp16 output tile staged by the coalesced epilogue
+    constexpr int SMEM = STAGES * STAGE > OTILE ? STAGES * STAGE : OTILE;
+    __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn_idx = wg % p.ntn;
+    const int tm_idx = wg / p.ntn;
+    const int m0 = tm_idx * TM;
+    const int n0 = tn_idx * TN;
+
+    // ---- per-thread DMA coordinates: lane -> (row = lane / CPR, slot = lane % CPR) of the RPI x CPR block one
+    //      wave-instruction fills; the slot holds source chunk slot ^ swizzle(row)  (== the read-side swizzle).
+    //      BK = 32: swizzle(row) = (row>>2)&3 = (rsub>>2)&3.  BK = 64: (row>>1)&7 = ((q&1)<<2 | rsub>>1), q = instruction
+    //      index inside the tile; PIW / WIW are even there, so the parity is that of the unrolled index.
+    const int rsub = lane / CPR;
+    const int slot = lane % CPR;
+    const int kc0 = BK == 32 ? (slot ^ ((rsub >> 2) & 3)) : (slot ^ (rsub >> 1));  // even instructions
+    const int kc1 = BK == 32 ? kc0 : (slot ^ (4 | (rsub >> 1)));                     // odd instructions (BK = 64)
+    // per staged pixel row: element offset of the window origin pixel (tap 0,0 -> may be "negative" = wraps, only used
+    // when the tap is valid) in each source, and a bitmask of the taps that fall inside the image
+    unsigned off0[PIW], off1[PIW], vmask[PIW];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < PIW; ++i) {
+        const int m = m0 + (wave * PIW + i) * RPI + rsub;
+        const bool rv = m < p.M;
+        const int mm = rv ? m : 0;
+        int n, oh, ow;
+        if (KS == 1 && p.stride == 1) {  // pixel index == m unless a source is upsampled
+            n = 0; oh = 0; ow = 0;
+            if (p.up0 | p.up1) { n = mm / ohw; const int rem = mm - n * ohw; oh = rem / p.OW; ow = rem - oh * p.OW; }
+        } else {
+            n = mm / ohw; const int rem = mm - n * ohw; oh = rem / p.OW; ow = rem - oh * p.OW;
+        }
+        const int iy0 = oh * p.stride - p.pad, ix0 = ow * p.stride - p.pad;
+        if (KS == 1) {
+            vmask[i] = rv ? 1u : 0u;
+            if (p.stride == 1 && !(p.up0 | p.up1)) {
+                off0[i] = (unsigned)mm * (unsigned)p.ld0;
+                off1[i] = (unsigned)mm * (unsigned)p.ld1;
+            } else {
+                const int H0 = p.H >> p.up0, W0 = p.W >> p.up0, H1 = p.H >> p.up1, W1 = p.W >> p.up1;
+                off0[i] = (unsigned)((n * H0 + (iy0 >> p.up0)) * W0 + (ix0 >> p.up0)) * (unsigned)p.ld0;
+                off1[i] = (unsigned)((n * H1 + (iy0 >> p.up1)) * W1 + (ix0 >> p.up1)) * (unsigned)p.ld1;
+            }
+        } else {
+            unsigned rb = 0, cb = 0;
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                rb |= ((unsigned)(iy0 + t) < (unsigned)p.H ? 1u : 0u) << t;
+                cb |= ((unsigned)(ix0 + t) < (unsigned)p.W ? 1u : 0u) << t;
+            }
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < KS; ++t) vm |= ((rb >> t) & 1u) ? (cb << (t * KS)) : 0u;
+            vmask[i] = rv ? vm : 0u;
+            const unsigned pix = (unsigned)((n * p.H + iy0) * p.W + ix0);  // wraps for border rows; masked there
+            off0[i] = pix * (unsigned)p.ld0;
+            off1[i] = pix * (unsigned)p.ld1;
+        }
+    }
+    unsigned woff[WIW];
+#pragma unroll
+    for (int j = 0; j < WIW; ++j)
+        woff[j] = (unsigned)(n0 + (wave * WIW + j) * RPI + rsub) * (unsigned)p.Kpad + ((j & 1) ? kc1 : kc0) * 8;
+    const half_t* zero = reinterpret_cast<const half_t*>(bsy_zero_page);
+    const bsy_rsrc_t rs0 = make_rsrc(p.src0, p.span0), rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.span1 : 0u),
+                     rsw = make_rsrc(p.wgt, p.wspan);
+
+    // K-step state.  ALIGNED: uniform (scalar) tap / channel base.  Generic: per-lane tap / 8-channel chunk index.
+    int s_tap = 0, s_cb = 0;
+    int tap = ALIGNED ? 0 : kc0 / p.Cin8;
+    int c8 = ALIGNED ? 0 : kc0 - tap * p.Cin8;
+    const int Cin = p.Cin8 * 8;
+
+    auto issue = [&](int kt, int stage) {
+        half_t* sP = smem + stage * STAGE;
+        half_t* sW = sP + TM * BK;
+        if (p.dbg & 1) return;
+        if (ALIGNED) {
+            const bool s1 = s_cb >= p.C0;
+            const int ld = s1 ? p.ld1 : p.ld0;
+            const int kh = (KS == 1) ? 0 : s_tap / KS;
+            const int kw = (KS == 1) ? 0 : s_tap - kh * KS;
+            // scalar part of the byte offset: tap displacement + channel base inside the source
+            const unsigned sc = 2u * (unsigned)((kh * p.W + kw) * ld + (s1 ? s_cb - p.C0 : s_cb));
+            const unsigned tbit = 1u << s_tap;
+#pragma unroll
+            for (int i = 0; i < PIW; ++i) {
+                const unsigned kcb = 16u * (unsigned)((i & 1) ? kc1 : kc0);
+                const unsigned o = (vmask[i] & tbit) ? 2u * (s1 ? off1[i] : off0[i]) + sc + kcb : BSY_OOB;
+                if (s1) dma16_buf(rs1, o, 0u, sP + (wave * PIW + i) * RPI * BK);
+                else dma16_buf(rs0, o, 0u, sP + (wave * PIW + i) * RPI * BK);
+            }
+            s_cb += BK;
+            if (s_cb >= Cin) { s_cb = 0; ++s_tap; }
+#pragma unroll
+            for (int j = 0; j < WIW; ++j)
+                dma16_buf(rsw, 2u * woff[j], (unsigned)kt * (2u * BK), sW + (wave * WIW + j) * RPI * BK);
+        } else {
+            const bool kvalid = tap < p.ntaps;
+            const int kh = (KS == 1) ? 0 : tap / KS;
+            const int kw = (KS == 1) ? 0 : tap - kh * KS;
+            const int cc = c8 * 8;
+            const bool s1 = cc >= p.C0;
+            const half_t* base = s1 ? p.src1 : p.src0;
+            const int ld = s1 ? p.ld1 : p.ld0;
+            const unsigned sc = (unsigned)((kh * p.W + kw) * ld + (s1 ? cc - p.C0 : cc));
+            const unsigned tbit = kvalid ? (1u << tap) : 0u;
+#pragma unroll
+            for (int i = 0; i < PIW; ++i) {
+                const unsigned o = (s1 ? off1[i] : off0[i]) + sc;
+                const half_t* g = (vmask[i] & tbit) ? base + (size_t)o : zero;
+                dma16(g, sP + (wave * PIW + i) * RPI * BK);
+            }
+            c8 += 4;
+            while (c8 >= p.Cin8) { c8 -= p.Cin8; ++tap; }
+#pragma unroll
+            for (int j = 0; j < WIW; ++j)
+                dma16(p.wgt + (size_t)(woff[j] + (unsigned)kt * 32u), sW + (wave * WIW + j) * RPI * BK);
+        }
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lrow = lane & 31;
+    const int lh = lane >> 5;
+    const int nk = p.Kpad / BK;
+
+    // prologue: STAGES-1 K-steps in flight
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // wait for K-step kt: everything issued after it may stay in flight
+        const int later = min(STAGES - 2, nk - 1 - kt);  // K-steps issued after kt that are still outstanding
+        if (later >= STAGES - 2 && STAGES > 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NDMA) : "memory");
+        } else if (STAGES > 3 && later == STAGES - 3) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES > 3 ? STAGES - 3 : 0) * NDMA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // K-step kt visible to every wave; every wave is done reading stage (kt-1)%STAGES
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        const half_t* sP = smem + (kt % STAGES) * STAGE;
+        const half_t* sW = sP + TM * BK;
+        // all fragment reads of the K-step first (distinct registers), then the MFMA burst: the LDS latency is paid
+        // once per K-step instead of once per 16-wide sub-step (the compiler otherwise reuses the fragment registers
+        // and serialises read -> wait -> 4 MFMA -> read ...)
+        constexpr int KSUB = BK / 16;
+        half8 bfr[KSUB][MT], afr[KSUB][NT];
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks) {
+            const int chunk = 2 * ks + lh;
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int row = (wm * MT + b) * 32 + lrow;
+                bfr[ks][b] = *reinterpret_cast<const half8*>(sP + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const int row = (wn * NT + a) * 32 + lrow;
+                afr[ks][a] = *reinterpret_cast<const half8*>(sW + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA burst (the scheduler would sink them back)
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+    }
+    if (p.dbg & 4) {
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.dst)[0] = 1.f;  // keep the accumulators live
+        return;
+    }
+    const bool lds_epi = !p.out_f32 && !(p.Cout & 7) && !(p.ldd & 7) && !((uintptr_t)p.dst & 15) && p.dst_scale == 1 &&
+                         (!p.res || (!(p.ldr & 7) && !((uintptr_t)p.res & 15)));
+    if (lds_epi) {
+        __syncthreads();  // every wave has finished reading the last K-step (all DMA already drained by vmcnt(0))
+        conv_epilogue_lds<TM, TN, MT, NT>(p, acc, smem, m0, n0, wm, wn, lrow, lh, tid);
+    } else {
+        conv_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, lrow, lh);
+    }
+}
+
+template <int KS, int WM, int WN, int MT, int NT, int STAGES, bool ALIGNED, int BK>
 static int launch_cfg(const ConvK& k, hipStream_t s) {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
     ConvK p = k;
     p.ntn = ceil_div(k.Cout, TN);
     const long long nblk = (long long)ceil_div(k.M, TM) * p.ntn;
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: grid %lld out of range", nblk);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, WM, WN, MT, NT>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, WM, WN, MT, NT, STAGES, ALIGNED, BK>), dim3((unsigned)nblk), dim3(256), 0, s, p);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
 
-int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, int* k_pad) {
+extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, int* k_pad) {
     if (C2 <= 0 || C1 <= 0 || (ksize != 1 && ksize != 3)) BSY_FAIL(BSY_ERR_ARG, "conv_packed_dims: bad shape");
     if (cout_pad) *cout_pad = round_up(C2, 128);
     if (k_pad) *k_pad = round_up(ksize * ksize * C1, 32);
@@ -300,14 +514,41 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     k.wgt = a.wgt; k.bias = a.bias; k.dst = a.dst; k.ldd = a.ldd; k.Cout = a.Cout; k.out_f32 = a.out_f32;
     k.res = a.res; k.ldr = a.ldr; k.act = a.act;
     k.dst_scale = a.dst_scale > 0 ? a.dst_scale : 1; k.dst_dy = a.dst_dy; k.dst_dx = a.dst_dx; k.ntn = 1;
-    // tile choice: weights are padded to 128 output rows, so any TN <= 128 may over-read safely
-    if (a.ksize == 1) {
-        if (a.Cout > 64) return launch_cfg<1, 2, 2, 2, 2>(k, s);
-        if (a.Cout > 32) return launch_cfg<1, 4, 1, 2, 2>(k, s);
-        return launch_cfg<1, 4, 1, 2, 1>(k, s);
-    } else {
-        if (a.Cout > 64) return launch_cfg<3, 2, 2, 2, 2>(k, s);
-        if (a.Cout > 32) return launch_cfg<3, 4, 1, 2, 2>(k, s);
-        return launch_cfg<3, 4, 1, 2, 1>(k, s);
+    static const int dbg = [] { const char* e = getenv("BSY_CONV_DBG"); return e ? atoi(e) : 0; }();
+    k.dbg = dbg;
+    {   // bytes addressable from each view's first element up to its last element (descriptor range check)
+        const long long px0 = (long long)a.B * (a.H >> a.up0) * (a.W >> a.up0), px1 = (long long)a.B * (a.H >> a.up1) * (a.W >> a.up1);
+        k.span0 = (unsigned)(((px0 - 1) * a.ld0 + a.C0) * 2);
+        k.span1 = a.C1 ? (unsigned)(((px1 - 1) * a.ld1 + a.C1) * 2) : 0u;
+        k.wspan = (unsigned)((long long)round_up(a.Cout, 128) * k.Kpad * 2);
     }
+    // tile choice: weights are padded to 128 output rows, so any TN <= 128 may over-read safely.
+    // BSY_CONV_STAGES (2..4) overrides the DMA ring depth for experiments.
+    static const int stages = [] { const char* e = getenv("BSY_CONV_STAGES"); return e ? atoi(e) : 3; }();
+    static const int bk64 = [] { const char* e = getenv("BSY_CONV_BK64"); return e ? atoi(e) : 1; }();
+    const bool aligned = !(Cin & 31) && !(a.C0 & 31);
+    const bool aligned64 = !(Cin & 63) && !(a.C0 & 63);
+    if (a.ksize == 3 && (a.up0 || a.up1)) BSY_FAIL(BSY_ERR_ARG, "conv: upsampled source only with ksize 1");
+    // element offsets are kept in 32 bits inside the kernel
+    if ((long long)a.B * a.H * a.W * (long long)(a.ld0 > a.ld1 ? a.ld0 : a.ld1) >= (1LL << 31))
+        BSY_FAIL(BSY_ERR_ARG, "conv: source view exceeds 2^31 elements (split the batch)");
+#define BSY_DISPATCH(KS_, WM_, WN_, MT_, NT_)                                        \
+    do {                                                                             \
+        if (!aligned) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, false, 32>(k, s);        \
+        if (aligned64 && bk64 && stages == 3) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, true, 64>(k, s); \
+        if (aligned64 && bk64) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 2, true, 64>(k, s); \
+        if (stages == 2) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 2, true, 32>(k, s);       \
+        if (stages == 4) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 4, true, 32>(k, s);       \
+        return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, true, 32>(k, s);                        \
+    } while (0)
+    if (a.ksize == 1) {
+        if (a.Cout > 64) BSY_DISPATCH(1, 2, 2, 2, 2);
+        if (a.Cout > 32) BSY_DISPATCH(1, 4, 1, 2, 2);
+        BSY_DISPATCH(1, 4, 1, 2, 1);
+    } else {
+        if (a.Cout > 64) BSY_DISPATCH(3, 2, 2, 2, 2);
+        if (a.Cout > 32) BSY_DISPATCH(3, 4, 1, 2, 2);
+        BSY_DISPATCH(3, 4, 1, 2, 1);
+    }
+#undef BSY_DISPATCH
 }

@@ -19,6 +19,16 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-3  # utils/torch_utils.py:424 (initialize_weights sets BatchNorm2d.eps = 1e-3)
 
+# Test aid (NOT reference behaviour): when True, the restatement rounds weights and every stored activation to fp16 at
+# the points where the HIP engine stores fp16 (fp32 accumulation in between), i.e. it models the engine's numerics.
+# Comparing the engine with THIS isolates kernel errors from the unavoidable fp16-storage error of the whole network.
+FP16_EMULATION = False
+
+
+def _q(t):
+    return t.half().float() if FP16_EMULATION else t
+
+
 # --------------------------------------------------------------------------------------------
 # Graph tables.  (from, repeats, type, args) -- same information as cfg/models/11/yolo11-seg.yaml:15-47
 # (stock YOLO11 backbone+neck) and cfg/models/v8/yolov8-seg.yaml:15-46, written in our own notation.
@@ -91,10 +101,17 @@ class Conv:
         bf = bb - bw.mul(mu).div(torch.sqrt(var + BN_EPS))
         return wf, bf
 
-    def __call__(self, P, x):
+    def __call__(self, P, x, res=None):
         w, b = self.folded(P)
-        y = F.conv2d(x, w, b, self.s, self.p, 1, self.g)
-        return F.silu(y) if self.act else y
+        if self.g == 1:
+            w = _q(w)  # dense conv weights are packed as fp16 (depthwise weights stay fp32 in the engine)
+        y = F.conv2d(_q(x), w, b, self.s, self.p, 1, self.g)
+        y = F.silu(y) if self.act else y
+        if res is not None:
+            # dense convs: the engine's epilogue parks fp16(act(.)) in LDS, then adds the residual and rounds again;
+            # depthwise convs add the residual in fp32 before the only rounding
+            y = (_q(y) if self.g == 1 else y) + res
+        return _q(y)
 
 
 def DWConv(name, c1, c2, k=1, s=1, act=True):  # nn/modules/conv.py:224-229
@@ -112,7 +129,7 @@ class PlainConv:
         yield (self.name + ".bias", (self.c2,))
 
     def __call__(self, P, x):
-        return F.conv2d(x, P[self.name + ".weight"], P[self.name + ".bias"])
+        return F.conv2d(_q(x), _q(P[self.name + ".weight"]), P[self.name + ".bias"])  # fp32 output in the engine too
 
 
 class Seq:
@@ -143,6 +160,8 @@ class Bottleneck:
         yield from self.cv2.specs()
 
     def __call__(self, P, x):
+        if FP16_EMULATION:  # the engine adds the shortcut in the conv epilogue, before the fp16 store
+            return self.cv2(P, self.cv1(P, x), res=x if self.add else None)
         y = self.cv2(P, self.cv1(P, x))
         return x + y if self.add else y
 
@@ -231,7 +250,7 @@ class Attention:
         for m in (self.qkv, self.proj, self.pe):
             yield from m.specs()
 
-    def __call__(self, P, x):
+    def __call__(self, P, x, res=None):
         B, C, H, W = x.shape
         N = H * W
         qkv = self.qkv(P, x)
@@ -239,6 +258,9 @@ class Attention:
             [self.key_dim, self.key_dim, self.head_dim], dim=2)
         attn = (q.transpose(-2, -1) @ k) * self.scale
         attn = attn.softmax(dim=-1)
+        if FP16_EMULATION:  # attention output stored as fp16, then pe(v) + it stored as fp16
+            a = _q((v @ attn.transpose(-2, -1)).view(B, C, H, W))
+            return self.proj(P, self.pe(P, v.reshape(B, C, H, W), res=a), res=res)
         x = (v @ attn.transpose(-2, -1)).view(B, C, H, W) + self.pe(P, v.reshape(B, C, H, W))
         return self.proj(P, x)
 
@@ -256,6 +278,9 @@ class PSABlock:
         yield from self.ffn.specs()
 
     def __call__(self, P, x):
+        if FP16_EMULATION and self.add:  # shortcut adds fused into the proj / ffn.1 epilogues
+            x = self.attn(P, x, res=x)
+            return self.ffn.mods[1](P, self.ffn.mods[0](P, x), res=x)
         x = x + self.attn(P, x) if self.add else self.attn(P, x)
         x = x + self.ffn(P, x) if self.add else self.ffn(P, x)
         return x

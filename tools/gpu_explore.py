@@ -41,6 +41,26 @@ def per_layer(tag="yolo11n_detect"):
                     got = eng.read_view(plan, h, t).numpy()
                 err = np.abs(got - ref)
                 print(f"  layer {i:2d} max|ref| {np.abs(ref).max():8.3f} max err {err.max():.3e} rel-to-max {err.max() / np.abs(ref).max():.2e}")
+        si = 1
+        while f"x{si}" in z:
+            xx = torch.from_numpy(z[f"x{si}"])
+            y2, _ = eng(xx.to(dt).to(DEV))
+            torch.cuda.synchronize()
+            e = np.abs(y2.float().cpu().numpy() - z[f"y{si}"])
+            print(f"  input {si} {tuple(xx.shape)}: box max err {e[:, :4].max():.4f} score max err {e[:, 4:].max():.2e} (mean {e[:, 4:].mean():.2e})")
+            R.FP16_EMULATION = True
+            with torch.inference_mode():
+                yq, _ = m.forward(P, xx)
+            R.FP16_EMULATION = False
+            e = np.abs(y2.float().cpu().numpy() - yq.numpy())
+            print(f"     vs fp16-emulating oracle: box max err {e[:, :4].max():.4f} score max err {e[:, 4:].max():.2e} (mean {e[:, 4:].mean():.2e})")
+            si += 1
+        R.FP16_EMULATION = True
+        with torch.inference_mode():
+            yq, _ = m.forward(P, x)
+        R.FP16_EMULATION = False
+        e = np.abs(y.float().cpu().numpy() - yq.numpy())
+        print(f"  input 0 vs fp16-emulating oracle: box max err {e[:, :4].max():.4f} score max err {e[:, 4:].max():.2e} (mean {e[:, 4:].mean():.2e})")
         yr = z["y0"]
         yy = y.float().cpu().numpy()
         print("  y box max err", np.abs(yy[:, :4] - yr[:, :4]).max(), " score max err", np.abs(yy[:, 4:] - yr[:, 4:]).max(),
