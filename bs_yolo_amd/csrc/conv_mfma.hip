@@ -205,7 +205,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[NT][
 // the whole kernel (3x).  Instead: bias + SiLU in registers -> fp16 tile [TM][TN] in LDS (the DMA ring is free after
 // the K loop) -> every thread moves 16-byte pieces with consecutive lanes on consecutive channels of one pixel row,
 // adding the residual (also read coalesced) on the way.
-template <int TM, int TN, int MT, int NT>
+template <int TM, int TN, int MT, int NT, int NTHR>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvK& p, f32x16 (&acc)[NT][MT], half_t* stile, int m0, int n0,
                                                   int wm, int wn, int lrow, int lh, int tid) {
     constexpr int LDT = TN + 8;  // padded tile row (halves)
@@ -231,11 +231,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvK& p, f32x16 (&acc)[
     }
     __syncthreads();
     constexpr int CPRW = TN / 8;                 // 16-byte pieces per tile row
-    constexpr int ITER = TM * CPRW / 256;
+    constexpr int ITER = TM * CPRW / NTHR;
     half_t* dst = reinterpret_cast<half_t*>(p.dst);
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTHR * i;
         const int row = id / CPRW, cc = (id % CPRW) * 8;
         const int m = m0 + row, c = n0 + cc;
         if (m >= p.M || c >= p.Cout) continue;
@@ -257,7 +257,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvK& p, f32x16 (&acc)[
 // issued through a buffer descriptor (out-of-range lanes -> zeros).  The generic variant (thin layers: Cin = 8 / 16 /
 // 48 ..., BK = 32 only) keeps it per lane and uses flat LDS-DMA + a zero page.
 template <int KS, int WAVES_M, int WAVES_N, int MT, int NT, int STAGES, bool ALIGNED, int BK>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const ConvK p) {
+    constexpr int NW = WAVES_M * WAVES_N;   // waves per workgroup (4 or 8)
+    constexpr int NTHR = 64 * NW;
     static_assert(BK == 32 || (BK == 64 && ALIGNED), "BK = 64 only for aligned layers");
     constexpr int TM = WAVES_M * MT * 32;
     constexpr int TN = WAVES_N * NT * 32;
@@ -265,8 +267,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
                                             // the packed weights have >= 128 rows, the extra rows are simply unused)
     constexpr int CPR = BK / 8;             // 16-byte chunks per LDS row
     constexpr int RPI = 64 / CPR;           // rows filled by one DMA wave-instruction
-    constexpr int PIW = TM / (RPI * 4);     // pixel-tile DMA instructions per wave
-    constexpr int WIW = TNS / (RPI * 4);    // weight-tile DMA instructions per wave
+    constexpr int PIW = TM / (RPI * NW);    // pixel-tile DMA instructions per wave
+    constexpr int WIW = TNS / (RPI * NW);   // weight-tile DMA instructions per wave
+    static_assert(PIW >= 1 && WIW >= 1 && (BK == 32 || (!(PIW & 1) && !(WIW & 1))), "tile too small for this wave count");
     constexpr int STAGE = (TM + TNS) * BK;  // halves per LDS stage
     constexpr int NDMA = PIW + WIW;         // DMA instructions per thread per K-step (identical for all waves)
     constexpr int SWS = BK == 32 ? 2 : 1;   // read-side swizzle: chunk ^ ((row >> SWS) & (CPR - 1))
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK p) {
                          (!p.res || (!(p.ldr & 7) && !((uintptr_t)p.res & 15)));
     if (lds_epi) {
         __syncthreads();  // every wave has finished reading the last K-step (all DMA already drained by vmcnt(0))
-        conv_epilogue_lds<TM, TN, MT, NT>(p, acc, smem, m0, n0, wm, wn, lrow, lh, tid);
+        conv_epilogue_lds<TM, TN, MT, NT, NTHR>(p, acc, smem, m0, n0, wm, wn, lrow, lh, tid);
     } else {
         conv_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, lrow, lh);
     }
@@ -477,7 +480,7 @@ static int launch_cfg(const ConvK& k, hipStream_t s) {
     p.ntn = ceil_div(k.Cout, TN);
     const long long nblk = (long long)ceil_div(k.M, TM) * p.ntn;
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: grid %lld out of range", nblk);
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, WM, WN, MT, NT, STAGES, ALIGNED, BK>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, WM, WN, MT, NT, STAGES, ALIGNED, BK>), dim3((unsigned)nblk), dim3(64 * WM * WN), 0, s, p);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
@@ -487,6 +490,42 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
     if (cout_pad) *cout_pad = round_up(C2, 128);
     if (k_pad) *k_pad = round_up(ksize * ksize * C1, 32);
     return BSY_OK;
+}
+
+// Configuration ids: tile << 4 | variant.
+//   tile   : 0 = 256 px x 32 couts, 1 = 256 x 64, 2 = 128 x 128, 3 = 128 x 64 (4 waves); 4 = 256 x 128 (8 waves)
+//   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
+//            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
+bool conv_cfg_valid(const ConvArgs& a, int cfg) {
+    const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
+    if (cfg < 0 || tile > 4 || var > 3) return false;
+    const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
+    if (var >= 1 && !aligned) return false;
+    if (var == 3 && !aligned64) return false;
+    if (tile == 4 && var != 1 && var != 2) return false;
+    return true;
+}
+
+int conv_candidates(const ConvArgs& a, int* out, int max_out) {
+    const int Cin = a.C0 + a.C1;
+    const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
+    const long long M = (long long)a.B * a.OH * a.OW;
+    const int tile = a.Cout > 64 ? 2 : (a.Cout > 32 ? 1 : 0);
+    int n = 0;
+    auto add = [&](int t, int v) { if (n < max_out) out[n++] = (t << 4) | v; };
+    if (!aligned) {
+        add(tile, 0);
+        if (a.Cout > 32 && a.Cout <= 64) add(3, 0);
+        return n;
+    }
+    if (aligned64) add(tile, 3);
+    add(tile, 1);
+    add(tile, 2);
+    if (a.Cout > 32) {  // 128 x 64: more (smaller) workgroups for small-M layers / narrower couts
+        if (tile != 3) { add(3, 1); if (aligned64) add(3, 3); }
+    }
+    if (a.Cout >= 128 && M >= 32768) { add(4, 1); add(4, 2); }
+    return n;
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
@@ -514,6 +553,11 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     k.wgt = a.wgt; k.bias = a.bias; k.dst = a.dst; k.ldd = a.ldd; k.Cout = a.Cout; k.out_f32 = a.out_f32;
     k.res = a.res; k.ldr = a.ldr; k.act = a.act;
     k.dst_scale = a.dst_scale > 0 ? a.dst_scale : 1; k.dst_dy = a.dst_dy; k.dst_dx = a.dst_dx; k.ntn = 1;
+    // ---- configuration: explicit (autotuned, ConvArgs::cfg) or heuristic -----------------------------------------
+    if (a.ksize == 3 && (a.up0 || a.up1)) BSY_FAIL(BSY_ERR_ARG, "conv: upsampled source only with ksize 1");
+    // element offsets are kept in 32 bits inside the kernel
+    if ((long long)a.B * a.H * a.W * (long long)(a.ld0 > a.ld1 ? a.ld0 : a.ld1) >= (1LL << 31))
+        BSY_FAIL(BSY_ERR_ARG, "conv: source view exceeds 2^31 elements (split the batch)");
     static const int dbg = [] { const char* e = getenv("BSY_CONV_DBG"); return e ? atoi(e) : 0; }();
     k.dbg = dbg;
     {   // bytes addressable from each view's first element up to its last element (descriptor range check)
@@ -522,33 +566,33 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         k.span1 = a.C1 ? (unsigned)(((px1 - 1) * a.ld1 + a.C1) * 2) : 0u;
         k.wspan = (unsigned)((long long)round_up(a.Cout, 128) * k.Kpad * 2);
     }
-    // tile choice: weights are padded to 128 output rows, so any TN <= 128 may over-read safely.
-    // BSY_CONV_STAGES (2..4) overrides the DMA ring depth for experiments.
-    static const int stages = [] { const char* e = getenv("BSY_CONV_STAGES"); return e ? atoi(e) : 3; }();
-    static const int bk64 = [] { const char* e = getenv("BSY_CONV_BK64"); return e ? atoi(e) : 1; }();
-    const bool aligned = !(Cin & 31) && !(a.C0 & 31);
-    const bool aligned64 = !(Cin & 63) && !(a.C0 & 63);
-    if (a.ksize == 3 && (a.up0 || a.up1)) BSY_FAIL(BSY_ERR_ARG, "conv: upsampled source only with ksize 1");
-    // element offsets are kept in 32 bits inside the kernel
-    if ((long long)a.B * a.H * a.W * (long long)(a.ld0 > a.ld1 ? a.ld0 : a.ld1) >= (1LL << 31))
-        BSY_FAIL(BSY_ERR_ARG, "conv: source view exceeds 2^31 elements (split the batch)");
-#define BSY_DISPATCH(KS_, WM_, WN_, MT_, NT_)                                        \
-    do {                                                                             \
-        if (!aligned) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, false, 32>(k, s);        \
-        if (aligned64 && bk64 && stages == 3) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, true, 64>(k, s); \
-        if (aligned64 && bk64) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 2, true, 64>(k, s); \
-        if (stages == 2) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 2, true, 32>(k, s);       \
-        if (stages == 4) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 4, true, 32>(k, s);       \
-        return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, true, 32>(k, s);                        \
-    } while (0)
-    if (a.ksize == 1) {
-        if (a.Cout > 64) BSY_DISPATCH(1, 2, 2, 2, 2);
-        if (a.Cout > 32) BSY_DISPATCH(1, 4, 1, 2, 2);
-        BSY_DISPATCH(1, 4, 1, 2, 1);
-    } else {
-        if (a.Cout > 64) BSY_DISPATCH(3, 2, 2, 2, 2);
-        if (a.Cout > 32) BSY_DISPATCH(3, 4, 1, 2, 2);
-        BSY_DISPATCH(3, 4, 1, 2, 1);
+    int cfg = a.cfg;
+    if (cfg < 0 || !conv_cfg_valid(a, cfg)) {
+        int list[BSY_CONV_MAX_CFG];
+        conv_candidates(a, list, BSY_CONV_MAX_CFG);
+        cfg = list[0];
     }
-#undef BSY_DISPATCH
+    const int tile = cfg >> 4, var = cfg & 15;
+    // tile: 0 = 256x32, 1 = 256x64, 2 = 128x128, 3 = 128x64, 4 = 256x128 (8 waves)
+    // var : 0 = generic BK32 S3, 1 = aligned BK32 S3, 2 = aligned BK32 S2, 3 = aligned BK64 S2
+#define BSY_VAR(KS_, WM_, WN_, MT_, NT_)                                                  \
+    do {                                                                                  \
+        if (var == 0) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, false, 32>(k, s);     \
+        if (var == 1) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 3, true, 32>(k, s);      \
+        if (var == 2) return launch_cfg<KS_, WM_, WN_, MT_, NT_, 2, true, 32>(k, s);      \
+        return launch_cfg<KS_, WM_, WN_, MT_, NT_, 2, true, 64>(k, s);                    \
+    } while (0)
+#define BSY_TILE(KS_)                                                                     \
+    do {                                                                                  \
+        if (tile == 0) BSY_VAR(KS_, 4, 1, 2, 1);                                          \
+        if (tile == 1) BSY_VAR(KS_, 4, 1, 2, 2);                                          \
+        if (tile == 2) BSY_VAR(KS_, 2, 2, 2, 2);                                          \
+        if (tile == 3) BSY_VAR(KS_, 2, 2, 2, 1);                                          \
+        if (var == 1) return launch_cfg<KS_, 4, 2, 2, 2, 3, true, 32>(k, s);              \
+        return launch_cfg<KS_, 4, 2, 2, 2, 2, true, 32>(k, s);                            \
+    } while (0)
+    if (a.ksize == 1) BSY_TILE(1);
+    BSY_TILE(3);
+#undef BSY_TILE
+#undef BSY_VAR
 }

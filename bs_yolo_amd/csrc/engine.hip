@@ -4,6 +4,7 @@
 // (nn/tasks.py:138-165) and of every module forward on the path -- into a list of bsy_op records that reference
 // workspace buffers by index.  A plan owns that workspace in HBM (one allocation, 256-byte aligned slices) and replays
 // the op list on the caller's stream; nothing here synchronises or allocates per call.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -114,7 +115,7 @@ struct Resolver {
     float* f(const bsy_view& v) { char* b = base(v); return b ? (float*)b + v.coff : nullptr; }
 };
 
-int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s) {
+int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, ConvArgs* cargs = nullptr) {
     const char* wb = (const char*)p->eng->weights;
     switch (op.kind) {
         case BSY_OP_CONV_FIRST: {
@@ -140,7 +141,9 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s) {
             a.ldd = op.dst.ld; a.Cout = op.dst.C; a.out_f32 = op.out_f32;
             a.res = R.h(op.res); a.ldr = op.res.buf >= 0 ? op.res.ld : 0;
             a.act = op.act; a.dst_scale = op.dst_scale; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
+            a.cfg = op.reserved[1] - 1;  // 0 = not tuned -> heuristic
             if (!R.ok) return BSY_ERR_ARG;
+            if (cargs) { *cargs = a; return BSY_OK; }
             return launch_conv(a, s);
         }
         case BSY_OP_DWCONV: {
@@ -207,6 +210,57 @@ extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream
     return BSY_OK;
 }
 
+// Per-op autotuning of the conv kernel configuration (tile shape / K-step / ring depth): runs the plan once, timing
+// every valid configuration of every conv op with HIP events on `stream` (1 warm-up + 3 timed launches each) and
+// records the fastest in the plan.  All configurations are bit-identical in their results (same per-element K order).
+extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream) {
+    if (!p || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_autotune: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    Resolver R{p, ext, n_ext};
+    int rc = BSY_OK;
+    for (size_t i = 0; i < p->ops.size() && rc == BSY_OK; ++i) {
+        bsy_op& op = p->ops[i];
+        if (op.kind != BSY_OP_CONV) { rc = run_op(p, op, R, s); continue; }
+        ConvArgs a;
+        op.reserved[1] = 0;
+        rc = run_op(p, op, R, s, &a);
+        if (rc != BSY_OK) break;
+        int cand[BSY_CONV_MAX_CFG];
+        const int nc = conv_candidates(a, cand, BSY_CONV_MAX_CFG);
+        float best = 1e30f;
+        int best_cfg = cand[0];
+        for (int c = 0; c < nc && rc == BSY_OK; ++c) {
+            a.cfg = cand[c];
+            rc = launch_conv(a, s);  // warm-up
+            if (rc != BSY_OK) break;
+            if (hipEventRecord(e0, s) != hipSuccess) { rc = BSY_ERR_HIP; break; }
+            for (int r = 0; r < 3 && rc == BSY_OK; ++r) rc = launch_conv(a, s);
+            if (rc != BSY_OK) break;
+            float ms = 0.f;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = BSY_ERR_HIP; bsy_set_error("plan_autotune: event timing failed"); break; }
+            if (ms < best) { best = ms; best_cfg = cand[c]; }
+        }
+        if (rc != BSY_OK) break;
+        op.reserved[1] = best_cfg + 1;
+        a.cfg = best_cfg;
+        rc = launch_conv(a, s);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// HOST array out[n_ops]: the configuration id chosen for each op (-1 = not a conv / not tuned).
+extern "C" int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n) {
+    if (!p || !out || n != (int)p->ops.size()) BSY_FAIL(BSY_ERR_ARG, "plan_get_tuning: bad argument");
+    for (int i = 0; i < n; ++i) out[i] = p->ops[i].kind == BSY_OP_CONV ? p->ops[i].reserved[1] - 1 : -1;
+    return BSY_OK;
+}
+
 extern "C" int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes) {
     if (!p || !host_dst || buf < 0 || (size_t)buf >= p->buf_off.size()) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: bad argument");
     if (bytes > p->buf_size[buf]) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: %zu > buffer size %zu", bytes, p->buf_size[buf]);
@@ -250,6 +304,8 @@ extern "C" int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, c
     a.OH = (H + 2 * a.pad - ksize) / stride + 1; a.OW = (W + 2 * a.pad - ksize) / stride + 1;
     a.wgt = (const half_t*)w; a.bias = b; a.dst = y; a.ldd = ldy; a.Cout = C2; a.out_f32 = y_f32;
     a.res = (const half_t*)res; a.ldr = ldr; a.act = act; a.dst_scale = 1;
+    static const int forced = [] { const char* e = getenv("BSY_CONV_CFG"); return e ? atoi(e) : -1; }();
+    a.cfg = forced;  // experiments: BSY_CONV_CFG=<tile<<4|variant>; invalid ids fall back to the heuristic
     return launch_conv(a, (hipStream_t)stream);
 }
 

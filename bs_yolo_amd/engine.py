@@ -18,7 +18,8 @@ from .weights import BN_EPS, adopt_offsets, pack_plan_weights
 
 
 class YoloEngine:
-    def __init__(self, cfg: dict, state_dict: Mapping[str, torch.Tensor], device: int = 0, bn_eps: float = BN_EPS):
+    def __init__(self, cfg: dict, state_dict: Mapping[str, torch.Tensor], device: int = 0, bn_eps: float = BN_EPS,
+                 autotune: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
@@ -26,6 +27,9 @@ class YoloEngine:
         self._h = C.c_void_p()
         L.check(L.lib.bsy_engine_create(device, C.byref(self._h)))
         self._plans: Dict[Tuple, Tuple] = {}
+        self._tuned = set()
+        import os
+        self.autotune = (os.environ.get("BSY_AUTOTUNE", "1") != "0") if autotune is None else bool(autotune)
         # pack once with a throw-away plan (op list structure does not depend on the input size)
         self._packed = Plan(cfg, 1, 64, 64)
         blob = pack_plan_weights(self._packed, state_dict, bn_eps)
@@ -76,8 +80,18 @@ class YoloEngine:
             raws = [torch.empty((B, m["no"], lh, lw), dtype=im.dtype, device=self.device) for lh, lw in m["levels"]]
         ext, n = self._ext(im, y, raws)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.autotune and (B, H, W, im.dtype) not in self._tuned:
+            # first call for this shape: pick the fastest kernel configuration per conv op (runs the plan once)
+            self._tuned.add((B, H, W, im.dtype))
+            L.check(L.lib.bsy_plan_autotune(h, ext, n, C.c_void_p(stream)))
         L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
         return y, raws
+
+    def tuning(self, B, H, W, dtype=torch.float16):
+        plan, h = self.plan_for(B, H, W, dtype, dtype)
+        out = (C.c_int32 * len(plan.ops))()
+        L.check(L.lib.bsy_plan_get_tuning(h, out, len(plan.ops)))
+        return [(o["name"], int(c)) for o, c in zip(plan.ops, out) if c >= 0]
 
     def __call__(self, im, augment=False, visualize=False, embed=None, want_raw=True):
         if augment or visualize or embed:

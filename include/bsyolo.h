@@ -99,6 +99,11 @@ int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, const int64_t* 
 void bsy_plan_destroy(bsy_plan* p);
 /* ext: HOST array of n_ext device pointers bound to the external slots (input image, y, raw maps ...). */
 int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
+/* Times every valid kernel configuration of every conv op once (HIP events on `stream`, synchronises) and records the
+ * fastest per op; later bsy_plan_run calls use it.  Results are bit-identical across configurations. */
+int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
+/* HOST out[n_ops]: configuration id per op (tile << 4 | variant), -1 for non-conv / untuned ops. */
+int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n_ops);
 /* Debug/test aid: synchronous copy of one workspace buffer to HOST memory (bytes <= the buffer's size). */
 int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes);
 /* Per-op device time of the last bsy_plan_profile call (ms, HIP events on `stream`); runs the plan once, syncs. */

@@ -110,12 +110,15 @@ def timing(scale="s", B=64, S=640, dt=torch.float16):
         bykind[kind] = bykind.get(kind, 0.0) + t
         rows.append((t, name, kind, fl, by, o))
     print("time by kind (ms):", {k: round(v, 3) for k, v in bykind.items()})
+    tun = dict(eng.tuning(B, S, S, dt))
+    import collections
+    print("tuned configs:", dict(collections.Counter(hex(v) for v in tun.values())))
     for t, name, kind, fl, by, o in rows:
         shape = ""
         if kind == L.OP_CONV:
             cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
             shape = f"{o['ksize']}x{o['ksize']}s{o['stride']} {cin:4d}->{o['dst'].C:4d} @{o['OH']}x{o['OW']}"
-        print(f"  {t:8.4f} ms kind {kind} {name:26s} {shape:30s} {fl / t / 1e9 if t > 0 else 0:7.1f} TF/s {by / t / 1e6 if t > 0 else 0:8.1f} GB/s")
+        print(f"  {t:8.4f} ms kind {kind} {name:26s} {shape:30s} {fl / t / 1e9 if t > 0 else 0:7.1f} TF/s {by / t / 1e6 if t > 0 else 0:8.1f} GB/s cfg {hex(tun.get(name, -1)) if name in tun else ''}")
     eng.close()
 
 
