@@ -51,7 +51,7 @@ struct ConvArgs {
     int cfg;  // kernel configuration id (tile << 4 | variant) chosen by the autotuner; < 0 = heuristic
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
-#define BSY_CONV_MAX_CFG 12
+#define BSY_CONV_MAX_CFG 16
 int conv_candidates(const ConvArgs& a, int* out, int max_out);  // valid configuration ids, heuristic best first
 bool conv_cfg_valid(const ConvArgs& a, int cfg);
 
@@ -103,6 +103,7 @@ struct DecodeArgs {
     int y_dtype;
 };
 int launch_decode(const DecodeArgs& a, hipStream_t s);
+int launch_nhwc2nchw(const half_t* src, int ld, int B, int C, int hw, void* out, int out_dtype, hipStream_t s);
 int launch_raw_nchw(const float* box, int ldb, const float* cls, int ldc, int B, int h, int w, int nc, void* out,
                     int out_dtype, hipStream_t s);
 

@@ -8,7 +8,7 @@
 //   * the contraction runs on v_mfma_f32_32x32x16_f16 with K = 27 padded to 32 -- the weights use the SAME packed layout
 //     as every other conv ([CoutPad][Kpad], k = (kh, kw, c)), held in registers as the A operand; the B operand
 //     (pixel on the lane) is gathered from the LDS patch: lane stride 2 pixels = 1 dword -> conflict-free 16-bit reads;
-//   * epilogue as conv_mfma.hip: lane = pixel, 4 consecutive channels per 8-byte store.
+//   * epilogue as conv_mfma.hip: the tile goes through LDS so every store is a coalesced 16-byte piece.
 #include "common.h"
 
 #define CF_TH 4
@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
                                                               const float* __restrict__ bias, half_t* __restrict__ dst,
                                                               int H, int W, int OH, int OW, int ldd, int Cout, int act,
                                                               int tiles_x, int tiles_y) {
-    __shared__ __attribute__((aligned(16))) half_t patch[3 * CF_PLANE + 8];
+    constexpr int OT = CF_TH * CF_TW * (32 * NT + 8);  // fp16 output tile of the coalesced epilogue
+    constexpr int SM = (3 * CF_PLANE + 8) > OT ? (3 * CF_PLANE + 8) : OT;
+    __shared__ __attribute__((aligned(16))) half_t stile[SM];
+    half_t* patch = stile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lh = lane >> 5;
     int bid = blockIdx.x;
@@ -85,19 +88,20 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
             for (int a = 0; a < NT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[a][s], bf, acc[a][b], 0, 0, 0);
         }
     }
-    const int oy = ty * CF_TH + wave;
-    if (oy >= OH) return;
+    // epilogue: bias + SiLU -> fp16 tile [4 rows][64 px][32*NT ch] in LDS (the patch is dead), then coalesced 16-byte
+    // stores: consecutive lanes write consecutive channels of one pixel, consecutive pixels are adjacent in NHWC
+    __syncthreads();
+    constexpr int CT = 32 * NT;       // channels in the tile
+    constexpr int LDT = CT + 8;       // padded row (halves)
+    half_t* tile = stile;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int ox = tx * CF_TW + b * 32 + lrow;
-        if (ox >= OW) continue;
-        half_t* dp = dst + ((size_t)(n * OH + oy) * OW + ox) * ldd;
+        const int prow = wave * CF_TW + b * 32 + lrow;
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = a * 32 + 8 * g + 4 * lh;
-                if (c >= Cout) continue;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
                 half4 o;
 #pragma unroll
@@ -105,8 +109,17 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
                     float t = acc[a][b][4 * g + e] + bv[e];
                     o[e] = (half_t)(act ? silu_f(t) : t);
                 }
-                *reinterpret_cast<half4*>(dp + c) = o;
+                *reinterpret_cast<half4*>(tile + prow * LDT + c) = o;
             }
+    }
+    __syncthreads();
+    constexpr int CPRW = CT / 8;
+    for (int id = tid; id < CF_TH * CF_TW * CPRW; id += 256) {
+        const int prow = id / CPRW, cc = (id % CPRW) * 8;
+        const int oy = ty * CF_TH + prow / CF_TW, ox = tx * CF_TW + prow % CF_TW;
+        if (oy >= OH || ox >= OW || cc >= Cout) continue;
+        *reinterpret_cast<half8*>(dst + ((size_t)(n * OH + oy) * OW + ox) * ldd + cc) =
+            *reinterpret_cast<const half8*>(tile + prow * LDT + cc);
     }
 }
 
@@ -136,8 +149,8 @@ static int launch_t(const ConvFirstArgs& a, hipStream_t s) {
 
 int launch_conv_first(const ConvFirstArgs& a, hipStream_t s) {
     if (a.ksize != 3 || a.stride != 2 || a.pad != 1) BSY_FAIL(BSY_ERR_ARG, "conv_first: only 3x3 stride 2 pad 1 (got k=%d s=%d p=%d)", a.ksize, a.stride, a.pad);
-    if (a.Cout % 4 || a.Cout > 128 || a.ldd % 4 || ((uintptr_t)a.dst & 7) || ((uintptr_t)a.w & 15) || ((uintptr_t)a.b & 15))
-        BSY_FAIL(BSY_ERR_ARG, "conv_first: Cout must be a multiple of 4 and <= 128; aligned pointers");
+    if (a.Cout % 8 || a.Cout > 128 || a.ldd % 8 || ((uintptr_t)a.dst & 15) || ((uintptr_t)a.w & 15) || ((uintptr_t)a.b & 15))
+        BSY_FAIL(BSY_ERR_ARG, "conv_first: Cout must be a multiple of 8 and <= 128; 16-byte aligned pointers");
     if (a.OH != (a.H + 2 - 3) / 2 + 1 || a.OW != (a.W + 2 - 3) / 2 + 1) BSY_FAIL(BSY_ERR_ARG, "conv_first: output extent mismatch");
     if (a.img_dtype == BSY_F16) return launch_t<half_t>(a, s);
     if (a.img_dtype == BSY_F32) return launch_t<float>(a, s);

@@ -493,12 +493,13 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 }
 
 // Configuration ids: tile << 4 | variant.
-//   tile   : 0 = 256 px x 32 couts, 1 = 256 x 64, 2 = 128 x 128, 3 = 128 x 64 (4 waves); 4 = 256 x 128 (8 waves)
+//   tile   : 0 = 256 px x 32 couts, 1 = 256 x 64, 2 = 128 x 128, 3 = 128 x 64 (4 waves); 4 = 256 x 128 (8 waves);
+//            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
-    if (cfg < 0 || tile > 4 || var > 3) return false;
+    if (cfg < 0 || tile > 6 || var > 3) return false;
     const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
     if (var >= 1 && !aligned) return false;
     if (var == 3 && !aligned64) return false;
@@ -525,6 +526,8 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (tile != 3) { add(3, 1); if (aligned64) add(3, 3); }
     }
     if (a.Cout >= 128 && M >= 32768) { add(4, 1); add(4, 2); }
+    if (a.Cout > 64) { add(5, 2); if (aligned64) add(5, 3); }
+    else if (a.Cout > 32) { add(6, 2); if (aligned64) add(6, 3); }
     return n;
 }
 
@@ -573,7 +576,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         cfg = list[0];
     }
     const int tile = cfg >> 4, var = cfg & 15;
-    // tile: 0 = 256x32, 1 = 256x64, 2 = 128x128, 3 = 128x64, 4 = 256x128 (8 waves)
+    // tile: 0 = 256x32, 1 = 256x64, 2 = 128x128, 3 = 128x64, 4 = 256x128 (8 waves), 5 = 64x128, 6 = 64x64
     // var : 0 = generic BK32 S3, 1 = aligned BK32 S3, 2 = aligned BK32 S2, 3 = aligned BK64 S2
 #define BSY_VAR(KS_, WM_, WN_, MT_, NT_)                                                  \
     do {                                                                                  \
@@ -588,6 +591,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         if (tile == 1) BSY_VAR(KS_, 4, 1, 2, 2);                                          \
         if (tile == 2) BSY_VAR(KS_, 2, 2, 2, 2);                                          \
         if (tile == 3) BSY_VAR(KS_, 2, 2, 2, 1);                                          \
+        if (tile == 5) BSY_VAR(KS_, 1, 4, 2, 1);                                          \
+        if (tile == 6) BSY_VAR(KS_, 2, 2, 1, 1);                                          \
         if (var == 1) return launch_cfg<KS_, 4, 2, 2, 2, 3, true, 32>(k, s);              \
         return launch_cfg<KS_, 4, 2, 2, 2, 2, true, 32>(k, s);                            \
     } while (0)

@@ -178,3 +178,35 @@ int launch_raw_nchw(const float* box, int ldb, const float* cls, int ldc, int B,
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
+
+// NHWC fp16 view -> BCHW (Segment's prototype masks `p`, head.py:184 / block.py:95-97).  32 x 32 (pixel x channel)
+// tiles through LDS so that both the NHWC reads (channels fastest) and the BCHW writes (pixels fastest) coalesce.
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc2nchw_kernel(const half_t* __restrict__ src, int ld, int C, int hw,
+                                                        T* __restrict__ out) {
+    __shared__ half_t t[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        t[r][tx] = (p < hw && c < C) ? src[((size_t)b * hw + p) * ld + c] : (half_t)0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < hw) out[((size_t)b * C + c) * hw + p] = (T)(float)t[tx][r];
+    }
+}
+
+int launch_nhwc2nchw(const half_t* src, int ld, int B, int C, int hw, void* out, int out_dtype, hipStream_t s) {
+    if (!src || !out || B <= 0 || C <= 0 || hw <= 0) BSY_FAIL(BSY_ERR_ARG, "nhwc2nchw: bad argument");
+    dim3 grid((hw + 31) / 32, (C + 31) / 32, B);
+    if (out_dtype == BSY_F16)
+        hipLaunchKernelGGL(nhwc2nchw_kernel<half_t>, grid, dim3(256), 0, s, src, ld, C, hw, (half_t*)out);
+    else if (out_dtype == BSY_F32)
+        hipLaunchKernelGGL(nhwc2nchw_kernel<float>, grid, dim3(256), 0, s, src, ld, C, hw, (float*)out);
+    else
+        BSY_FAIL(BSY_ERR_ARG, "nhwc2nchw: dtype %d unsupported", out_dtype);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}

@@ -194,6 +194,14 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             return launch_raw_nchw(box, op.box[l].ld, cls, op.cls[l].ld, op.B, op.lvl_h[l], op.lvl_w[l], op.nc, out,
                                    op.out_dtype, s);
         }
+        case BSY_OP_NHWC2NCHW: {
+            if (op.dst.buf >= BSY_EXT_BASE && (op.dst.buf - BSY_EXT_BASE >= R.n_ext || !R.ext[op.dst.buf - BSY_EXT_BASE]))
+                return BSY_OK;  // optional output
+            const half_t* src = R.h(op.src0);
+            void* out = R.base(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_nhwc2nchw(src, op.src0.ld, op.B, op.src0.C, op.H * op.W, out, op.out_dtype, s);
+        }
         default:
             BSY_FAIL(BSY_ERR_ARG, "plan_run: unknown op kind %d", op.kind);
     }

@@ -59,8 +59,9 @@ class YoloEngine:
         self._plans[key] = (plan, h)
         return plan, h
 
-    def _ext(self, im, y, raws):
+    def _ext(self, im, y, raws, proto=None):
         ptrs = [im.data_ptr(), y.data_ptr()] + [r.data_ptr() if r is not None else None for r in raws]
+        ptrs.append(proto.data_ptr() if proto is not None else None)
         return (C.c_void_p * len(ptrs))(*ptrs), len(ptrs)
 
     def forward(self, im: torch.Tensor, want_raw: bool = True):
@@ -78,13 +79,19 @@ class YoloEngine:
         raws: List[Optional[torch.Tensor]] = [None, None, None]
         if want_raw:
             raws = [torch.empty((B, m["no"], lh, lw), dtype=im.dtype, device=self.device) for lh, lw in m["levels"]]
-        ext, n = self._ext(im, y, raws)
+        proto = None
+        if m["nm"]:
+            ph, pw = m["proto_hw"]
+            proto = torch.empty((B, m["nm"], ph, pw), dtype=im.dtype, device=self.device)
+        ext, n = self._ext(im, y, raws, proto)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.autotune and (B, H, W, im.dtype) not in self._tuned:
             # first call for this shape: pick the fastest kernel configuration per conv op (runs the plan once)
             self._tuned.add((B, H, W, im.dtype))
             L.check(L.lib.bsy_plan_autotune(h, ext, n, C.c_void_p(stream)))
         L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
+        if m["nm"]:  # Segment.forward (head.py:197): (cat(y, mc), (raw, mc, proto)); y already carries the mc rows
+            return y, (raws, y[:, 4 + m["nc"]:], proto)
         return y, raws
 
     def tuning(self, B, H, W, dtype=torch.float16):

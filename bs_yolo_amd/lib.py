@@ -16,7 +16,7 @@ LIB_PATH = PKG / "libbsyolo_hip.so"
 
 BSY_F16, BSY_F32, BSY_U8 = 0, 1, 2
 BSY_EXT_BASE = 0x100000
-(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW) = range(7)
+(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW) = range(8)
 
 SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_destroy",

@@ -207,6 +207,27 @@ class Plan:
             self.conv(pn + ".ffn.1", f, c, 1, 1, act=False, dst=b, res=b)                     # b = b + ffn(b)
         return self.conv(name + ".cv2", ab, c2, 1, 1)
 
+    def proto(self, name: str, x: T, c_: int, nm: int) -> T:
+        """block.py:80-97 Proto: cv3(cv2(ConvTranspose2d(c_, c_, 2, 2)(cv1(x)))) -> (B, nm, 2H, 2W)."""
+        t = self.conv(name + ".cv1", x, c_, 3, 1)
+        up = self.alloc(c_, 2 * x.H, 2 * x.W)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                key = f"{name}.upsample@{dy}{dx}"
+                if key not in self.wrecs:
+                    self.wrecs[key] = WRec(name=name + ".upsample", kind="deconv", cout=c_, cin=c_, k=1, tap=(dy, dx))
+                self.ops.append(dict(kind=L.OP_CONV, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=t, src1=None,
+                                     dst=T(up.buf, up.ld, 0, c_, x.H, x.W), res=None, ksize=1, stride=1, pad=0, act=0,
+                                     out_f32=0, wkey=key, dst_scale=2, dst_dy=dy, dst_dx=dx, name=key))
+                self.flops += 2 * self.B * x.H * x.W * c_ * c_
+        t = self.conv(name + ".cv2", up, c_, 3, 1)
+        p = self.conv(name + ".cv3", t, nm, 1, 1)
+        self.ops.append(dict(kind=L.OP_NHWC2NCHW, H=p.H, W=p.W, OH=0, OW=0, src0=p,
+                             dst=T(L.BSY_EXT_BASE + self.EXT_PROTO, 0, 0, nm, 0, 0), out_dtype=self.out_dtype,
+                             name=name + ".nchw"))
+        self.meta.update(proto_hw=(p.H, p.W))
+        return p
+
     def detect(self, name: str, xs: List[T], nc: int, legacy: bool, nm: int = 0, npr: int = 0):
         """head.py:21-148 (+ Segment :175-197)."""
         ch = [t.C for t in xs]
@@ -308,9 +329,13 @@ class Plan:
             elif m in ("Detect", "Segment"):
                 xs = x if isinstance(x, list) else [x]
                 assert all(isinstance(t, T) for t in xs)
-                if m == "Segment":
-                    raise NotImplementedError("Segment head: next round (SURVEY 8 a10)")
-                self.detect(name, xs, args[0], legacy)
+                if m == "Segment":  # head.py:175-197; npr scaled like parse_model does (tasks.py:1082-1083)
+                    nm = args[1]
+                    npr = make_divisible(min(args[2], max_ch) * width, 8)
+                    self.proto(name + ".proto", xs[0], npr, nm)
+                    self.detect(name, xs, args[0], legacy, nm=nm)
+                else:
+                    self.detect(name, xs, args[0], legacy)
                 y, cout = None, 0
             else:
                 raise NotImplementedError(f"module {m} is not on the accelerated path")

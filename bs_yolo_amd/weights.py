@@ -48,9 +48,15 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
     """-> (weight bytes, bias bytes) for one op."""
     if r.kind == "plain":
         w, b = _f32(sd[r.name + ".weight"]), _f32(sd[r.name + ".bias"])
+    elif r.kind == "deconv":
+        # nn.ConvTranspose2d(c, c, 2, 2, 0) (block.py:91): out[2i+dy, 2j+dx] = W[:, :, dy, dx]^T x[i, j] + b, i.e. one
+        # 1x1 conv per output phase; weight layout (cin, cout, 2, 2)
+        wt, b = _f32(sd[r.name + ".weight"]), _f32(sd[r.name + ".bias"])
+        dy, dx = r.tap
+        w = wt[:, :, dy, dx].t().contiguous().view(r.cout, r.cin, 1, 1)
     else:
         w, b = fold_conv_bn(sd, r.name, eps)
-    if r.kind in ("conv", "plain", "first"):
+    if r.kind in ("conv", "plain", "first", "deconv"):
         cout, cin, k = r.cout, r.cin, r.k
         assert tuple(w.shape) == (cout, cin, k, k), (r.name, tuple(w.shape), (cout, cin, k, k))
         if r.perm is not None:
@@ -104,6 +110,11 @@ def synth_state_dict(plan: Plan, seed: int = 0, cls_gain: float = 0.1, cls_bias:
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
     for r in plan.wrecs.values():
+        if r.kind == "deconv":
+            if r.name + ".weight" not in sd:
+                sd[r.name + ".weight"] = torch.randn(r.cin, r.cout, 2, 2, generator=g) * (2.0 / r.cin) ** 0.5
+                sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) * 0.4 - 0.2
+            continue
         if r.kind == "plain":
             fan = r.cin * r.k * r.k
             sd[r.name + ".weight"] = torch.randn(r.cout, r.cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5

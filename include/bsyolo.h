@@ -60,7 +60,8 @@ enum bsy_op_kind {
     BSY_OP_SPPF_POOL = 3,  /* three chained MaxPool2d(5,1,2) -> channel slices of the SPPF concat buffer      */
     BSY_OP_ATTN = 4,       /* softmax(q^T k * scale) v, per (image, head); MFMA flash-style                   */
     BSY_OP_DECODE = 5,     /* Detect._inference: DFL + dist2bbox + sigmoid -> (B, 4+nc+nm, A)                 */
-    BSY_OP_RAW_NCHW = 6    /* raw per-level head maps NHWC f32 -> BCHW (the `x` list Detect.forward returns)  */
+    BSY_OP_RAW_NCHW = 6,   /* raw per-level head maps NHWC f32 -> BCHW (the `x` list Detect.forward returns)  */
+    BSY_OP_NHWC2NCHW = 7   /* NHWC f16 view -> BCHW tensor (Segment protos, block.py:80-97 output)            */
 };
 
 typedef struct bsy_op {

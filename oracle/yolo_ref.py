@@ -391,7 +391,7 @@ class Proto:
 
     def __call__(self, P, x):
         x = self.cv1(P, x)
-        x = F.conv_transpose2d(x, P[self.name + ".upsample.weight"], P[self.name + ".upsample.bias"], 2, 0)
+        x = _q(F.conv_transpose2d(x, _q(P[self.name + ".upsample.weight"]), P[self.name + ".upsample.bias"], 2, 0))
         return self.cv3(P, self.cv2(P, x))
 
 

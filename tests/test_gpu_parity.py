@@ -218,7 +218,7 @@ def _engine_vs_oracle(tag, dtype):
     si = 0
     while f"x{si}" in z:
         x = torch.from_numpy(z[f"x{si}"])
-        y, raws = eng(x.to(dtype).to(DEV))
+        y, aux = eng(x.to(dtype).to(DEV))
         torch.cuda.synchronize()
         R.FP16_EMULATION = True  # oracle with the engine's storage precision (fp16 weights/activations, fp32 accumulate)
         try:
@@ -226,14 +226,22 @@ def _engine_vs_oracle(tag, dtype):
                 yq, _ = m.forward(P, x)
         finally:
             R.FP16_EMULATION = False
+        if meta["task"] == "segment":  # Segment.forward: (cat(y, mc), (raw list, mc, protos)) (head.py:197)
+            raws, mc, proto = aux
+            assert torch.equal(mc, y[:, 4 + meta["nc"]:])
+            pe = np.abs(proto.float().cpu().numpy() - z[f"proto{si}"])
+            assert pe.max() < 2e-2 * np.abs(z[f"proto{si}"]).max(), pe.max()
+        else:
+            raws = aux
         stats.append((y.float().cpu().numpy(), z[f"y{si}"], yq.numpy(), [r.float().cpu().numpy() for r in raws],
-                      [z[f"raw{si}_{l}"] for l in range(3)]))
+                      [z[f"raw{si}_{l}"] for l in range(3)], meta["nc"]))
         si += 1
     eng.close()
     return stats
 
 
-@pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect"])
+@pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
+                                 "yolov8n_segment"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_engine_matches_reference_golden(tag, dtype):
     """Whole graph through the engine vs (a) the REFERENCE's own fp32 CPU outputs (golden) and (b) the oracle run
@@ -244,13 +252,16 @@ def test_engine_matches_reference_golden(tag, dtype):
     few anchors (measured: max 3.8e-3, mean <= 1.9e-5).  (a) adds the fp16 storage error itself, which a pure-CPU fp16
     emulation shows too (4.1e-3 on the 96x160 case): measured max 5.8e-3 / mean 2.7e-5 on scores, 0.49 px on boxes.
     Box error scales with stride x DFL-bin error (not with image size): 0.5 px = 7.8e-4 of a 640 image."""
-    for y, yref, yq, raws, rawref in _engine_vs_oracle(tag, dtype):
-        es, eb = np.abs(y[:, 4:] - yref[:, 4:]), np.abs(y[:, :4] - yref[:, :4])
+    for y, yref, yq, raws, rawref, nc in _engine_vs_oracle(tag, dtype):
+        es, eb = np.abs(y[:, 4:4 + nc] - yref[:, 4:4 + nc]), np.abs(y[:, :4] - yref[:, :4])
         assert es.max() < 1e-2 and es.mean() < 1e-4, (es.max(), es.mean())
         assert eb.max() < 1.0 and eb.mean() < 0.05, (eb.max(), eb.mean())
-        qs, qb = np.abs(y[:, 4:] - yq[:, 4:]), np.abs(y[:, :4] - yq[:, :4])
+        qs, qb = np.abs(y[:, 4:4 + nc] - yq[:, 4:4 + nc]), np.abs(y[:, :4] - yq[:, :4])
         assert qs.max() < 1e-2 and qs.mean() < 5e-5, (qs.max(), qs.mean())
         assert qb.max() < 1.0 and qb.mean() < 0.03, (qb.max(), qb.mean())
+        if y.shape[1] > 4 + nc:  # mask coefficients (raw conv outputs, O(1..10) magnitude)
+            em = np.abs(y[:, 4 + nc:] - yref[:, 4 + nc:])
+            assert em.max() < 2e-2 * np.abs(yref[:, 4 + nc:]).max(), em.max()
         for r, rr in zip(raws, rawref):
             assert np.abs(r - rr).max() / np.abs(rr).max() < 2e-2
 

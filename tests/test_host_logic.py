@@ -103,8 +103,27 @@ def test_plan_rejects_unsupported_graphs():
     cfg["backbone"][2] = [-1, 2, "C3k2_gai", [256, False, 0.25]]  # the BS-YOLO block: not accelerated yet
     with pytest.raises(NotImplementedError):
         Plan(cfg, 1, 64, 64)
+    cfg = stock_cfg("yolo11", "n")
+    cfg["head"] = list(cfg["head"])
+    cfg["head"][-1] = [[16, 19, 22], 1, "Pose", ["nc", [17, 3]]]  # other task heads stay on the reference
     with pytest.raises(NotImplementedError):
-        Plan(stock_cfg("yolo11", "n", task="segment"), 1, 64, 64)
+        Plan(cfg, 1, 64, 64)
+
+
+def test_segment_plan_matches_reference_work():
+    """YOLOv8l-seg @640 (BASELINE config 4): 210.4 GFLOP/image, protos at (160, 160)."""
+    p = Plan(stock_cfg("yolov8", "l", 80, "segment"), 1, 640, 640)
+    assert abs(p.flops / 1e9 - 210.4) < 0.5
+    assert p.meta["proto_hw"] == (160, 160) and p.meta["nm"] == 32 and p.meta["A"] == 8400
+    m = R.Model("yolov8", "l", 80, "segment")
+    want = {n for n, _ in m.param_specs() if not n.endswith("dfl.conv.weight")}
+    used = set()
+    for r in p.wrecs.values():
+        if r.kind in ("plain", "deconv"):
+            used |= {r.name + ".weight", r.name + ".bias"}
+        else:
+            used |= {r.name + ".conv.weight"} | {f"{r.name}.bn.{s}" for s in ("weight", "bias", "running_mean", "running_var")}
+    assert used == want
 
 
 def test_fold_matches_reference_known_answer():

@@ -128,4 +128,4 @@ if __name__ == "__main__":
         per_layer("yolo11n_detect")
         per_layer("yolo11s_detect")
     if what in ("time", "all"):
-        timing("s", 64, 640)
+        timing("s", int(sys.argv[2]) if len(sys.argv) > 2 else 64, 640)
