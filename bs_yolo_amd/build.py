@@ -24,6 +24,7 @@ SOURCES = {
     "detect.hip": [],
     "nms.hip": ["-ffp-contract=off"],
     "letterbox.hip": ["-ffp-contract=off"],
+    "masks.hip": ["-ffp-contract=off"],
     "engine.hip": [],
 }
 

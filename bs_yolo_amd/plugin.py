@@ -10,6 +10,7 @@ Three hooks, each using an extension point the reference already has (see INTEGR
                            embed (tasks.py:134-164), CPU tensors, unsupported modules) goes to the original forward.
   install_nms(ops_module)  ``ultralytics.utils.ops.non_max_suppression`` is looked up as a module attribute on every
                            call (models/yolo/detect/predict.py:25, detect/val.py:95): replacing the attribute suffices.
+  install_masks(ops_module) same for ``ultralytics.utils.ops.process_mask`` (models/yolo/segment/predict.py:53).
   install_preprocess(p)    rebinds ``BasePredictor.preprocess`` (engine/predictor.py:116-134) on a predictor instance so
                            lists of HWC BGR uint8 images are letterboxed on the device.
 """
@@ -25,7 +26,7 @@ from .engine import YoloEngine
 from .plan import Plan
 from .weights import BN_EPS
 
-SUPPORTED_HEADS = ("Detect",)
+SUPPORTED_HEADS = ("Detect", "Segment")
 
 
 def model_bn_eps(model) -> float:
@@ -108,6 +109,24 @@ def install_nms(ops_module):
     non_max_suppression._bsy_orig = orig
     ops_module.non_max_suppression = non_max_suppression
     return non_max_suppression
+
+
+def install_masks(ops_module):
+    """ops_module = ultralytics.utils.ops: GPU calls of process_mask (segment/predict.py:53) go to the HIP kernels."""
+    from . import masks as _masks
+    orig = ops_module.process_mask
+    if getattr(orig, "_bsy", False):
+        return orig
+
+    def process_mask(protos, masks_in, bboxes, shape, upsample=False):
+        if not (isinstance(protos, torch.Tensor) and protos.is_cuda):
+            return orig(protos, masks_in, bboxes, shape, upsample)
+        return _masks.process_mask(protos, masks_in, bboxes, shape, upsample)
+
+    process_mask._bsy = True
+    process_mask._bsy_orig = orig
+    ops_module.process_mask = process_mask
+    return process_mask
 
 
 def install_preprocess(predictor):

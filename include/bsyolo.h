@@ -180,6 +180,16 @@ int bsy_scale_boxes(float* det, const int32_t* counts, int B, int max_det, int r
 int bsy_letterbox(const uint8_t* const* imgs, const int32_t* hw, const int32_t* geom, int B, int H2, int W2, void* out,
                   int out_dtype, bsy_stream stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * process_mask + crop_mask (utils/ops.py:663-694, :644-660) for ONE image: protos (nm, mh, mw) f16/f32 BCHW slice,
+ * coef (n, >=nm) f32 rows of stride ldc (the mask columns of the NMS output), boxes (n, >=4) f32 xyxy in input-image
+ * pixels (stride ldb), lowres = n*mh*mw f32 scratch.  out = (n, ih, iw) when upsample else (n, mh, mw), 0/1 as
+ * u8 or f32 (the reference's `masks.gt_(0.0)` yields a float tensor).
+ * --------------------------------------------------------------------------------------------------------- */
+int bsy_process_mask(const void* protos, int proto_dtype, int nm, int mh, int mw, const float* coef, int ldc,
+                     const float* boxes, int ldb, int n, int ih, int iw, int upsample, float* lowres, void* out,
+                     int out_dtype, bsy_stream stream);
+
 const char* bsy_last_error(void);
 int bsy_version(void);
 

@@ -403,6 +403,30 @@ def test_nms_properties_at_full_size():
         assert again.tolist() == list(range(n))
 
 
+@pytest.mark.parametrize("upsample", [False, True])
+@pytest.mark.parametrize("pdtype", [torch.float32, torch.float16])
+def test_process_mask_matches_oracle(upsample, pdtype):
+    """process_mask / crop_mask (ops.py:663-694): binary masks equal the oracle's except where the pre-threshold
+    value is within fp32 summation noise of zero (different dot-product order than torch.matmul)."""
+    from bs_yolo_amd import masks as HM
+    g = torch.Generator().manual_seed(8)
+    nm, mh, mw, ih, iw, n = 32, 40, 48, 160, 192, 13
+    protos = torch.randn(nm, mh, mw, generator=g).to(pdtype)
+    coef = torch.randn(n, nm, generator=g)
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([iw * 0.6, ih * 0.6])
+    wh = torch.rand(n, 2, generator=g) * torch.tensor([iw * 0.4, ih * 0.4]) + 4
+    boxes = torch.cat((xy, xy + wh), 1)
+    ref = PP.process_mask(protos.float(), coef, boxes, (ih, iw), upsample)
+    got = HM.process_mask(protos.to(DEV), coef.to(DEV), boxes.to(DEV), (ih, iw), upsample)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    mism = (got.cpu() != ref).float().mean().item()
+    assert mism < 2e-4, mism
+    # empty input: (0, h, w)
+    e = HM.process_mask(protos.to(DEV), coef[:0].to(DEV), boxes[:0].to(DEV), (ih, iw), upsample)
+    assert e.shape[0] == 0
+
+
 def test_scale_boxes_matches_oracle():
     g = torch.Generator().manual_seed(2)
     B, max_det = 3, 20
