@@ -25,6 +25,10 @@ struct bsy_plan {
     char* workspace = nullptr;
     size_t workspace_bytes = 0;
     std::vector<hipEvent_t> events;
+    // side streams ("lanes") for independent op chains + the events that fork / join them
+    std::vector<hipStream_t> lanes;      // index 0 unused (lane 0 = caller's stream)
+    std::vector<hipEvent_t> lane_done;   // per lane: recorded at its tail before a join
+    hipEvent_t fork_ev = nullptr;
 };
 
 extern "C" int bsy_engine_create(int device, bsy_engine** out) {
@@ -83,6 +87,16 @@ extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, cons
         delete p;
         BSY_FAIL(BSY_ERR_HIP, "plan_create: hipMemset failed");
     }
+    int max_lane = 0;
+    for (const auto& o : p->ops) max_lane = o.lane > max_lane ? o.lane : max_lane;
+    if (max_lane > 32) { (void)hipFree(p->workspace); delete p; BSY_FAIL(BSY_ERR_ARG, "plan_create: too many lanes"); }
+    p->lanes.assign(max_lane + 1, nullptr);
+    p->lane_done.assign(max_lane + 1, nullptr);
+    bool ok = hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming) == hipSuccess;
+    for (int l = 1; l <= max_lane && ok; ++l)
+        ok = hipStreamCreateWithFlags(&p->lanes[l], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { bsy_plan_destroy(p); BSY_FAIL(BSY_ERR_HIP, "plan_create: stream/event creation failed"); }
     *out = p;
     return BSY_OK;
 }
@@ -90,6 +104,9 @@ extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, cons
 extern "C" void bsy_plan_destroy(bsy_plan* p) {
     if (!p) return;
     for (auto ev : p->events) (void)hipEventDestroy(ev);
+    for (auto ev : p->lane_done) if (ev) (void)hipEventDestroy(ev);
+    for (auto st : p->lanes) if (st) (void)hipStreamDestroy(st);
+    if (p->fork_ev) (void)hipEventDestroy(p->fork_ev);
     if (p->workspace) (void)hipFree(p->workspace);
     delete p;
 }
@@ -141,7 +158,7 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             a.ldd = op.dst.ld; a.Cout = op.dst.C; a.out_f32 = op.out_f32;
             a.res = R.h(op.res); a.ldr = op.res.buf >= 0 ? op.res.ld : 0;
             a.act = op.act; a.dst_scale = op.dst_scale; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
-            a.cfg = op.reserved[1] - 1;  // 0 = not tuned -> heuristic
+            a.cfg = op.tuned_cfg - 1;  // 0 = not tuned -> heuristic
             if (!R.ok) return BSY_ERR_ARG;
             if (cargs) { *cargs = a; return BSY_OK; }
             return launch_conv(a, s);
@@ -208,14 +225,46 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
 }
 }  // namespace
 
+extern "C" void bsy_plan_destroy(bsy_plan* p);
+
+// Ops are listed in a valid serial order.  An op on lane k > 0 runs on the plan's side stream k, which is forked from
+// the caller's stream (event wait) the first time it is used after a join; an op flagged `join` first waits for every
+// active side stream.  Chains on different lanes must not depend on each other between a fork and the next join
+// (plan.py guarantees it: per-level Detect / Segment branches).
 extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream) {
     if (!p || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_run: bad argument");
+    hipStream_t main = (hipStream_t)stream;
     Resolver R{p, ext, n_ext};
-    for (size_t i = 0; i < p->ops.size(); ++i) {
-        const int rc = run_op(p, p->ops[i], R, (hipStream_t)stream);
-        if (rc != BSY_OK) return rc;
+    unsigned active = 0;  // bit k: side stream k has work since the last join
+    int rc = BSY_OK;
+    for (size_t i = 0; i < p->ops.size() && rc == BSY_OK; ++i) {
+        const bsy_op& op = p->ops[i];
+        if (op.join && active) {
+            for (size_t l = 1; l < p->lanes.size(); ++l)
+                if (active & (1u << l)) {
+                    HIP_TRY(hipEventRecord(p->lane_done[l], p->lanes[l]));
+                    HIP_TRY(hipStreamWaitEvent(main, p->lane_done[l], 0));
+                }
+            active = 0;
+        }
+        hipStream_t s = main;
+        if (op.lane > 0) {
+            s = p->lanes[op.lane];
+            if (!(active & (1u << op.lane))) {
+                HIP_TRY(hipEventRecord(p->fork_ev, main));
+                HIP_TRY(hipStreamWaitEvent(s, p->fork_ev, 0));
+                active |= 1u << op.lane;
+            }
+        }
+        rc = run_op(p, op, R, s);
     }
-    return BSY_OK;
+    // never leave side streams un-joined (error paths included): the caller only synchronises its own stream
+    for (size_t l = 1; l < p->lanes.size(); ++l)
+        if (active & (1u << l)) {
+            (void)hipEventRecord(p->lane_done[l], p->lanes[l]);
+            (void)hipStreamWaitEvent(main, p->lane_done[l], 0);
+        }
+    return rc;
 }
 
 // Per-op autotuning of the conv kernel configuration (tile shape / K-step / ring depth): runs the plan once, timing
@@ -233,7 +282,7 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
         bsy_op& op = p->ops[i];
         if (op.kind != BSY_OP_CONV) { rc = run_op(p, op, R, s); continue; }
         ConvArgs a;
-        op.reserved[1] = 0;
+        op.tuned_cfg = 0;
         rc = run_op(p, op, R, s, &a);
         if (rc != BSY_OK) break;
         int cand[BSY_CONV_MAX_CFG];
@@ -253,7 +302,7 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
             if (ms < best) { best = ms; best_cfg = cand[c]; }
         }
         if (rc != BSY_OK) break;
-        op.reserved[1] = best_cfg + 1;
+        op.tuned_cfg = best_cfg + 1;
         a.cfg = best_cfg;
         rc = launch_conv(a, s);
     }
@@ -265,7 +314,7 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
 // HOST array out[n_ops]: the configuration id chosen for each op (-1 = not a conv / not tuned).
 extern "C" int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n) {
     if (!p || !out || n != (int)p->ops.size()) BSY_FAIL(BSY_ERR_ARG, "plan_get_tuning: bad argument");
-    for (int i = 0; i < n; ++i) out[i] = p->ops[i].kind == BSY_OP_CONV ? p->ops[i].reserved[1] - 1 : -1;
+    for (int i = 0; i < n; ++i) out[i] = p->ops[i].kind == BSY_OP_CONV ? p->ops[i].tuned_cfg - 1 : -1;
     return BSY_OK;
 }
 

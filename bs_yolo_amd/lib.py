@@ -53,7 +53,8 @@ class Op(C.Structure):
         ("lvl_stride", C.c_float * 3),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("level", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("lane", C.c_int32), ("tuned_cfg", C.c_int32), ("join", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 

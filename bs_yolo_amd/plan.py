@@ -77,7 +77,9 @@ class Plan:
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
         self.flops = 0  # 2*MAC of every dense/depthwise conv + attention matmuls, whole batch
         self.meta: Dict = {}
+        self._lane = 0
         self._build()
+        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV) for o in self.ops)
 
     # ---- buffers -------------------------------------------------------------------------------------------
     def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
@@ -109,7 +111,7 @@ class Plan:
         key = self._wrec(name, name=name, kind="plain" if plain else "conv", cout=cout, cin=cin, k=k, perm=perm)
         self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
                              src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
-                             act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name))
+                             act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane))
         self.flops += 2 * self.B * OH * OW * cout * cin * k * k
         return dst
 
@@ -130,7 +132,7 @@ class Plan:
             dst = self.alloc(src.C, src.H, src.W)
         key = self._wrec(name, name=name, kind="dw", cout=src.C, cin=1, k=3)
         self.ops.append(dict(kind=L.OP_DWCONV, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, dst=dst, res=res,
-                             ksize=3, stride=1, pad=1, act=int(act), wkey=key, name=name))
+                             ksize=3, stride=1, pad=1, act=int(act), wkey=key, name=name, lane=self._lane))
         self.flops += 2 * self.B * src.H * src.W * src.C * 9
         return dst
 
@@ -233,11 +235,15 @@ class Plan:
         ch = [t.C for t in xs]
         c2, c3 = max(16, ch[0] // 4, 64), max(ch[0], min(nc, 100))
         boxes, clss, msks = [], [], []
+        # every (level, branch) chain is independent until the decoder: give each its own lane so the engine runs them
+        # concurrently (the 40x40 / 20x20 chains are far too small to fill 256 CUs on their own)
         for i, x in enumerate(xs):
             assert not x.up
+            self._lane = 2 * i
             t = self.conv(f"{name}.cv2.{i}.0", x, c2, 3, 1)
             t = self.conv(f"{name}.cv2.{i}.1", t, c2, 3, 1)
             boxes.append(self.conv(f"{name}.cv2.{i}.2", t, 64, 1, 1, act=False, plain=True, out_f32=True))
+            self._lane = 2 * i + 1
             if legacy:
                 t = self.conv(f"{name}.cv3.{i}.0", x, c3, 3, 1)
                 t = self.conv(f"{name}.cv3.{i}.1", t, c3, 3, 1)
@@ -248,13 +254,15 @@ class Plan:
                 t = self.conv(f"{name}.cv3.{i}.1.1", t, c3, 1, 1)
             clss.append(self.conv(f"{name}.cv3.{i}.2", t, nc, 1, 1, act=False, plain=True, out_f32=True))
             if nm:
+                self._lane = 2 * len(xs) + i
                 c4 = max(ch[0] // 4, nm)
                 t = self.conv(f"{name}.cv4.{i}.0", x, c4, 3, 1)
                 t = self.conv(f"{name}.cv4.{i}.1", t, c4, 3, 1)
                 msks.append(self.conv(f"{name}.cv4.{i}.2", t, nm, 1, 1, act=False, plain=True, out_f32=True))
+        self._lane = 0
         A = sum(t.H * t.W for t in xs)
         strides = [float(self.H // t.H) for t in xs]
-        self.ops.append(dict(kind=L.OP_DECODE, H=self.H, W=self.W, OH=0, OW=0, nl=len(xs), nc=nc, nm=nm, A=A, box=boxes,
+        self.ops.append(dict(kind=L.OP_DECODE, join=1, H=self.H, W=self.W, OH=0, OW=0, nl=len(xs), nc=nc, nm=nm, A=A, box=boxes,
                              cls=clss, msk=msks, lvl_h=[t.H for t in xs], lvl_w=[t.W for t in xs], lvl_stride=strides,
                              dst=T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc + nm, 0, 0), out_dtype=self.out_dtype,
                              name=name + ".decode"))
@@ -375,4 +383,5 @@ class Plan:
                 o.lvl_w[j] = d["lvl_w"][j] if j < len(d.get("lvl_w", [])) else 0
                 o.lvl_stride[j] = d["lvl_stride"][j] if j < len(d.get("lvl_stride", [])) else 0.0
             o.in_dtype, o.out_dtype, o.level = d.get("in_dtype", 0), d.get("out_dtype", 0), d.get("level", 0)
+            o.lane, o.join, o.tuned_cfg = d.get("lane", 0), d.get("join", 0), 0
         return arr

@@ -86,7 +86,11 @@ typedef struct bsy_op {
     float lvl_stride[3];
     int32_t in_dtype, out_dtype; /* CONV_FIRST input dtype; DECODE/RAW output dtype */
     int32_t level;          /* RAW_NCHW: which level; output = external slot in dst.buf */
-    int32_t reserved[8];
+    int32_t lane;           /* 0 = caller's stream; k > 0 = plan-owned side stream k (independent op chains, e.g. the
+                             * per-level Detect branches, run concurrently; forked from lane 0 at first use) */
+    int32_t tuned_cfg;      /* conv: 1 + configuration id recorded by bsy_plan_autotune (0 = heuristic) */
+    int32_t join;           /* 1: every side stream is joined back into lane 0 before this op */
+    int32_t reserved[5];
 } bsy_op;
 
 int bsy_engine_create(int device, bsy_engine** out);
