@@ -359,8 +359,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
         if (ALIGNED) {
             const bool s1 = s_cb >= p.C0;
             const int ld = s1 ? p.ld1 : p.ld0;
-            const int kh = (KS == 1) ? 0 : s_tap / KS;
-            const int kw = (KS == 1) ? 0 : s_tap - kh * KS;
+            int kh = (KS == 1) ? 0 : s_tap / KS;
+            int kw = (KS == 1) ? 0 : s_tap - kh * KS;
+            if (p.dbg & 8) { kh = 1; kw = 1; }  // experiment: every tap reads the centre pixel (no im2col re-read through L2)
             // scalar part of the byte offset: tap displacement + channel base inside the source
             const unsigned sc = 2u * (unsigned)((kh * p.W + kw) * ld + (s1 ? s_cb - p.C0 : s_cb));
             const unsigned tbit = 1u << s_tap;

@@ -73,6 +73,18 @@ class YoloEngine:
         B, Cc, H, W = im.shape
         if Cc != 3:
             raise ValueError("expected 3 input channels")
+        # the kernels keep element offsets in 32 bits: split batches whose largest activation would exceed 2^31
+        # elements (e.g. 256 x 1280x1280) into equal chunks -- images are independent
+        big = max(self._packed.wrecs[next(iter(self._packed.wrecs))].cout, 8) * (H // 2) * (W // 2)
+        if B > 1 and B * big >= (1 << 31) - (1 << 24):
+            n_chunks = -(-B * big // ((1 << 31) - (1 << 24)))
+            step = -(-B // n_chunks)
+            outs = [self.forward(im[i:i + step], want_raw) for i in range(0, B, step)]
+            y = torch.cat([o[0] for o in outs])
+            if self.meta["nm"]:
+                raws = [torch.cat([o[1][0][l] for o in outs]) for l in range(3)] if want_raw else [None] * 3
+                return y, (raws, y[:, 4 + self.meta["nc"]:], torch.cat([o[1][2] for o in outs]))
+            return y, ([torch.cat([o[1][l] for o in outs]) for l in range(3)] if want_raw else [None] * 3)
         plan, h = self.plan_for(B, H, W, im.dtype, im.dtype)
         m = plan.meta
         y = torch.empty((B, 4 + m["nc"] + m["nm"], m["A"]), dtype=im.dtype, device=self.device)

@@ -266,6 +266,25 @@ def test_engine_matches_reference_golden(tag, dtype):
             assert np.abs(r - rr).max() / np.abs(rr).max() < 2e-2
 
 
+def test_engine_yolo11m_1280_config3_shape():
+    """BASELINE config 3 geometry (YOLO11m, 1280x1280, A = 33600) on a 2-image shard: engine vs the oracle."""
+    m = R.Model("yolo11", "m", 80, "detect")
+    P = R.synth_params(m, 3)
+    x = torch.rand(2, 3, 1280, 1280, generator=torch.Generator().manual_seed(2))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.inference_mode():
+        yref, _ = m.forward(P, x)
+    eng = YoloEngine(stock_cfg("yolo11", "m"), P)
+    y, raws = eng(x.to(DEV))  # fp32 in -> fp32 y (an fp16 y would round 1280-px box coordinates to 1-px steps)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (2, 84, 33600) and [tuple(r.shape[2:]) for r in raws] == [(160, 160), (80, 80), (40, 40)]
+    es = (y[:, 4:].float().cpu() - yref[:, 4:]).abs()
+    eb = (y[:, :4].float().cpu() - yref[:, :4]).abs()
+    assert es.max() < 2e-2 and es.mean() < 1e-4, (es.max(), es.mean())
+    assert eb.max() < 2.0 and eb.mean() < 0.05, (eb.max(), eb.mean())
+    eng.close()
+
+
 def test_engine_batch_independence_and_determinism():
     """Images are independent units: a batch equals its images run one by one; reruns are bit-identical."""
     m = R.Model("yolo11", "n", 80, "detect")
