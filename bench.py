@@ -139,12 +139,25 @@ def main():
             prof, plan = eng.profile(x)
         conv_ms = sum(t for (_, kind, t) in prof if kind == L.OP_CONV)
         n_conv = sum(1 for (_, kind, _) in prof if kind == L.OP_CONV)
-        conv_flops = 0
+        conv_flops = conv_bytes = 0
         for o in plan.ops:
             if o["kind"] == L.OP_CONV:
                 cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
                 conv_flops += 2 * B * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2
+                # algorithmic bytes: every operand read once, result written once
+                conv_bytes += B * o["H"] * o["W"] * o["src0"].C * 2 // (4 if o["src0"].up else 1)
+                if o.get("src1"):
+                    conv_bytes += B * o["H"] * o["W"] * o["src1"].C * 2 // (4 if o["src1"].up else 1)
+                out_b = B * o["OH"] * o["OW"] * o["dst"].C * (4 if o.get("out_f32") else 2)
+                conv_bytes += out_b * (2 if o.get("res") else 1)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        # HBM traffic of the same kernel family cannot be sampled from inside the process: it is the PMC measurement
+        # committed under profiles/ (tools/pmc_bench_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # passes, gfx950 correction), per launch like `achieved`; only valid for the default workload
+        traffic = None
+        tfile = ROOT / "profiles" / "r01_traffic.json"
+        if tfile.exists() and args.scale == "s" and S == 640 and B == 64:
+            traffic = round(json.load(open(tfile))["conv_mfma_hbm_bytes_per_launch_avg"])
         fwd_ms = sum(t for (_, _, t) in prof)
         out = {
             "metric": "images/sec YOLO11s 640x640 bs=64 (forward + NMS)", "value": round(value, 1), "unit": "images/sec",
@@ -158,7 +171,9 @@ def main():
                        "model_gflop_per_image": round(plan.flops / B / 1e9, 2),
                        "whole_path_tflops": round(plan.flops * world / (ms_step * 1e-3) / 1e12, 1)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_traffic.json)",
+                         "algorithmic_bytes_per_launch_avg": round(conv_bytes / n_conv),
                          "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": n_conv,
                          "flops_per_launch_avg": round(conv_flops / n_conv), "avg_launch_ms": round(conv_ms / n_conv, 5),
                          "conv_ms_per_step": round(conv_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4)},
