@@ -51,7 +51,7 @@ struct ConvArgs {
     int cfg;  // kernel configuration id (tile << 4 | variant) chosen by the autotuner; < 0 = heuristic
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
-#define BSY_CONV_MAX_CFG 16
+#define BSY_CONV_MAX_CFG 24
 int conv_candidates(const ConvArgs& a, int* out, int max_out);  // valid configuration ids, heuristic best first
 bool conv_cfg_valid(const ConvArgs& a, int cfg);
 

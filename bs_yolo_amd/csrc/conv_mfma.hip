@@ -495,12 +495,14 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 
 // Configuration ids: tile << 4 | variant.
 //   tile   : 0 = 256 px x 32 couts, 1 = 256 x 64, 2 = 128 x 128, 3 = 128 x 64 (4 waves); 4 = 256 x 128 (8 waves);
-//            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers)
+//            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers);
+//            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
-    if (cfg < 0 || tile > 6 || var > 3) return false;
+    if (cfg < 0 || tile > 7 || var > 3) return false;
+    if (tile == 7 && ((a.Cout & 255) || (var != 1 && var != 2))) return false;  // 256x256: whole 256-cout tiles only
     const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
     if (var >= 1 && !aligned) return false;
     if (var == 3 && !aligned64) return false;
@@ -512,23 +514,29 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
     const int Cin = a.C0 + a.C1;
     const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
     const long long M = (long long)a.B * a.OH * a.OW;
-    const int tile = a.Cout > 64 ? 2 : (a.Cout > 32 ? 1 : 0);
+    const int tile = a.Cout > 64 ? 2 : (a.Cout > 32 ? 1 : 0);  // heuristic default: widest cout tile that is not wasted
     int n = 0;
-    auto add = [&](int t, int v) { if (n < max_out) out[n++] = (t << 4) | v; };
+    auto add = [&](int t, int v) {
+        const int c = (t << 4) | v;
+        for (int i = 0; i < n; ++i) if (out[i] == c) return;
+        if (n < max_out && conv_cfg_valid(a, c)) out[n++] = c;
+    };
     if (!aligned) {
         add(tile, 0);
-        if (a.Cout > 32 && a.Cout <= 64) add(3, 0);
+        if (a.Cout > 32) { add(3, 0); add(6, 0); }
+        if (a.Cout > 64) add(5, 0);
         return n;
     }
-    if (aligned64) add(tile, 3);
-    add(tile, 1);
-    add(tile, 2);
-    if (a.Cout > 32) {  // 128 x 64: more (smaller) workgroups for small-M layers / narrower couts
-        if (tile != 3) { add(3, 1); if (aligned64) add(3, 3); }
+    // heuristic first, then the exhaustive (tile x variant) sweep the autotuner times
+    add(tile, aligned64 ? 3 : 1);
+    static const int tn[8] = {32, 64, 128, 64, 128, 128, 64, 256};
+    for (int t = 0; t < 8; ++t) {
+        if (tn[t] >= 2 * round_up(a.Cout, 32)) continue;      // more than half of the cout tile would be padding
+        if (tn[t] == 32 && a.Cout > 32) continue;               // 32-wide tiles re-read the pixels once per 32 couts
+        if (t == 4 && (a.Cout < 128 || M < 32768)) continue;    // 8-wave 256x128 only for wide, large layers
+        if (t == 7 && M < 16384) continue;
+        for (int v = 1; v <= 3; ++v) add(t, v);
     }
-    if (a.Cout >= 128 && M >= 32768) { add(4, 1); add(4, 2); }
-    if (a.Cout > 64) { add(5, 2); if (aligned64) add(5, 3); }
-    else if (a.Cout > 32) { add(6, 2); if (aligned64) add(6, 3); }
     return n;
 }
 
@@ -594,6 +602,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         if (tile == 3) BSY_VAR(KS_, 2, 2, 2, 1);                                          \
         if (tile == 5) BSY_VAR(KS_, 1, 4, 2, 1);                                          \
         if (tile == 6) BSY_VAR(KS_, 2, 2, 1, 1);                                          \
+        if (tile == 7 && var == 1) return launch_cfg<KS_, 4, 2, 2, 4, 3, true, 32>(k, s); \
+        if (tile == 7) return launch_cfg<KS_, 4, 2, 2, 4, 2, true, 32>(k, s);             \
         if (var == 1) return launch_cfg<KS_, 4, 2, 2, 2, 3, true, 32>(k, s);              \
         return launch_cfg<KS_, 4, 2, 2, 2, 2, true, 32>(k, s);                            \
     } while (0)
