@@ -80,8 +80,12 @@ def main():
         sys.exit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BSY_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from bs_yolo_amd import lib as L
@@ -103,7 +107,7 @@ def main():
         nonlocal gathered
         y, _ = eng(x, want_raw=False)
         det, counts = HN.nms_batched(y, 0.25, 0.7, max_det=300)
-        if world > 1:
+        if use_dist:
             if gathered is None:
                 gathered = (torch.empty((world,) + det.shape, dtype=det.dtype, device=dev),
                             torch.empty((world,) + counts.shape, dtype=counts.dtype, device=dev))
@@ -114,18 +118,18 @@ def main():
     for _ in range(args.warmup):
         det, counts = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         det, counts = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -178,10 +182,10 @@ def main():
                          "flops_per_launch_avg": round(conv_flops / n_conv), "avg_launch_ms": round(conv_ms / n_conv, 5),
                          "conv_ms_per_step": round(conv_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, sd)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
