@@ -3,8 +3,8 @@
 // Replaces model.0 Conv.forward_fuse (nn/modules/conv.py:149-151; layer 0 of cfg/models/11/yolo11-seg.yaml:17) and
 // absorbs the NCHW->NHWC layout change.  HBM-bound (reads 3*H*W, writes Cout*H*W/4 elements per image), so the job is
 // to touch every input byte ~once, coalesced, and keep the 27-deep contraction off the VALU:
-//   * a workgroup owns a 4 x 64 output tile; its 9 x 129 x 3 input patch is read plane by plane (consecutive lanes ->
-//     consecutive x, the NCHW-contiguous axis) and parked in LDS as fp16;
+//   * a workgroup owns a 4 x 64 output tile; its 9 x 129 x 3 input patch is read plane by plane with 16-byte vector
+//     loads (the 128 image-aligned columns of every row) and parked in LDS as fp16;
 //   * the contraction runs on v_mfma_f32_32x32x16_f16 with K = 27 padded to 32 -- the weights use the SAME packed layout
 //     as every other conv ([CoutPad][Kpad], k = (kh, kw, c)), held in registers as the A operand; the B operand
 //     (pixel on the lane) is gathered from the LDS patch: lane stride 2 pixels = 1 dword -> conflict-free 16-bit reads;
@@ -15,7 +15,8 @@
 #define CF_TW 64
 #define CF_PR (2 * CF_TH + 1)   // 9 patch rows
 #define CF_PC (2 * CF_TW + 1)   // 129 patch cols
-#define CF_ROW 132              // padded row stride (halves)
+#define CF_ROW 136              // row = [7 unused][1 halo col][128 cols]: the 128 image-aligned columns start 16-B aligned
+#define CF_C0 7                 // LDS column of patch column 0
 #define CF_PLANE (CF_PR * CF_ROW)
 #define CF_ZERO (3 * CF_PLANE)  // one zero element for the K padding
 
@@ -37,15 +38,39 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
     const int n = bid / tiles_y;
     const int iy0 = ty * CF_TH * 2 - 1, ix0 = tx * CF_TW * 2 - 1;
     const T* ip = img + (size_t)n * 3 * H * W;
-    for (int idx = tid; idx < 3 * CF_PR * CF_PC; idx += 256) {
-        const int c = idx / (CF_PR * CF_PC);
-        const int rem = idx - c * (CF_PR * CF_PC);
-        const int r = rem / CF_PC;
-        const int col = rem - r * CF_PC;
-        const int iy = iy0 + r, ix = ix0 + col;
-        float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = (float)ip[((size_t)c * H + iy) * W + ix];
-        patch[c * CF_PLANE + r * CF_ROW + col] = (half_t)v;
+    // patch column 0 is the halo (image column ix0 = 128*tx - 1); columns 1..128 are image columns 128*tx .. 128*tx+127,
+    // i.e. 16 aligned groups of 8 pixels per (channel, row): one vector load + one 16-byte LDS store each when the
+    // image row allows it (W % 8 == 0), element-wise otherwise
+    const bool vec = !(W & 7) && !((uintptr_t)img & 15);
+    for (int idx = tid; idx < 3 * CF_PR * 17; idx += 256) {
+        const int cr = idx / 17, j = idx - cr * 17;       // (channel,row) pair, group j: 0 = halo, 1..16 = 8-pixel groups
+        const int c = cr / CF_PR, r = cr - c * CF_PR;
+        const int iy = iy0 + r;
+        const bool rowok = (unsigned)iy < (unsigned)H;
+        const T* rp = ip + ((size_t)c * H + (rowok ? iy : 0)) * W;
+        half_t* lp = patch + c * CF_PLANE + r * CF_ROW + CF_C0;
+        if (j == 0) {
+            const int ix = ix0;
+            lp[0] = (rowok && ix >= 0) ? (half_t)(float)rp[ix] : (half_t)0.f;
+        } else {
+            const int x0 = ix0 + 1 + 8 * (j - 1);
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (rowok && x0 < W) {
+                if (vec) {  // x0 % 8 == 0 and W % 8 == 0: the whole group is inside the row
+                    if (sizeof(T) == 2) {
+                        v = *reinterpret_cast<const half8*>(rp + x0);
+                    } else {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(rp + x0), b = *reinterpret_cast<const f32x4*>(rp + x0 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = (half_t)a[e]; v[4 + e] = (half_t)b[e]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (x0 + e < W) ? (half_t)(float)rp[x0 + e] : (half_t)0.f;
+                }
+            }
+            *reinterpret_cast<half8*>(lp + 1 + 8 * (j - 1)) = v;
+        }
     }
     if (tid < 8) patch[CF_ZERO + tid] = (half_t)0.f;
 
@@ -78,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int pixbase = (2 * wave) * CF_ROW + 2 * (b * 32 + lrow);
+        const int pixbase = (2 * wave) * CF_ROW + CF_C0 + 2 * (b * 32 + lrow);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             half8 bf;

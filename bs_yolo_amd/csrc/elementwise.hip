@@ -13,78 +13,95 @@ __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
     return r;
 }
 
-#define DW_PX 4  // output pixels per thread along x: 3 x 6 input vectors serve 4 outputs (4.5 loads/output instead of 9)
+#define DW_PX 2   // output pixels per thread along x
+#define DW_RY 8   // output rows per thread: a rolling 3-row register window -> 2 vector loads per output instead of 9,
+                  // and the 9 x 8 weights are fetched once per 16 outputs
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W,
                                                         int C, const float* __restrict__ w,
                                                         const float* __restrict__ bias, half_t* __restrict__ dst,
                                                         int ldd, int act, const half_t* __restrict__ res, int ldr) {
     const int C8 = C >> 3;
-    const int WG = (W + DW_PX - 1) / DW_PX;
-    const long long total = (long long)B * H * WG * C8;
+    const int WG = (W + DW_PX - 1) / DW_PX, HG = (H + DW_RY - 1) / DW_RY;
+    const long long total = (long long)B * HG * WG * C8;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % C8) * 8;  // channel chunk fastest: a pixel's channels are contiguous -> coalesced
     long long t = idx / C8;
     const int x0 = (int)(t % WG) * DW_PX;
     t /= WG;
-    const int y = (int)(t % H);
-    const int n = (int)(t / H);
-    float acc[DW_PX][8];
+    const int y0 = (int)(t % HG) * DW_RY;
+    const int n = (int)(t / HG);
+    float wk[9][8], bs[8];
 #pragma unroll
-    for (int p = 0; p < DW_PX; ++p)
+    for (int k = 0; k < 9; ++k) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + k * C + c), w1 = *reinterpret_cast<const f32x4*>(w + k * C + c + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[p][j] = bias[c + j];
+        for (int j = 0; j < 4; ++j) { wk[k][j] = w0[j]; wk[k][4 + j] = w1[j]; }
+    }
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c), b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int iy = y + kh - 1;
-        if ((unsigned)iy >= (unsigned)H) continue;
-        float wk[3][8];
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const float* wp = w + (kh * 3 + kw) * C + c;
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { wk[kw][j] = w0[j]; wk[kw][4 + j] = w1[j]; }
-        }
-        const half_t* rowp = src + ((size_t)(n * H + iy) * W) * lds_ + c;
+        for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
+    }
+    const half_t* ip = src + (size_t)n * H * W * lds_ + c;
+    auto load_row = [&](int iy, half8 (&r)[DW_PX + 2]) {
+        const bool rowok = (unsigned)iy < (unsigned)H;
 #pragma unroll
         for (int q = 0; q < DW_PX + 2; ++q) {
             const int ix = x0 + q - 1;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            const half8 v = *reinterpret_cast<const half8*>(rowp + (size_t)ix * lds_);
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (rowok && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const half8*>(ip + ((size_t)iy * W + ix) * lds_);
+            r[q] = v;
+        }
+    };
+    half8 top[DW_PX + 2], mid[DW_PX + 2], bot[DW_PX + 2];
+    load_row(y0 - 1, top);
+    load_row(y0, mid);
+#pragma unroll 1
+    for (int dy = 0; dy < DW_RY; ++dy) {
+        const int y = y0 + dy;
+        if (y >= H) break;
+        load_row(y + 1, bot);
+        float acc[DW_PX][8];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int p = q - kw;  // output pixel this input column feeds through tap kw
-                if (p < 0 || p >= DW_PX) continue;
+        for (int p = 0; p < DW_PX; ++p)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[p][j] = fmaf((float)v[j], wk[kw][j], acc[p][j]);
+            for (int j = 0; j < 8; ++j) {
+                float a = bs[j];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    a = fmaf((float)top[p + kw][j], wk[kw][j], a);
+                    a = fmaf((float)mid[p + kw][j], wk[3 + kw][j], a);
+                    a = fmaf((float)bot[p + kw][j], wk[6 + kw][j], a);
+                }
+                acc[p][j] = a;
             }
+#pragma unroll
+        for (int p = 0; p < DW_PX; ++p) {
+            const int x = x0 + p;
+            if (x >= W) continue;
+            const size_t pix = (size_t)(n * H + y) * W + x;
+            half8 o;
+            if (res) {
+                const half8 r = *reinterpret_cast<const half8*>(res + pix * ldr + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)((act ? silu_f(acc[p][j]) : acc[p][j]) + (float)r[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)(act ? silu_f(acc[p][j]) : acc[p][j]);
+            }
+            *reinterpret_cast<half8*>(dst + pix * ldd + c) = o;
         }
-    }
 #pragma unroll
-    for (int p = 0; p < DW_PX; ++p) {
-        const int x = x0 + p;
-        if (x >= W) continue;
-        const size_t pix = (size_t)(n * H + y) * W + x;
-        half8 o;
-        if (res) {
-            const half8 r = *reinterpret_cast<const half8*>(res + pix * ldr + c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)((act ? silu_f(acc[p][j]) : acc[p][j]) + (float)r[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)(act ? silu_f(acc[p][j]) : acc[p][j]);
-        }
-        *reinterpret_cast<half8*>(dst + pix * ldd + c) = o;
+        for (int q = 0; q < DW_PX + 2; ++q) { top[q] = mid[q]; mid[q] = bot[q]; }
     }
 }
 
 int launch_dwconv(const DwArgs& a, hipStream_t s) {
     if ((a.C & 7) || (a.lds & 7) || (a.ldd & 7) || (a.res && (a.ldr & 7)) || ((uintptr_t)a.src & 15) ||
-        ((uintptr_t)a.dst & 15) || ((uintptr_t)a.res & 15) || ((uintptr_t)a.w & 15))
+        ((uintptr_t)a.dst & 15) || ((uintptr_t)a.res & 15) || ((uintptr_t)a.w & 15) || ((uintptr_t)a.b & 15))
         BSY_FAIL(BSY_ERR_ARG, "dwconv: channels/strides must be multiples of 8 and pointers 16-byte aligned");
-    const long long total = (long long)a.B * a.H * ((a.W + DW_PX - 1) / DW_PX) * (a.C / 8);
+    const long long total = (long long)a.B * ((a.H + DW_RY - 1) / DW_RY) * ((a.W + DW_PX - 1) / DW_PX) * (a.C / 8);
     if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "dwconv: empty");
     hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H,
                        a.W, a.C, a.w, a.b, a.dst, a.ldd, a.act, a.res, a.ldr);
