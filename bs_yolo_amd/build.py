@@ -19,6 +19,7 @@ SOURCES = {
     "err.cpp": [],
     "conv_mfma.hip": [],
     "conv_first.hip": [],
+    "stem_fused.hip": [],
     "elementwise.hip": [],
     "attention.hip": [],
     "detect.hip": [],

@@ -51,7 +51,7 @@ struct ConvArgs {
     int cfg;  // kernel configuration id (tile << 4 | variant) chosen by the autotuner; < 0 = heuristic
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
-#define BSY_CONV_MAX_CFG 24
+#define BSY_CONV_MAX_CFG 32
 int conv_candidates(const ConvArgs& a, int* out, int max_out);  // valid configuration ids, heuristic best first
 bool conv_cfg_valid(const ConvArgs& a, int cfg);
 
@@ -65,6 +65,22 @@ struct ConvFirstArgs {
     int ldd, Cout, act;
 };
 int launch_conv_first(const ConvFirstArgs& a, hipStream_t s);
+
+// Fused stem (stem_fused.hip): image -> Conv 3x3 s2 (3 -> C0) -> Conv 3x3 s2 (C0 -> C1), layer 0 kept on chip.
+struct StemArgs {
+    const void* img;
+    int img_dtype;
+    int B, H, W, OH, OW;    // image extent; OH/OW = layer-1 output extent
+    const void* w0;         // layer 0: packed f16 [CoutPad][32]
+    const float* b0;
+    const void* w1;         // layer 1: packed f16 [CoutPad][Kpad1], k = (kh, kw, c)
+    const float* b1;
+    int C0, C1, Kpad1;
+    half_t* dst;
+    int ldd, act;
+};
+bool stem_fused_supported(int C0, int C1, int H, int W);
+int launch_stem_fused(const StemArgs& a, hipStream_t s);
 
 struct DwArgs {
     const half_t* src;

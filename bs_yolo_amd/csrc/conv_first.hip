@@ -3,22 +3,19 @@
 // Replaces model.0 Conv.forward_fuse (nn/modules/conv.py:149-151; layer 0 of cfg/models/11/yolo11-seg.yaml:17) and
 // absorbs the NCHW->NHWC layout change.  HBM-bound (reads 3*H*W, writes Cout*H*W/4 elements per image), so the job is
 // to touch every input byte ~once, coalesced, and keep the 27-deep contraction off the VALU:
-//   * a workgroup owns a 4 x 64 output tile; its 9 x 129 x 3 input patch is read plane by plane with 16-byte vector
-//     loads (the 128 image-aligned columns of every row) and parked in LDS as fp16;
-//   * the contraction runs on v_mfma_f32_32x32x16_f16 with K = 27 padded to 32 -- the weights use the SAME packed layout
-//     as every other conv ([CoutPad][Kpad], k = (kh, kw, c)), held in registers as the A operand; the B operand
-//     (pixel on the lane) is gathered from the LDS patch: lane stride 2 pixels = 1 dword -> conflict-free 16-bit reads;
+//   * a workgroup owns a 4 x 64 output tile; its 9 x 132 x 3 input patch is read in aligned groups of 4 pixels per
+//     plane and parked in LDS pixel-interleaved with a zero 4th channel (image_conv.h);
+//   * the contraction runs on v_mfma_f32_32x32x16_f16 with K = 9 taps x 4 = 36 padded to 48 -- weights packed like every
+//     other conv ([CoutPad][Kpad], k = (kh, kw, c)) but with the zero 4th input channel, held in registers as the A
+//     operand; a lane's B fragment is two taps = two 8-byte LDS reads at compile-time offsets;
 //   * epilogue as conv_mfma.hip: the tile goes through LDS so every store is a coalesced 16-byte piece.
-#include "common.h"
+#include "image_conv.h"
 
 #define CF_TH 4
 #define CF_TW 64
 #define CF_PR (2 * CF_TH + 1)   // 9 patch rows
-#define CF_PC (2 * CF_TW + 1)   // 129 patch cols
-#define CF_ROW 136              // row = [7 unused][1 halo col][128 cols]: the 128 image-aligned columns start 16-B aligned
-#define CF_C0 7                 // LDS column of patch column 0
-#define CF_PLANE (CF_PR * CF_ROW)
-#define CF_ZERO (3 * CF_PLANE)  // one zero element for the K padding
+#define CF_NG 33                // 4-pixel groups per patch row: image columns 128*tx - 4 .. 128*tx + 127
+#define CF_ROWPX (4 * CF_NG)    // 132 patch pixels per row (8 bytes each)
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restrict__ img, const half_t* __restrict__ wgt,
@@ -26,7 +23,8 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
                                                               int H, int W, int OH, int OW, int ldd, int Cout, int act,
                                                               int tiles_x, int tiles_y) {
     constexpr int OT = CF_TH * CF_TW * (32 * NT + 8);  // fp16 output tile of the coalesced epilogue
-    constexpr int SM = (3 * CF_PLANE + 8) > OT ? (3 * CF_PLANE + 8) : OT;
+    constexpr int PT = CF_PR * CF_ROWPX * 4;
+    constexpr int SM = PT > OT ? PT : OT;
     __shared__ __attribute__((aligned(16))) half_t stile[SM];
     half_t* patch = stile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,62 +34,22 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int n = bid / tiles_y;
-    const int iy0 = ty * CF_TH * 2 - 1, ix0 = tx * CF_TW * 2 - 1;
+    const int iy0 = ty * CF_TH * 2 - 1, ix0 = tx * CF_TW * 2 - 4;
     const T* ip = img + (size_t)n * 3 * H * W;
-    // patch column 0 is the halo (image column ix0 = 128*tx - 1); columns 1..128 are image columns 128*tx .. 128*tx+127,
-    // i.e. 16 aligned groups of 8 pixels per (channel, row): one vector load + one 16-byte LDS store each when the
-    // image row allows it (W % 8 == 0), element-wise otherwise
-    const bool vec = !(W & 7) && !((uintptr_t)img & 15);
-    for (int idx = tid; idx < 3 * CF_PR * 17; idx += 256) {
-        const int cr = idx / 17, j = idx - cr * 17;       // (channel,row) pair, group j: 0 = halo, 1..16 = 8-pixel groups
-        const int c = cr / CF_PR, r = cr - c * CF_PR;
-        const int iy = iy0 + r;
-        const bool rowok = (unsigned)iy < (unsigned)H;
-        const T* rp = ip + ((size_t)c * H + (rowok ? iy : 0)) * W;
-        half_t* lp = patch + c * CF_PLANE + r * CF_ROW + CF_C0;
-        if (j == 0) {
-            const int ix = ix0;
-            lp[0] = (rowok && ix >= 0) ? (half_t)(float)rp[ix] : (half_t)0.f;
-        } else {
-            const int x0 = ix0 + 1 + 8 * (j - 1);
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (rowok && x0 < W) {
-                if (vec) {  // x0 % 8 == 0 and W % 8 == 0: the whole group is inside the row
-                    if (sizeof(T) == 2) {
-                        v = *reinterpret_cast<const half8*>(rp + x0);
-                    } else {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(rp + x0), b = *reinterpret_cast<const f32x4*>(rp + x0 + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = (half_t)a[e]; v[4 + e] = (half_t)b[e]; }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (x0 + e < W) ? (half_t)(float)rp[x0 + e] : (half_t)0.f;
-                }
-            }
-            *reinterpret_cast<half8*>(lp + 1 + 8 * (j - 1)) = v;
-        }
+    const bool vec = !(W & 3) && !((uintptr_t)img & (4 * sizeof(T) - 1));
+    for (int idx = tid; idx < CF_PR * CF_NG; idx += 256) {
+        const int r = idx / CF_NG, j = idx - r * CF_NG;
+        const ImgItem<T> it = vec ? img_item_load<T>(ip, H, W, iy0 + r, ix0 + 4 * j, true)
+                                  : img_item_load_slow<T>(ip, H, W, iy0 + r, ix0 + 4 * j, true);
+        img_item_park<T>(it, patch + (r * CF_ROWPX + 4 * j) * 4);
     }
-    if (tid < 8) patch[CF_ZERO + tid] = (half_t)0.f;
-
-    // weights: A operand, rows = output channels
-    half8 afr[NT][2];
+    // weights: A operand, rows = output channels, [CoutPad][64] with k = (kh, kw, c4)
+    half8 afr[NT][IMGC_KSUB];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            afr[a][s] = *reinterpret_cast<const half8*>(wgt + (size_t)(a * 32 + lrow) * 32 + 16 * s + 8 * lh);
-    // LDS offsets of this lane's 16 k-values relative to its pixel's patch origin
-    int koff[2][8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * s + 8 * lh + j;
-            const int tap = k / 3, c = k - tap * 3;
-            const int kh = tap / 3, kw = tap - kh * 3;
-            koff[s][j] = k < 27 ? c * CF_PLANE + kh * CF_ROW + kw : -1;
-        }
+        for (int s = 0; s < IMGC_KSUB; ++s)
+            afr[a][s] = *reinterpret_cast<const half8*>(wgt + (size_t)(a * 32 + lrow) * IMGC_KROW + 16 * s + 8 * lh);
     __syncthreads();
 
     f32x16 acc[NT][2];
@@ -103,12 +61,11 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int pixbase = (2 * wave) * CF_ROW + CF_C0 + 2 * (b * 32 + lrow);
+        // output pixel (row `wave`, column x = 32 b + lrow): its window starts at patch pixel (2 wave, 2 x + 3)
+        const int win = ((2 * wave) * CF_ROWPX + 2 * (b * 32 + lrow) + 3) * 4;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            half8 bf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bf[j] = patch[koff[s][j] >= 0 ? pixbase + koff[s][j] : CF_ZERO];
+        for (int s = 0; s < IMGC_KSUB; ++s) {
+            const half8 bf = img_frag<CF_ROWPX>(patch, win, s, lh);
 #pragma unroll
             for (int a = 0; a < NT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[a][s], bf, acc[a][b], 0, 0, 0);
         }

@@ -46,6 +46,7 @@ struct ConvK {
     int act;
     int dst_scale, dst_dy, dst_dx;
     int ntn;  // number of cout tiles
+    int ntm;  // number of pixel tiles (persistent kernel)
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
     int dbg;  // ablation switches for profiling (BSY_CONV_DBG): 1 = no DMA, 4 = no epilogue
 };
@@ -368,12 +369,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
 #pragma unroll
             for (int i = 0; i < PIW; ++i) {
                 const unsigned kcb = 16u * (unsigned)((i & 1) ? kc1 : kc0);
-                const unsigned o = (vmask[i] & tbit) ? 2u * (s1 ? off1[i] : off0[i]) + sc + kcb : BSY_OOB;
+                unsigned o = (vmask[i] & tbit) ? 2u * (s1 ? off1[i] : off0[i]) + sc + kcb : BSY_OOB;
+                if (p.dbg & 128) o &= 0xFFFF0u;  // experiment: every read inside 1 MiB (L2-resident), wrong numerics
+                if (p.dbg & 256) o &= 0x3FF0u;   // experiment: every read inside 16 KiB (L1-resident), wrong numerics
                 if (s1) dma16_buf(rs1, o, 0u, sP + (wave * PIW + i) * RPI * BK);
                 else dma16_buf(rs0, o, 0u, sP + (wave * PIW + i) * RPI * BK);
             }
-            s_cb += BK;
-            if (s_cb >= Cin) { s_cb = 0; ++s_tap; }
+            if (p.dbg & 64) {  // experiment (timing only, wrong numerics): taps innermost -> re-reads one K-step apart
+                if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += BK; }
+            } else {
+                s_cb += BK;
+                if (s_cb >= Cin) { s_cb = 0; ++s_tap; }
+            }
 #pragma unroll
             for (int j = 0; j < WIW; ++j)
                 dma16_buf(rsw, 2u * woff[j], (unsigned)kt * (2u * BK), sW + (wave * WIW + j) * RPI * BK);
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // K-step kt visible to every wave; every wave is done reading stage (kt-1)%STAGES
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        if (!(p.dbg & 16) && kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const half_t* sP = smem + (kt % STAGES) * STAGE;
         const half_t* sW = sP + TM * BK;
         // all fragment reads of the K-step first (distinct registers), then the MFMA burst: the LDS latency is paid
@@ -452,6 +459,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA burst (the scheduler would sink them back)
+        // experiment (dbg 16): issue the next DMA here, under the LDS read latency, instead of right after the barrier
+        if ((p.dbg & 16) && kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        if (p.dbg & 32) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < KSUB; ++ks)
 #pragma unroll
@@ -459,6 +469,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
 #pragma unroll
                 for (int b = 0; b < MT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+        if (p.dbg & 32) __builtin_amdgcn_s_setprio(0);
     }
     if (p.dbg & 4) {
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.dst)[0] = 1.f;  // keep the accumulators live
@@ -472,6 +483,228 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     } else {
         conv_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, lrow, lh);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent 1x1 kernel with dedicated store waves ("thin-K" layers: 2-24 K-steps per tile).
+//
+// With one tile per workgroup the load -> MFMA -> store phases of those layers only overlap across the 2-5 resident
+// workgroups: removing the epilogue alone made them 2.4x faster, removing the DMA alone 2x.  Here a workgroup of 8 waves
+// walks tiles (tile = blockIdx.x + j * gridDim.x) with ONE continuous DMA ring:
+//   waves 0-3 (compute): issue the LDS-DMA (running STAGES-1 K-steps ahead, ACROSS tile boundaries), MFMA, then park
+//                        bias + SiLU results as an fp16 tile in LDS and carry straight on with the next tile;
+//   waves 4-7 (store)  : walk the same barrier sequence, and after each tile's hand-over barrier move the parked tile to
+//                        HBM with coalesced 16-byte stores.  Their stores sit in THEIR OWN vmcnt queues, so the compute
+//                        waves' counted `s_waitcnt vmcnt(N)` keeps seeing nothing but DMA.
+// Barrier protocol (every wave executes every s_barrier): per tile nk "K-step" barriers B(t,k) + one hand-over barrier
+// E(t) after the compute waves' tile writes.  Store waves read tile t between E(t) and B(t+1,0); compute waves overwrite
+// the parked tile only after B(t+1,nk-1) >= B(t+1,0): no second tile buffer needed.
+// Restrictions (checked by conv_cfg_valid): ksize 1, ALIGNED channels, fp16 output, no residual, Cout % 8 == 0.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PERSIST_MAX_COUT 1024
+template <int WAVES_M, int WAVES_N, int MT, int NT, int STAGES, int BK>
+__global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
+    constexpr int TM = WAVES_M * MT * 32, TN = WAVES_N * NT * 32;
+    constexpr int TNS = TN < 64 ? 64 : TN;
+    constexpr int CPR = BK / 8, RPI = 64 / CPR;
+    constexpr int PIW = TM / (RPI * 4), WIW = TNS / (RPI * 4);
+    constexpr int STAGE = (TM + TNS) * BK, NDMA = PIW + WIW;
+    constexpr int SWS = BK == 32 ? 2 : 1;
+    constexpr int LDT = TN + 8, OT = TM * LDT;
+    static_assert(WAVES_M * WAVES_N == 4 && PIW >= 1 && WIW >= 1 && (BK == 32 || (!(PIW & 1) && !(WIW & 1))), "bad tile");
+    __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE + OT + 2 * PERSIST_MAX_COUT];
+    half_t* otile = smem + STAGES * STAGE;
+    float* sbias = reinterpret_cast<float*>(otile + OT);  // the whole (padded) bias vector, loaded once: keeps ordinary VMEM
+                                                          // loads -- and the vmcnt(0) they imply -- out of the tile loop
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.Kpad / BK;
+    const int ntiles = p.ntm * p.ntn;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;  // grid <= ntiles -> at least one
+    for (int i = tid; i < p.ntn * TN; i += 512) sbias[i] = p.bias[i];  // bias is padded to CoutPad (multiple of 128)
+    __syncthreads();
+
+    if (wave >= 4) {
+        // ------------------------------------------------ store waves ------------------------------------------------
+        const int st = tid - 256;
+        constexpr int CPRW = TN / 8, ITER = TM * CPRW / 256;
+        half_t* dst = reinterpret_cast<half_t*>(p.dst);
+        for (int t = 0; t < my_tiles; ++t) {
+            const int tile = blockIdx.x + t * G;
+            const int m0 = (tile / p.ntn) * TM, n0 = (tile % p.ntn) * TN;
+            for (int k = 0; k < nk; ++k) __builtin_amdgcn_s_barrier();  // B(t, k)
+            __builtin_amdgcn_s_barrier();                              // E(t): tile t is parked
+            half8 v[ITER];
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) {
+                const int id = st + 256 * i;
+                v[i] = *reinterpret_cast<const half8*>(otile + (id / CPRW) * LDT + (id % CPRW) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) {
+                const int id = st + 256 * i;
+                const int m = m0 + id / CPRW, c = n0 + (id % CPRW) * 8;
+                if (m < p.M && c < p.Cout) *reinterpret_cast<half8*>(dst + (size_t)m * p.ldd + c) = v[i];
+            }
+            // all LDS reads have returned (their values were consumed by the stores' operands): the next barrier this
+            // wave joins is B(t+1, 0), before which the compute waves cannot touch the parked tile again
+        }
+        return;
+    }
+
+    // ------------------------------------------------ compute + DMA waves ------------------------------------------------
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int rsub = lane / CPR, slot = lane % CPR;
+    const int kc0 = BK == 32 ? (slot ^ ((rsub >> 2) & 3)) : (slot ^ (rsub >> 1));
+    const int kc1 = BK == 32 ? kc0 : (slot ^ (4 | (rsub >> 1)));
+    const bsy_rsrc_t rs0 = make_rsrc(p.src0, p.span0), rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.span1 : 0u),
+                     rsw = make_rsrc(p.wgt, p.wspan);
+    const int ohw = p.OH * p.OW;
+    const int Cin = p.Cin8 * 8;
+
+    // issue-side state (runs ahead of the compute side, across tile boundaries)
+    unsigned off0[PIW], off1[PIW], woff[WIW];
+    bool rv[PIW];
+    int it = 0, ikt = 0, s_cb = 0;
+    auto setup_tile = [&](int tcount) {
+        const int tile = blockIdx.x + tcount * G;
+        const int m0 = (tile / p.ntn) * TM, n0 = (tile % p.ntn) * TN;
+#pragma unroll
+        for (int i = 0; i < PIW; ++i) {
+            const int m = m0 + (wave * PIW + i) * RPI + rsub;
+            rv[i] = m < p.M;
+            const int mm = rv[i] ? m : 0;
+            if (!(p.up0 | p.up1) && p.stride == 1) {
+                off0[i] = (unsigned)mm * (unsigned)p.ld0;
+                off1[i] = (unsigned)mm * (unsigned)p.ld1;
+            } else {
+                const int n = mm / ohw, rem = mm - n * ohw, oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int iy = oh * p.stride, ix = ow * p.stride;
+                const int H0 = p.H >> p.up0, W0 = p.W >> p.up0, H1 = p.H >> p.up1, W1 = p.W >> p.up1;
+                off0[i] = (unsigned)((n * H0 + (iy >> p.up0)) * W0 + (ix >> p.up0)) * (unsigned)p.ld0;
+                off1[i] = (unsigned)((n * H1 + (iy >> p.up1)) * W1 + (ix >> p.up1)) * (unsigned)p.ld1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WIW; ++j)
+            woff[j] = (unsigned)(n0 + (wave * WIW + j) * RPI + rsub) * (unsigned)p.Kpad + ((j & 1) ? kc1 : kc0) * 8;
+        s_cb = 0;
+    };
+    auto issue_step = [&](int stage) {
+        if (ikt == 0) setup_tile(it);
+        half_t* sP = smem + stage * STAGE;
+        half_t* sW = sP + TM * BK;
+        const bool s1 = s_cb >= p.C0;
+        const unsigned sc = 2u * (unsigned)(s1 ? s_cb - p.C0 : s_cb);
+#pragma unroll
+        for (int i = 0; i < PIW; ++i) {
+            const unsigned kcb = 16u * (unsigned)((i & 1) ? kc1 : kc0);
+            const unsigned o = rv[i] ? 2u * (s1 ? off1[i] : off0[i]) + sc + kcb : BSY_OOB;
+            if (s1) dma16_buf(rs1, o, 0u, sP + (wave * PIW + i) * RPI * BK);
+            else dma16_buf(rs0, o, 0u, sP + (wave * PIW + i) * RPI * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < WIW; ++j)
+            dma16_buf(rsw, 2u * woff[j], (unsigned)ikt * (2u * BK), sW + (wave * WIW + j) * RPI * BK);
+        s_cb += BK;
+        if (++ikt == nk) { ikt = 0; ++it; }
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int total = my_tiles * nk;
+    int ip = 0;
+    for (; ip < STAGES - 1 && ip < total; ++ip) issue_step(ip % STAGES);
+    int ckt = 0, ct = 0;
+    for (int cp = 0; cp < total; ++cp) {
+        const int later = min(STAGES - 2, total - 1 - cp);
+        if (later >= STAGES - 2 && STAGES > 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NDMA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // B(ct, ckt)
+        if (ip < total) { issue_step(ip % STAGES); ++ip; }
+        const half_t* sP = smem + (cp % STAGES) * STAGE;
+        const half_t* sW = sP + TM * BK;
+        constexpr int KSUB = BK / 16;
+        half8 bfr[KSUB][MT], afr[KSUB][NT];
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks) {
+            const int chunk = 2 * ks + lh;
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int row = (wm * MT + b) * 32 + lrow;
+                bfr[ks][b] = *reinterpret_cast<const half8*>(sP + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const int row = (wn * NT + a) * 32 + lrow;
+                afr[ks][a] = *reinterpret_cast<const half8*>(sW + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+        if (++ckt == nk) {
+            ckt = 0;
+            const int n0 = ((blockIdx.x + ct * G) % p.ntn) * TN;
+            // park bias + SiLU as fp16 (the store waves finished reading the previous tile before B(ct, 0))
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int prow = (wm * MT + b) * 32 + lrow;
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const int cl = (wn * NT + a) * 32;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = cl + 8 * g + 4 * lh;
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + n0 + c);
+                        half4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tv = acc[a][b][4 * g + e] + bv[e];
+                            o[e] = (half_t)(p.act ? silu_f(tv) : tv);
+                            acc[a][b][4 * g + e] = 0.f;
+                        }
+                        *reinterpret_cast<half4*>(otile + prow * LDT + c) = o;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // E(ct)
+            ++ct;
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT, int STAGES, int BK>
+static int launch_persist(const ConvK& k, hipStream_t s) {
+    constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
+    ConvK p = k;
+    p.ntn = ceil_div(k.Cout, TN);
+    p.ntm = ceil_div(k.M, TM);
+    const long long ntiles = (long long)p.ntm * p.ntn;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: tile count %lld out of range", ntiles);
+    constexpr int lds_bytes = ((TM + (TN < 64 ? 64 : TN)) * BK * STAGES + TM * (TN + 8) + 2 * PERSIST_MAX_COUT) * 2;
+    const int per_cu = 160 * 1024 / lds_bytes > 2 ? 2 : (160 * 1024 / lds_bytes);  // 512-thread workgroups: <= 2 per CU
+    const long long grid = ntiles < 256LL * per_cu ? ntiles : 256LL * per_cu;
+    hipLaunchKernelGGL((conv1x1_persist_kernel<WM, WN, MT, NT, STAGES, BK>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
 }
 
 template <int KS, int WM, int WN, int MT, int NT, int STAGES, bool ALIGNED, int BK>
@@ -489,6 +722,7 @@ static int launch_cfg(const ConvK& k, hipStream_t s) {
 extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, int* k_pad) {
     if (C2 <= 0 || C1 <= 0 || (ksize != 1 && ksize != 3)) BSY_FAIL(BSY_ERR_ARG, "conv_packed_dims: bad shape");
     if (cout_pad) *cout_pad = round_up(C2, 128);
+    if (C1 == 3) C1 = 4;  // image convs are packed with a zero 4th input channel (image_conv.h)
     if (k_pad) *k_pad = round_up(ksize * ksize * C1, 32);
     return BSY_OK;
 }
@@ -496,12 +730,18 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 // Configuration ids: tile << 4 | variant.
 //   tile   : 0 = 256 px x 32 couts, 1 = 256 x 64, 2 = 128 x 128, 3 = 128 x 64 (4 waves); 4 = 256 x 128 (8 waves);
 //            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers);
-//            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128)
+//            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128);
+//            8 = 128 x 128, 9 = 128 x 64 persistent 1x1 kernel (4 compute + 4 store waves, tiles walked per workgroup)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
-    if (cfg < 0 || tile > 7 || var > 3) return false;
+    if (cfg < 0 || tile > 9 || var > 3) return false;
+    if (tile >= 8) {  // persistent 1x1 kernel with store waves
+        const bool aligned_ = !(Cin & 31) && !(a.C0 & 31), aligned64_ = !(Cin & 63) && !(a.C0 & 63);
+        return a.ksize == 1 && aligned_ && var >= 1 && (var != 3 || aligned64_) && !a.out_f32 && !a.res && !(a.Cout & 7) && a.Cout <= 1024 &&
+               !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 && a.stride == 1;
+    }
     if (tile == 7 && ((a.Cout & 255) || (var != 1 && var != 2))) return false;  // 256x256: whole 256-cout tiles only
     const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
     if (var >= 1 && !aligned) return false;
@@ -529,12 +769,13 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
     }
     // heuristic first, then the exhaustive (tile x variant) sweep the autotuner times
     add(tile, aligned64 ? 3 : 1);
-    static const int tn[8] = {32, 64, 128, 64, 128, 128, 64, 256};
-    for (int t = 0; t < 8; ++t) {
+    static const int tn[10] = {32, 64, 128, 64, 128, 128, 64, 256, 128, 64};
+    for (int t = 0; t < 10; ++t) {
         if (tn[t] >= 2 * round_up(a.Cout, 32)) continue;      // more than half of the cout tile would be padding
         if (tn[t] == 32 && a.Cout > 32) continue;               // 32-wide tiles re-read the pixels once per 32 couts
         if (t == 4 && (a.Cout < 128 || M < 32768)) continue;    // 8-wave 256x128 only for wide, large layers
         if (t == 7 && M < 16384) continue;
+        if (t >= 8 && (M < 65536 || getenv("BSY_NO_PERSIST"))) continue;                      // persistent tiles need several tiles per workgroup
         for (int v = 1; v <= 3; ++v) add(t, v);
     }
     return n;
@@ -596,6 +837,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     } while (0)
 #define BSY_TILE(KS_)                                                                     \
     do {                                                                                  \
+        if (tile == 8 && var == 1) return launch_persist<2, 2, 2, 2, 3, 32>(k, s);        \
+        if (tile == 8 && var == 2) return launch_persist<2, 2, 2, 2, 2, 32>(k, s);        \
+        if (tile == 8) return launch_persist<2, 2, 2, 2, 2, 64>(k, s);                    \
+        if (tile == 9 && var == 1) return launch_persist<2, 2, 2, 1, 3, 32>(k, s);        \
+        if (tile == 9 && var == 2) return launch_persist<2, 2, 2, 1, 2, 32>(k, s);        \
+        if (tile == 9) return launch_persist<2, 2, 2, 1, 2, 64>(k, s);                    \
         if (tile == 0) BSY_VAR(KS_, 4, 1, 2, 1);                                          \
         if (tile == 1) BSY_VAR(KS_, 4, 1, 2, 2);                                          \
         if (tile == 2) BSY_VAR(KS_, 2, 2, 2, 2);                                          \

@@ -26,9 +26,13 @@ def pack_conv_weight(w: torch.Tensor, b: Optional[torch.Tensor], device) -> tupl
     cout, cin, k, _ = w.shape
     cp, kp = C.c_int(), C.c_int()
     L.check(L.lib.bsy_conv_packed_dims(cout, cin, k, C.byref(cp), C.byref(kp)))
+    w = w.detach().float().cpu()
+    if cin == 3:  # image conv: zero 4th input channel (csrc/image_conv.h)
+        w = torch.cat([w, torch.zeros(cout, 1, k, k)], 1)
+        cin = 4
     K = k * k * cin
     wp = torch.zeros(cp.value, kp.value, dtype=torch.float16)
-    wp[:cout, :K] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, K).half()
+    wp[:cout, :K] = w.permute(0, 2, 3, 1).reshape(cout, K).half()
     bp = torch.zeros(cp.value, dtype=torch.float32)
     if b is not None:
         bp[:cout] = b.detach().float().cpu()
@@ -63,6 +67,21 @@ def conv_first(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int = 3, 
     out = torch.empty((B, OH, OW, cout), dtype=torch.float16, device=img.device)
     L.check(L.lib.bsy_conv_first(_p(img), L.dtype_code(img.dtype), B, H, W, _p(wp), _p(bp), _p(out), cout, cout, k, s,
                                  int(act), _stream(img)))
+    return out
+
+
+def stem_fused(img: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor,
+               act: bool = True) -> torch.Tensor:
+    """Layers 0 + 1 in one launch: img BCHW fp16/fp32; w0 (C0,3,3,3), w1 (C1,C0,3,3) fp32 -> NHWC fp16 (B,H/4,W/4,C1)."""
+    assert img.is_contiguous() and img.shape[1] == 3
+    B, _, H, W = img.shape
+    c0, c1 = w0.shape[0], w1.shape[0]
+    w0p, b0p = pack_conv_weight(w0, b0, img.device)
+    w1p, b1p = pack_conv_weight(w1, b1, img.device)
+    oh0, ow0 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((B, (oh0 - 1) // 2 + 1, (ow0 - 1) // 2 + 1, c1), dtype=torch.float16, device=img.device)
+    L.check(L.lib.bsy_stem_fused(_p(img), L.dtype_code(img.dtype), B, H, W, _p(w0p), _p(b0p), c0, _p(w1p), _p(b1p), c1,
+                                 _p(out), c1, int(act), _stream(img)))
     return out
 
 

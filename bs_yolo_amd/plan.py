@@ -17,6 +17,7 @@ stock tables in graphs.py), so a reference model drops in without translation.
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple, Union
@@ -63,15 +64,22 @@ class WRec:
     b_off: int = -1
 
 
+def stem_supported(c0: int, c1: int, H: int, W: int) -> bool:
+    """Shapes csrc/stem_fused.hip accepts (mirror of stem_fused_supported / bsy_stem_fused_supported)."""
+    return (c0, c1) in ((32, 64), (16, 32)) and W % 4 == 0 and H >= 4 and W >= 4
+
+
 class Plan:
     """Flat op list + workspace buffer table for one (B, H, W)."""
 
     EXT_IMG, EXT_Y, EXT_RAW0 = 0, 1, 2  # external slots: image, prediction, raw level maps (2,3,4), proto (5)
     EXT_PROTO = 5
 
-    def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16):
+    def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
+                 fuse_stem: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
+        self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -352,6 +360,32 @@ class Plan:
             x = y
         self.layer_out = outs
         self.meta.update(scale=scale, n_layers=len(layers), legacy=legacy)
+        self._fuse_stem()
+
+    def _fuse_stem(self):
+        """Peephole: layer 0 (image conv) + layer 1 (3x3 s2 conv fed by layer 0 alone) -> one OP_STEM launch
+        (csrc/stem_fused.hip); layer 0's map is then never materialised (layer_out[0] = None)."""
+        if not self.fuse_stem or len(self.ops) < 2:
+            return
+        a, b = self.ops[0], self.ops[1]
+        if a["kind"] != L.OP_CONV_FIRST or b["kind"] != L.OP_CONV:
+            return
+        mid = a["dst"]
+        if (b["src0"] is not mid or b.get("src1") is not None or b.get("res") is not None or b["ksize"] != 3
+                or b["stride"] != 2 or b["out_f32"] or not b["act"] or a["ksize"] != 3 or a["stride"] != 2):
+            return
+        if not stem_supported(mid.C, b["dst"].C, self.H, self.W):
+            return
+        for o in self.ops[2:]:  # layer 0 must have no other reader
+            for key in ("src0", "src1", "res"):
+                t = o.get(key)
+                if t is not None and t.buf == mid.buf:
+                    return
+        self.buf_bytes[mid.buf] = 16  # never written
+        self.ops[0:2] = [dict(kind=L.OP_STEM, H=self.H, W=self.W, OH=b["OH"], OW=b["OW"], src0=a["src0"], dst=b["dst"],
+                              ksize=3, stride=2, pad=1, act=1, wkey=a["wkey"], wkey2=b["wkey"], mid_c=mid.C,
+                              in_dtype=self.in_dtype, name=a["name"] + "+" + b["name"].split(".")[-1], lane=0)]
+        self.layer_out[0] = None
 
     # ---- serialisation ------------------------------------------------------------------------------------------
     def c_ops(self):
@@ -372,6 +406,11 @@ class Plan:
                 w = self.wrecs[d["wkey"]]
                 assert w.w_off >= 0, "pack weights before serialising"
                 o.w_off, o.b_off = w.w_off, w.b_off
+            if "wkey2" in d:
+                w = self.wrecs[d["wkey2"]]
+                assert w.w_off >= 0, "pack weights before serialising"
+                o.w2_off, o.b2_off = w.w_off, w.b_off
+            o.mid_c = d.get("mid_c", 0)
             o.heads, o.key_dim, o.head_dim, o.scale = d.get("heads", 0), d.get("key_dim", 0), d.get("head_dim", 0), \
                 d.get("scale", 0.0)
             o.nl, o.nc, o.nm, o.A = d.get("nl", 0), d.get("nc", 0), d.get("nm", 0), d.get("A", 0)

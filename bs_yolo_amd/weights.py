@@ -62,6 +62,9 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
         if r.perm is not None:
             idx = torch.as_tensor(r.perm, dtype=torch.long)
             w, b = w[idx], b[idx]
+        if r.kind == "first":  # image conv: zero 4th input channel, k = (kh, kw, c4)  (csrc/image_conv.h)
+            w = torch.cat([w, torch.zeros(cout, 4 - cin, k, k)], 1)
+            cin = 4
         K = k * k * cin
         cp, kp = (cout + 127) // 128 * 128, (K + 31) // 32 * 32
         wp = torch.zeros(cp, kp, dtype=torch.float16)

@@ -61,7 +61,9 @@ enum bsy_op_kind {
     BSY_OP_ATTN = 4,       /* softmax(q^T k * scale) v, per (image, head); MFMA flash-style                   */
     BSY_OP_DECODE = 5,     /* Detect._inference: DFL + dist2bbox + sigmoid -> (B, 4+nc+nm, A)                 */
     BSY_OP_RAW_NCHW = 6,   /* raw per-level head maps NHWC f32 -> BCHW (the `x` list Detect.forward returns)  */
-    BSY_OP_NHWC2NCHW = 7   /* NHWC f16 view -> BCHW tensor (Segment protos, block.py:80-97 output)            */
+    BSY_OP_NHWC2NCHW = 7,  /* NHWC f16 view -> BCHW tensor (Segment protos, block.py:80-97 output)            */
+    BSY_OP_STEM = 8        /* layers 0 + 1 fused: image -> Conv 3x3 s2 (3 -> mid_c) -> Conv 3x3 s2 (mid_c -> dst.C);
+                            * w_off/b_off = layer 0, w2_off/b2_off = layer 1; the layer-0 map never reaches HBM   */
 };
 
 typedef struct bsy_op {
@@ -90,7 +92,8 @@ typedef struct bsy_op {
                              * per-level Detect branches, run concurrently; forked from lane 0 at first use) */
     int32_t tuned_cfg;      /* conv: 1 + configuration id recorded by bsy_plan_autotune (0 = heuristic) */
     int32_t join;           /* 1: every side stream is joined back into lane 0 before this op */
-    int32_t reserved[5];
+    int32_t mid_c;          /* STEM: channels of the fused-away layer-0 map */
+    int64_t w2_off, b2_off; /* STEM: layer-1 weights / bias (byte offsets into the weight blob) */
 } bsy_op;
 
 int bsy_engine_create(int device, bsy_engine** out);
@@ -123,13 +126,23 @@ int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream
  * b: f32 [CoutPad]; y: (B,OH,OW,ldy); res same geometry as y or NULL. */
 int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, const void* w, const float* b, void* y, int ldy,
                int C2, int ksize, int stride, int act, const void* res, int ldr, int y_f32, bsy_stream stream);
-/* Packed sizes for a (C2, C1, k, k) conv: rows padded to 128 output channels, K = k*k*C1 padded to 32. */
+/* Packed sizes for a (C2, C1, k, k) conv: rows padded to 128 output channels, K = k*k*C1 padded to 32.
+ * C1 == 3 (the image conv) packs a zero 4th input channel: K = k*k*4. */
 int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, int* k_pad);
 
-/* First conv (3x3, stride 2) from a BCHW image (f16 or f32): w packed like bsy_conv2d's ([CoutPad][32] f16,
- * k = (kh, kw, c)), b f32 [CoutPad] -> NHWC f16. */
+/* First conv (3x3, stride 2) from a BCHW image (f16 or f32): w packed like bsy_conv2d's with a zero 4th input
+ * channel ([CoutPad][64] f16, k = (kh, kw, c4)), b f32 [CoutPad] -> NHWC f16. */
 int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const void* w, const float* b, void* y,
                    int ldy, int C2, int ksize, int stride, int act, bsy_stream stream);
+
+/* Layers 0 + 1 of the stock graphs as ONE launch (cfg/models/11/yolo11.yaml:17-18, two Conv.forward_fuse calls,
+ * conv.py:149-151): img BCHW (f16 / f32) -> Conv(3, C0, 3, 2) -> Conv(C0, C1, 3, 2) -> NHWC f16 (B, OH1, OW1, ldy).
+ * w0/b0 as bsy_conv_first, w1/b1 as bsy_conv2d.  (C0, C1) in {(32, 64), (16, 32)}, W % 4 == 0; anything else is
+ * BSY_ERR_ARG (callers then run the two layers separately).  Bit-identical to bsy_conv_first + bsy_conv2d. */
+int bsy_stem_fused(const void* img, int img_dtype, int B, int H, int W, const void* w0, const float* b0, int C0,
+                   const void* w1, const float* b1, int C1, void* y, int ldy, int act, bsy_stream stream);
+/* 1 when bsy_stem_fused accepts this shape. */
+int bsy_stem_fused_supported(int C0, int C1, int H, int W);
 
 /* DWConv (conv.py:224-229) 3x3 s1: w f32 [9][C], b f32 [C]. */
 int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y, int ldy,

@@ -147,6 +147,41 @@ def test_conv_first_matches_oracle(dtype):
     np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape,c0,c1", [((2, 3, 64, 64), 32, 64), ((1, 3, 96, 160), 32, 64), ((3, 3, 38, 52), 32, 64),
+                                         ((2, 3, 70, 36), 16, 32), ((70, 3, 32, 32), 32, 64)])
+def test_stem_fused_matches_unfused_and_oracle(dtype, shape, c0, c1):
+    """Layers 0 + 1 as one launch (csrc/stem_fused.hip): bit-identical to bsy_conv_first + bsy_conv2d, and equal to
+    the fp32 reference of the two Conv.forward_fuse calls (conv.py:149-151) with the layer-0 map rounded to fp16.
+    Shapes cover ragged tiles (layer-1 maps 9 x 13, 17 x 9), heights that are not multiples of 4, and more tiles
+    than persistent workgroups (70 images)."""
+    g = torch.Generator().manual_seed(12)
+    img = torch.rand(*shape, generator=g)
+    w0 = h16(torch.randn(c0, 3, 3, 3, generator=g) * 0.3)
+    b0 = torch.randn(c0, generator=g) * 0.2
+    w1 = h16(torch.randn(c1, c0, 3, 3, generator=g) * (2.0 / (9 * c0)) ** 0.5)
+    b1 = torch.randn(c1, generator=g) * 0.2
+    x = img.to(dtype).to(DEV)
+    fused = O.stem_fused(x, w0, b0, w1, b1)
+    mid = O.conv_first(x, w0, b0)
+    w1p, b1p = O.pack_conv_weight(w1, b1, DEV)
+    two = O.conv2d_nhwc(mid, w1p, b1p, c1, 3, 2, True)
+    torch.cuda.synchronize()
+    assert fused.shape == two.shape
+    assert torch.equal(fused, two)
+    ref = F.silu(F.conv2d(h16(F.silu(F.conv2d(h16(img), w0, b0, 2, 1))), w1, b1, 2, 1))
+    np.testing.assert_allclose(nchw(fused.float().cpu()).numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
+
+
+def test_stem_fused_rejects_unsupported():
+    assert L.lib.bsy_stem_fused_supported(32, 64, 640, 640) == 1
+    assert L.lib.bsy_stem_fused_supported(64, 128, 640, 640) == 0  # yolo11m/l/x: layer-1 weights do not fit in registers
+    assert L.lib.bsy_stem_fused_supported(32, 64, 64, 66) == 0     # W % 4
+    img = torch.rand(1, 3, 64, 66, device=DEV).half()
+    with pytest.raises(L.BsyError):
+        O.stem_fused(img, torch.zeros(32, 3, 3, 3), torch.zeros(32), torch.zeros(64, 32, 3, 3), torch.zeros(64))
+
+
 @pytest.mark.parametrize("act,use_res", [(True, False), (False, True)])
 def test_dwconv_matches_oracle(act, use_res):
     g = torch.Generator().manual_seed(5)
@@ -298,6 +333,26 @@ def test_engine_batch_independence_and_determinism():
         yi, _ = eng(x[i:i + 1])
         assert torch.equal(yi[0], y[i])
     eng.close()
+
+
+@pytest.mark.parametrize("scale", ["n", "s"])
+def test_engine_stem_fusion_is_bit_identical(scale):
+    """The OP_STEM plan (layers 0 + 1 in one launch) returns exactly what the two-launch plan returns."""
+    m = R.Model("yolo11", scale, 80, "detect")
+    P = R.synth_params(m, 0)
+    cfg = stock_cfg("yolo11", scale)
+    fused, plain = YoloEngine(cfg, P, fuse_stem=True), YoloEngine(cfg, P, fuse_stem=False)
+    x = torch.rand(2, 3, 160, 96, generator=torch.Generator().manual_seed(3)).half().to(DEV)
+    pf, _ = fused.plan_for(2, 160, 96, torch.float16, torch.float16)
+    pp, _ = plain.plan_for(2, 160, 96, torch.float16, torch.float16)
+    assert pf.ops[0]["kind"] == L.OP_STEM and pp.ops[0]["kind"] == L.OP_CONV_FIRST
+    yf, rf = fused(x)
+    yp, rp = plain(x)
+    assert torch.equal(yf, yp)
+    for a, b in zip(rf, rp):
+        assert torch.equal(a, b)
+    fused.close()
+    plain.close()
 
 
 # ------------------------------------------------------------------------------------------------------------

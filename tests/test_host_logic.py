@@ -59,7 +59,7 @@ def test_op_struct_layout():
 def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     """Dense-conv FLOPs per 640x640 image equal the reference graph (BASELINE.md section 2 / SURVEY 8d); the
     reference counts 81 dense convs for n/s because DFL is a 1x1 conv there (block.py:58-77), here it lives in decode."""
-    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640)
+    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False)
     dense = 0
     n = 0
     for o in p.ops:
@@ -70,6 +70,25 @@ def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     assert n == nconv
     assert abs(dense / 1e9 - gflops) < 0.01 * gflops
     assert p.meta["A"] == 8400 and p.meta["strides"] == [8.0, 16.0, 32.0]
+
+
+def test_stem_fusion_peephole():
+    """Layers 0 + 1 become one OP_STEM launch where csrc/stem_fused.hip supports the widths (n: 16/32, s: 32/64);
+    m/l/x keep two launches.  Work accounting (plan.flops) and the parameter records do not change."""
+    for scale, fused in (("n", True), ("s", True), ("m", False)):
+        a = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=False)
+        b = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=True)
+        assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
+        if fused:
+            assert len(b.ops) == len(a.ops) - 1 and b.ops[0]["kind"] == L.OP_STEM
+            assert b.ops[0]["dst"] is not None and b.ops[0]["mid_c"] == a.ops[0]["dst"].C
+            assert b.ops[0]["wkey"] == "model.0" and b.ops[0]["wkey2"] == "model.1"
+            assert b.layer_out[0] is None and sum(b.buf_bytes) < sum(a.buf_bytes)
+        else:
+            assert len(b.ops) == len(a.ops) and b.ops[0]["kind"] == L.OP_CONV_FIRST
+    odd = Plan(stock_cfg("yolo11", "s"), 1, 64, 64, fuse_stem=True)
+    assert odd.ops[0]["kind"] == L.OP_STEM
+    assert L.OP_STEM == 8 and L.Op.mid_c.offset == 380 and L.Op.w2_off.offset == 384 and L.Op.b2_off.offset == 392
 
 
 def test_plan_consumes_exactly_the_reference_parameters():
