@@ -20,6 +20,7 @@ SOURCES = {
     "conv_mfma.hip": [],
     "conv_first.hip": [],
     "stem_fused.hip": [],
+    "bneck_fused.hip": [],
     "elementwise.hip": [],
     "attention.hip": [],
     "detect.hip": [],

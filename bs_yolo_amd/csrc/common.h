@@ -82,6 +82,20 @@ struct StemArgs {
 bool stem_fused_supported(int C0, int C1, int H, int W);
 int launch_stem_fused(const StemArgs& a, hipStream_t s);
 
+// Fused Bottleneck (bneck_fused.hip): y = x + conv3x3(conv3x3(x)), hidden map kept on chip.
+struct BneckArgs {
+    const half_t* src;  // (B,H,W,lds) view of C channels
+    int lds;
+    int B, H, W, C, CH;
+    const void *w1, *w2;   // packed f16 [CoutPad][Kpad1] (C -> CH) and [CoutPad][Kpad2] (CH -> C)
+    const float *b1, *b2;
+    int Kpad1, Kpad2;
+    half_t* dst;
+    int ldd, act;
+};
+bool bneck_fused_supported(int C, int CH);
+int launch_bneck_fused(const BneckArgs& a, hipStream_t s);
+
 struct DwArgs {
     const half_t* src;
     int lds;

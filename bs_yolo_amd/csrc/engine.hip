@@ -158,6 +158,19 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok) return BSY_ERR_ARG;
             return launch_stem_fused(a, s);
         }
+        case BSY_OP_BNECK: {
+            BneckArgs a;
+            a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W;
+            a.C = op.dst.C; a.CH = op.mid_c;
+            a.w1 = (const void*)(wb + op.w_off); a.b1 = (const float*)(wb + op.b_off);
+            a.w2 = (const void*)(wb + op.w2_off); a.b2 = (const float*)(wb + op.b2_off);
+            int cp = 0;
+            bsy_conv_packed_dims(a.CH, a.C, 3, &cp, &a.Kpad1);
+            bsy_conv_packed_dims(a.C, a.CH, 3, &cp, &a.Kpad2);
+            a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.act = op.act;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_bneck_fused(a, s);
+        }
         case BSY_OP_CONV: {
             ConvArgs a;
             a.src0 = R.h(op.src0); a.src1 = R.h(op.src1);
@@ -407,6 +420,23 @@ extern "C" int bsy_stem_fused(const void* img, int img_dtype, int B, int H, int 
 }
 
 extern "C" int bsy_stem_fused_supported(int C0, int C1, int H, int W) { return stem_fused_supported(C0, C1, H, W) ? 1 : 0; }
+
+extern "C" int bsy_bottleneck_fused(const void* x, int ldx, int B, int H, int W, int C, int CH, const void* w1,
+                                    const float* b1, const void* w2, const float* b2, void* y, int ldy, int act,
+                                    bsy_stream stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y) BSY_FAIL(BSY_ERR_ARG, "bottleneck: null pointer");
+    BneckArgs a;
+    a.src = (const half_t*)x; a.lds = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.CH = CH;
+    a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    int cp = 0;
+    if (C <= 0 || CH <= 0) BSY_FAIL(BSY_ERR_ARG, "bottleneck: bad widths");
+    bsy_conv_packed_dims(CH, C, 3, &cp, &a.Kpad1);
+    bsy_conv_packed_dims(C, CH, 3, &cp, &a.Kpad2);
+    a.dst = (half_t*)y; a.ldd = ldy; a.act = act;
+    return launch_bneck_fused(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_bottleneck_fused_supported(int C, int CH) { return bneck_fused_supported(C, CH) ? 1 : 0; }
 
 extern "C" int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y,
                              int ldy, int act, const void* res, int ldr, bsy_stream stream) {

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
             pre[i] = img_item_load<T>(ip, p.H, p.W, 4 * oy0 - 3 + it_r[i], 4 * ox0 - 4 + 4 * it_j[i], tid + 256 * i < ST_NITEM);
     };
 
+    // Retire the weight / bias loads HERE: left pending, the compiler waits for them at their first use inside the tile
+    // loop with vmcnt(0) -- on every iteration, which then also waits for the prefetch issued just before.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     int tile = blockIdx.x;
     if (tile < p.ntiles) fetch(tile);
     for (; tile < p.ntiles; tile += gridDim.x) {

@@ -85,6 +85,23 @@ def stem_fused(img: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, w1: torch.
     return out
 
 
+def bottleneck_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x + cv2(cv1(x)) in one launch.  x, out: (B,H,W,C) fp16 NHWC, possibly channel slices of wider buffers
+    (stride(2) = leading dimension); w1 (CH,C,3,3), w2 (C,CH,3,3) fp32 (BN already folded)."""
+    B, H, W, c = x.shape
+    assert x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and x.stride(0) == H * W * x.stride(2)
+    ch = w1.shape[0]
+    w1p, b1p = pack_conv_weight(w1, b1, x.device)
+    w2p, b2p = pack_conv_weight(w2, b2, x.device)
+    if out is None:
+        out = torch.empty((B, H, W, c), dtype=torch.float16, device=x.device)
+    assert out.shape == x.shape and out.stride(3) == 1 and out.stride(1) == W * out.stride(2)
+    L.check(L.lib.bsy_bottleneck_fused(_p(x), x.stride(2), B, H, W, c, ch, _p(w1p), _p(b1p), _p(w2p), _p(b2p), _p(out),
+                                       out.stride(2), 1, _stream(x)))
+    return out
+
+
 def dwconv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: bool = True,
                    res: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x (B,H,W,C) fp16; w (C,1,3,3) fp32.  DWConv (conv.py:224-229)."""

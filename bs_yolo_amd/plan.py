@@ -69,6 +69,11 @@ def stem_supported(c0: int, c1: int, H: int, W: int) -> bool:
     return (c0, c1) in ((32, 64), (16, 32)) and W % 4 == 0 and H >= 4 and W >= 4
 
 
+def bneck_supported(c: int, ch: int) -> bool:
+    """Widths csrc/bneck_fused.hip accepts (mirror of bsy_bottleneck_fused_supported)."""
+    return (c, ch) == (32, 16)
+
+
 class Plan:
     """Flat op list + workspace buffer table for one (B, H, W)."""
 
@@ -76,10 +81,11 @@ class Plan:
     EXT_PROTO = 5
 
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
-                 fuse_stem: Optional[bool] = None):
+                 fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
+        self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -87,7 +93,7 @@ class Plan:
         self.meta: Dict = {}
         self._lane = 0
         self._build()
-        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV) for o in self.ops)
+        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK) for o in self.ops)
 
     # ---- buffers -------------------------------------------------------------------------------------------
     def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
@@ -148,6 +154,15 @@ class Plan:
     def bottleneck(self, name: str, x: T, dst: T, shortcut: bool, k=(3, 3), e=0.5):
         """block.py:3405-3419: x + cv2(cv1(x))."""
         c_ = int(dst.C * e)
+        if (self.fuse_bneck and tuple(k) == (3, 3) and shortcut and x.C == dst.C and not x.up and not x.f32
+                and bneck_supported(x.C, c_)):
+            # one launch, hidden map kept in LDS (csrc/bneck_fused.hip)
+            k1 = self._wrec(name + ".cv1", name=name + ".cv1", kind="conv", cout=c_, cin=x.C, k=3, perm=None)
+            k2 = self._wrec(name + ".cv2", name=name + ".cv2", kind="conv", cout=dst.C, cin=c_, k=3, perm=None)
+            self.ops.append(dict(kind=L.OP_BNECK, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=x, dst=dst, ksize=3, stride=1,
+                                 pad=1, act=1, wkey=k1, wkey2=k2, mid_c=c_, name=name, lane=self._lane))
+            self.flops += 2 * self.B * x.H * x.W * 9 * 2 * c_ * x.C
+            return
         t = self.conv(name + ".cv1", x, c_, k[0], 1)
         self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=x if (shortcut and x.C == dst.C) else None)
 

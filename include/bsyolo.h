@@ -62,8 +62,10 @@ enum bsy_op_kind {
     BSY_OP_DECODE = 5,     /* Detect._inference: DFL + dist2bbox + sigmoid -> (B, 4+nc+nm, A)                 */
     BSY_OP_RAW_NCHW = 6,   /* raw per-level head maps NHWC f32 -> BCHW (the `x` list Detect.forward returns)  */
     BSY_OP_NHWC2NCHW = 7,  /* NHWC f16 view -> BCHW tensor (Segment protos, block.py:80-97 output)            */
-    BSY_OP_STEM = 8        /* layers 0 + 1 fused: image -> Conv 3x3 s2 (3 -> mid_c) -> Conv 3x3 s2 (mid_c -> dst.C);
+    BSY_OP_STEM = 8,       /* layers 0 + 1 fused: image -> Conv 3x3 s2 (3 -> mid_c) -> Conv 3x3 s2 (mid_c -> dst.C);
                             * w_off/b_off = layer 0, w2_off/b2_off = layer 1; the layer-0 map never reaches HBM   */
+    BSY_OP_BNECK = 9       /* Bottleneck(c, c, shortcut, k=(3,3), e=0.5) fused: dst = src0 + cv2(cv1(src0)), hidden
+                            * width mid_c; w_off/b_off = cv1, w2_off/b2_off = cv2                                  */
 };
 
 typedef struct bsy_op {
@@ -92,8 +94,8 @@ typedef struct bsy_op {
                              * per-level Detect branches, run concurrently; forked from lane 0 at first use) */
     int32_t tuned_cfg;      /* conv: 1 + configuration id recorded by bsy_plan_autotune (0 = heuristic) */
     int32_t join;           /* 1: every side stream is joined back into lane 0 before this op */
-    int32_t mid_c;          /* STEM: channels of the fused-away layer-0 map */
-    int64_t w2_off, b2_off; /* STEM: layer-1 weights / bias (byte offsets into the weight blob) */
+    int32_t mid_c;          /* STEM / BNECK: channels of the fused-away intermediate map */
+    int64_t w2_off, b2_off; /* STEM / BNECK: second conv's weights / bias (byte offsets into the weight blob) */
 } bsy_op;
 
 int bsy_engine_create(int device, bsy_engine** out);
@@ -143,6 +145,14 @@ int bsy_stem_fused(const void* img, int img_dtype, int B, int H, int W, const vo
                    const void* w1, const float* b1, int C1, void* y, int ldy, int act, bsy_stream stream);
 /* 1 when bsy_stem_fused accepts this shape. */
 int bsy_stem_fused_supported(int C0, int C1, int H, int W);
+
+/* Bottleneck.forward (block.py:3417-3419) with k = (3, 3), shortcut, g = 1: y = x + cv2(cv1(x)), cv1: C -> CH, cv2: CH -> C,
+ * both folded Conv+BN+SiLU, as ONE launch with the hidden map kept in LDS.  x: (B,H,W,ldx) view of C channels,
+ * y: (B,H,W,ldy); w1/b1, w2/b2 as bsy_conv2d.  (C, CH) = (32, 16) only; anything else is BSY_ERR_ARG (callers then
+ * run two bsy_conv2d).  Bit-identical to the two-launch path. */
+int bsy_bottleneck_fused(const void* x, int ldx, int B, int H, int W, int C, int CH, const void* w1, const float* b1,
+                         const void* w2, const float* b2, void* y, int ldy, int act, bsy_stream stream);
+int bsy_bottleneck_fused_supported(int C, int CH);
 
 /* DWConv (conv.py:224-229) 3x3 s1: w f32 [9][C], b f32 [C]. */
 int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y, int ldy,

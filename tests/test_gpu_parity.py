@@ -182,6 +182,43 @@ def test_stem_fused_rejects_unsupported():
         O.stem_fused(img, torch.zeros(32, 3, 3, 3), torch.zeros(32), torch.zeros(64, 32, 3, 3), torch.zeros(64))
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 40, 24), (3, 9, 13), (70, 8, 16), (1, 3, 5)])
+def test_bottleneck_fused_matches_unfused_and_oracle(shape):
+    """Bottleneck (block.py:3405-3419, k = (3,3), shortcut) as one launch (csrc/bneck_fused.hip): bit-identical to two
+    bsy_conv2d launches (the second with the residual) and equal to the fp32 reference with the hidden map rounded to
+    fp16.  Input and output are channel slices of one wider buffer, as inside C3k2's concat buffer; shapes cover
+    ragged tiles, maps smaller than one tile and more tiles than persistent workgroups."""
+    B, H, W = shape
+    c, ch, ld = 32, 16, 96
+    g = torch.Generator().manual_seed(21)
+    buf = h16(torch.randn(B, H, W, ld, generator=g))
+    w1 = h16(torch.randn(ch, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5)
+    b1 = torch.randn(ch, generator=g) * 0.2
+    w2 = h16(torch.randn(c, ch, 3, 3, generator=g) * (2.0 / (9 * ch)) ** 0.5)
+    b2 = torch.randn(c, generator=g) * 0.2
+    dbuf = buf.half().to(DEV)
+    x = dbuf[..., 32:64]
+    O.bottleneck_fused(x, w1, b1, w2, b2, out=dbuf[..., 64:96])
+    w1p, b1p = O.pack_conv_weight(w1, b1, DEV)
+    w2p, b2p = O.pack_conv_weight(w2, b2, DEV)
+    xc = x.contiguous()
+    mid = O.conv2d_nhwc(xc, w1p, b1p, ch, 3, 1, True)
+    two = O.conv2d_nhwc(mid, w2p, b2p, c, 3, 1, True, res=xc)
+    torch.cuda.synchronize()
+    assert torch.equal(dbuf[..., 64:96], two)
+    assert torch.equal(dbuf[..., :64].cpu(), buf[..., :64].half())  # the other slices are untouched
+    xr = nchw(buf[..., 32:64])
+    ref = xr + F.silu(F.conv2d(h16(F.silu(F.conv2d(xr, w1, b1, 1, 1))), w2, b2, 1, 1))
+    np.testing.assert_allclose(nchw(two.float().cpu()).numpy(), ref.numpy(), rtol=4e-3, atol=4e-3)
+
+
+def test_bottleneck_fused_rejects_unsupported():
+    assert L.lib.bsy_bottleneck_fused_supported(32, 16) == 1 and L.lib.bsy_bottleneck_fused_supported(64, 32) == 0
+    x = torch.zeros(1, 8, 8, 64, device=DEV).half()
+    with pytest.raises(L.BsyError):
+        O.bottleneck_fused(x, torch.zeros(32, 64, 3, 3), torch.zeros(32), torch.zeros(64, 32, 3, 3), torch.zeros(64))
+
+
 @pytest.mark.parametrize("act,use_res", [(True, False), (False, True)])
 def test_dwconv_matches_oracle(act, use_res):
     g = torch.Generator().manual_seed(5)
@@ -337,15 +374,17 @@ def test_engine_batch_independence_and_determinism():
 
 @pytest.mark.parametrize("scale", ["n", "s"])
 def test_engine_stem_fusion_is_bit_identical(scale):
-    """The OP_STEM plan (layers 0 + 1 in one launch) returns exactly what the two-launch plan returns."""
+    """The OP_STEM / OP_BNECK plan (fused launches) returns exactly what the plan of plain convs returns."""
     m = R.Model("yolo11", scale, 80, "detect")
     P = R.synth_params(m, 0)
     cfg = stock_cfg("yolo11", scale)
-    fused, plain = YoloEngine(cfg, P, fuse_stem=True), YoloEngine(cfg, P, fuse_stem=False)
+    fused, plain = YoloEngine(cfg, P, fuse_stem=True, fuse_bneck=True), YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False)
     x = torch.rand(2, 3, 160, 96, generator=torch.Generator().manual_seed(3)).half().to(DEV)
     pf, _ = fused.plan_for(2, 160, 96, torch.float16, torch.float16)
     pp, _ = plain.plan_for(2, 160, 96, torch.float16, torch.float16)
     assert pf.ops[0]["kind"] == L.OP_STEM and pp.ops[0]["kind"] == L.OP_CONV_FIRST
+    assert (scale != "s") or any(o["kind"] == L.OP_BNECK for o in pf.ops)
+    assert not any(o["kind"] == L.OP_BNECK for o in pp.ops)
     yf, rf = fused(x)
     yp, rp = plain(x)
     assert torch.equal(yf, yp)

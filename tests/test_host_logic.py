@@ -59,7 +59,7 @@ def test_op_struct_layout():
 def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     """Dense-conv FLOPs per 640x640 image equal the reference graph (BASELINE.md section 2 / SURVEY 8d); the
     reference counts 81 dense convs for n/s because DFL is a 1x1 conv there (block.py:58-77), here it lives in decode."""
-    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False)
+    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False)
     dense = 0
     n = 0
     for o in p.ops:
@@ -76,8 +76,8 @@ def test_stem_fusion_peephole():
     """Layers 0 + 1 become one OP_STEM launch where csrc/stem_fused.hip supports the widths (n: 16/32, s: 32/64);
     m/l/x keep two launches.  Work accounting (plan.flops) and the parameter records do not change."""
     for scale, fused in (("n", True), ("s", True), ("m", False)):
-        a = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=False)
-        b = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=True)
+        a = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=False, fuse_bneck=False)
+        b = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=True, fuse_bneck=False)
         assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
         if fused:
             assert len(b.ops) == len(a.ops) - 1 and b.ops[0]["kind"] == L.OP_STEM
@@ -89,6 +89,26 @@ def test_stem_fusion_peephole():
     odd = Plan(stock_cfg("yolo11", "s"), 1, 64, 64, fuse_stem=True)
     assert odd.ops[0]["kind"] == L.OP_STEM
     assert L.OP_STEM == 8 and L.Op.mid_c.offset == 380 and L.Op.w2_off.offset == 384 and L.Op.b2_off.offset == 392
+
+
+def test_bottleneck_fusion_peephole():
+    """C3k2's thin Bottleneck (32 -> 16 -> 32 with shortcut: model.2.m.0 of YOLO11s) becomes one OP_BNECK launch;
+    other widths keep two convs.  FLOP accounting and parameter records are unchanged."""
+    a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=False)
+    b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=True)
+    assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
+    fused = [o for o in b.ops if o["kind"] == L.OP_BNECK]
+    assert [o["name"] for o in fused] == ["model.2.m.0"] and len(b.ops) == len(a.ops) - 1
+    o = fused[0]
+    assert (o["src0"].C, o["mid_c"], o["dst"].C) == (32, 16, 32) and o["src0"].buf == o["dst"].buf  # slices of the concat buffer
+    assert o["wkey"] == "model.2.m.0.cv1" and o["wkey2"] == "model.2.m.0.cv2" and L.OP_BNECK == 9
+    for r in ("cv1", "cv2"):
+        ra, rb = a.wrecs[f"model.2.m.0.{r}"], b.wrecs[f"model.2.m.0.{r}"]
+        assert (ra.kind, ra.cout, ra.cin, ra.k) == (rb.kind, rb.cout, rb.cin, rb.k)
+    n = Plan(stock_cfg("yolo11", "n"), 1, 64, 64, fuse_bneck=True)  # same widths one level down
+    assert [o["name"] for o in n.ops if o["kind"] == L.OP_BNECK] == ["model.4.m.0", "model.16.m.0"]
+    m = Plan(stock_cfg("yolo11", "m"), 1, 64, 64, fuse_bneck=True)  # C3k blocks, e = 1.0: not fused
+    assert not any(o["kind"] == L.OP_BNECK for o in m.ops)
 
 
 def test_plan_consumes_exactly_the_reference_parameters():
