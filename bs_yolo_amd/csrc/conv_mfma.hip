@@ -47,6 +47,7 @@ struct ConvK {
     int dst_scale, dst_dy, dst_dx;
     int ntn;  // number of cout tiles
     int ntm;  // number of pixel tiles (persistent kernel)
+    int tiles_x, tiles_y, B;  // patch kernel: 8 x 16 output tiles per image
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
     int dbg;  // ablation switches for profiling (BSY_CONV_DBG): 1 = no DMA, 4 = no epilogue
 };
@@ -707,6 +708,207 @@ static int launch_persist(const ConvK& k, hipStream_t s) {
     return BSY_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Patch-based 3x3 stride-1 kernel (configuration tiles 10 / 11).
+//
+// The implicit-GEMM kernel above stages every input pixel NINE times (once per tap) through the vector-memory path and
+// LDS; at 128 x 128 tiles that is 64 B/clk/CU of LDS-DMA -- the texture-addresser's peak -- plus the matching LDS
+// writes, and measured MFMA utilisation stalls near 25-30 %.  A 3x3 stride-1 conv only needs each input pixel once
+// per workgroup: here a workgroup owns an 8 x 16 output tile, keeps the 10 x 18 input patch of the current 32-channel
+// chunk in LDS and reads all nine taps' B fragments from it (a tap is a constant entry offset); only the weights
+// (TN x 32 per (chunk, tap) step) stream through the 3-stage DMA ring.  Vector-memory bytes per MFMA drop ~2.5x.
+//   * K order: chunk-major, taps inside (the packed weights stay k = (kh, kw, c): step (chunk, tap) reads K offset
+//     tap * Cin + 32 * chunk).  That differs from the implicit-GEMM kernel's tap-major order, so results agree with it
+//     to fp32 accumulation rounding, not bit for bit.
+//   * patch: 192 entries (180 used) x 64 B, filled by LDS-DMA 16 entries per wave-instruction; slot s of entry q holds
+//     channel chunk s ^ ((q >> 2) & 3) (the DMA lane picks its source chunk), so 16 consecutive entries read
+//     conflict-free.  Double-buffered: chunk c + 1 is fetched at tap 0 of chunk c.
+//   * counted vmcnt: a wave has WIW weight DMAs per step in flight for two steps, plus PIW patch DMAs issued at tap 0.
+// Restrictions (conv_cfg_valid): 3x3, stride 1, one source, no upsample, Cin % 32 == 0, fp16 output.
+// ---------------------------------------------------------------------------------------------------------------------
+#define CP_TH 8
+#define CP_TW 16
+#define CP_PW (CP_TW + 2)
+#define CP_NPX ((CP_TH + 2) * CP_PW)  // 180
+#define CP_NPI 12                     // patch DMA wave-instructions per chunk (16 entries each)
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvK p) {
+    constexpr int TN = 64 * NT, TM = CP_TH * CP_TW;
+    constexpr int PBUF = CP_NPI * 16 * 32;  // halves per patch buffer
+    constexpr int WST = TN * 32;            // halves per weight stage
+    constexpr int STAGES = 3;
+    constexpr int PIW = CP_NPI / 4, WIW = TN / 64;  // DMA wave-instructions per wave: patch (per chunk) / weights (per step)
+    constexpr int OTILE = TM * (TN + 8);
+    constexpr int RING = 2 * PBUF + STAGES * WST;
+    constexpr int SMEM = RING > OTILE ? RING : OTILE;
+    __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+    half_t* sW = smem + 2 * PBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn_idx = wg % p.ntn;
+    int t = wg / p.ntn;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int n = t / p.tiles_y;
+    const int oy0 = ty * CP_TH, ox0 = tx * CP_TW, n0 = tn_idx * TN;
+
+    const bsy_rsrc_t rs0 = make_rsrc(p.src0, p.span0), rsw = make_rsrc(p.wgt, p.wspan);
+    // patch DMA coordinates: instruction i of this wave fills entries 16 (wave + 4 i) .. +15; lane -> (entry, slot)
+    unsigned poff[PIW];
+#pragma unroll
+    for (int i = 0; i < PIW; ++i) {
+        const int q = 16 * (wave + 4 * i) + (lane >> 2);
+        const int pr = q / CP_PW, pc = q - pr * CP_PW;
+        const int y = oy0 - 1 + pr, x = ox0 - 1 + pc;
+        const int chunk = (lane & 3) ^ ((q >> 2) & 3);
+        poff[i] = (q < CP_NPX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                      ? 2u * ((unsigned)((n * p.H + y) * p.W + x) * (unsigned)p.ld0 + 8u * chunk) : BSY_OOB;
+    }
+    // weight DMA coordinates: instruction j fills rows 16 (wave * WIW + j) .. +15 of the stage
+    unsigned woff[WIW];
+#pragma unroll
+    for (int j = 0; j < WIW; ++j) {
+        const int r = 16 * (wave * WIW + j) + (lane >> 2);
+        woff[j] = 2u * ((unsigned)(n0 + r) * (unsigned)p.Kpad + 8u * ((lane & 3) ^ ((r >> 2) & 3)));
+    }
+    const int Cin = p.Cin8 * 8;
+    const int nchunks = Cin >> 5, nsteps = 9 * nchunks;
+
+    auto issue_patch = [&](int chunk) {
+        half_t* dst = smem + (chunk & 1) * PBUF;
+#pragma unroll
+        for (int i = 0; i < PIW; ++i) dma16_buf(rs0, poff[i], 64u * (unsigned)chunk, dst + (wave + 4 * i) * 512);
+    };
+    int w_tap = 0, w_chunk = 0;  // (chunk, tap) of the next weight step to issue
+    auto issue_weights = [&](int step) {
+        half_t* dst = sW + (step % STAGES) * WST;
+        const unsigned koff = 2u * (unsigned)(w_tap * Cin + 32 * w_chunk);
+#pragma unroll
+        for (int j = 0; j < WIW; ++j) dma16_buf(rsw, woff[j], koff, dst + (wave * WIW + j) * 512);
+        if (++w_tap == 9) { w_tap = 0; ++w_chunk; }
+    };
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // lane pixel of MFMA tile b: tile row wm*4 + 2b + (lrow >> 4), column lrow & 15 -> patch entry of tap (0, 0)
+    int lq[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) lq[b] = (wm * 4 + 2 * b + (lrow >> 4)) * CP_PW + (lrow & 15);
+
+    issue_patch(0);
+    issue_weights(0);
+    if (nsteps > 1) issue_weights(1);
+    int tap = 0, chunk = 0;
+    for (int k = 0; k < nsteps; ++k) {
+        // wait for W(k) (and everything older: the patch of this chunk); younger: W(k+1) and, when this is tap 1, the
+        // next chunk's patch issued one step ago
+        const bool p_young = tap == 1 && chunk + 1 < nchunks;
+        if (k + 1 >= nsteps) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (p_young) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIW + PIW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIW) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // step k visible to every wave; every wave is done reading step k-1
+        if (tap == 0 && chunk + 1 < nchunks) issue_patch(chunk + 1);
+        if (k + 2 < nsteps) issue_weights(k + 2);
+        const half_t* sP = smem + (chunk & 1) * PBUF;
+        const half_t* sWk = sW + (k % STAGES) * WST;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = kh * CP_PW + kw;
+        half8 bfr[2][2], afr[2][NT];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int q = lq[b] + toff;
+            const int s0 = lh ^ ((q >> 2) & 3);
+            const half_t* e = sP + q * 32;
+            bfr[0][b] = *reinterpret_cast<const half8*>(e + (s0 << 3));
+            bfr[1][b] = *reinterpret_cast<const half8*>(e + ((s0 ^ 2) << 3));
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int row = (wn * NT + a) * 32 + lrow;
+            const int s0 = lh ^ ((row >> 2) & 3);
+            afr[0][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + (s0 << 3));
+            afr[1][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + ((s0 ^ 2) << 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+        if (++tap == 9) { tap = 0; ++chunk; }
+    }
+    __syncthreads();  // every wave has finished reading the last step: LDS becomes the output tile
+
+    constexpr int LDT = TN + 8;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int prow = (wm * 2 + b) * 32 + lrow;  // = tile row * 16 + column
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int cl = (wn * NT + a) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cl + 8 * g + 4 * lh;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tv = acc[a][b][4 * g + e] + bv[e];
+                    o[e] = (half_t)(p.act ? silu_f(tv) : tv);
+                }
+                *reinterpret_cast<half4*>(smem + prow * LDT + c) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPRW = TN / 8, ITER = TM * CPRW / 256;
+    half_t* dst = reinterpret_cast<half_t*>(p.dst);
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int id = tid + 256 * i;
+        const int prow = id / CPRW, cc = (id % CPRW) * 8;
+        const int oy = oy0 + (prow >> 4), ox = ox0 + (prow & 15), c = n0 + cc;
+        if (oy >= p.H || ox >= p.W || c >= p.Cout) continue;
+        const size_t pix = (size_t)(n * p.H + oy) * p.W + ox;
+        half8 v = *reinterpret_cast<const half8*>(smem + prow * LDT + cc);
+        if (p.res) {
+            const half8 r = *reinterpret_cast<const half8*>(p.res + pix * p.ldr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r[e]);
+        }
+        *reinterpret_cast<half8*>(dst + pix * p.ldd + c) = v;
+    }
+}
+
+template <int NT>
+static int launch_patch(const ConvK& k, hipStream_t s) {
+    ConvK p = k;
+    p.ntn = ceil_div(k.Cout, 64 * NT);
+    p.tiles_x = ceil_div(k.W, CP_TW);
+    p.tiles_y = ceil_div(k.H, CP_TH);
+    const long long nblk = (long long)k.B * p.tiles_x * p.tiles_y * p.ntn;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: tile count %lld out of range", nblk);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<NT>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
 template <int KS, int WM, int WN, int MT, int NT, int STAGES, bool ALIGNED, int BK>
 static int launch_cfg(const ConvK& k, hipStream_t s) {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
@@ -731,12 +933,18 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 //   tile   : 0 = 256 px x 32 couts, 1 = 256 x 64, 2 = 128 x 128, 3 = 128 x 64 (4 waves); 4 = 256 x 128 (8 waves);
 //            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers);
 //            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128);
-//            8 = 128 x 128, 9 = 128 x 64 persistent 1x1 kernel (4 compute + 4 store waves, tiles walked per workgroup)
+//            8 = 128 x 128, 9 = 128 x 64 persistent 1x1 kernel (4 compute + 4 store waves, tiles walked per workgroup);
+//            10 = 8x16 px x 128 couts, 11 = 8x16 px x 64 couts: patch-based 3x3 stride-1 kernel (variant 1 only)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
-    if (cfg < 0 || tile > 9 || var > 3) return false;
+    if (cfg < 0 || tile > 11 || var > 3) return false;
+    if (tile >= 10) {  // patch-based 3x3 stride-1 kernel (TN 128 / 64)
+        return var == 1 && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
+               !(a.Cout & 7) && !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 &&
+               (!a.res || (!(a.ldr & 7) && !((uintptr_t)a.res & 15))) && (tile == 10 ? a.Cout > 64 : true);
+    }
     if (tile >= 8) {  // persistent 1x1 kernel with store waves
         const bool aligned_ = !(Cin & 31) && !(a.C0 & 31), aligned64_ = !(Cin & 63) && !(a.C0 & 63);
         return a.ksize == 1 && aligned_ && var >= 1 && (var != 3 || aligned64_) && !a.out_f32 && !a.res && !(a.Cout & 7) && a.Cout <= 1024 &&
@@ -778,6 +986,7 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (t >= 8 && (M < 65536 || getenv("BSY_NO_PERSIST"))) continue;                      // persistent tiles need several tiles per workgroup
         for (int v = 1; v <= 3; ++v) add(t, v);
     }
+    if (a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) { add(10, 1); add(11, 1); }  // 3x3 s1 patch kernel (small maps waste tiles)
     return n;
 }
 
@@ -804,7 +1013,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     k.M = (int)M; k.Cin8 = Cin / 8; k.ntaps = a.ksize * a.ksize;
     k.Kpad = round_up(a.ksize * a.ksize * Cin, 32); k.nk = k.Kpad / 32;
     k.wgt = a.wgt; k.bias = a.bias; k.dst = a.dst; k.ldd = a.ldd; k.Cout = a.Cout; k.out_f32 = a.out_f32;
-    k.res = a.res; k.ldr = a.ldr; k.act = a.act;
+    k.res = a.res; k.ldr = a.ldr; k.act = a.act; k.B = a.B; k.tiles_x = k.tiles_y = 0;
     k.dst_scale = a.dst_scale > 0 ? a.dst_scale : 1; k.dst_dy = a.dst_dy; k.dst_dx = a.dst_dx; k.ntn = 1;
     // ---- configuration: explicit (autotuned, ConvArgs::cfg) or heuristic -----------------------------------------
     if (a.ksize == 3 && (a.up0 || a.up1)) BSY_FAIL(BSY_ERR_ARG, "conv: upsampled source only with ksize 1");
@@ -837,6 +1046,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     } while (0)
 #define BSY_TILE(KS_)                                                                     \
     do {                                                                                  \
+        if (tile == 10) return launch_patch<2>(k, s);                                     \
+        if (tile == 11) return launch_patch<1>(k, s);                                     \
         if (tile == 8 && var == 1) return launch_persist<2, 2, 2, 2, 3, 32>(k, s);        \
         if (tile == 8 && var == 2) return launch_persist<2, 2, 2, 2, 2, 32>(k, s);        \
         if (tile == 8) return launch_persist<2, 2, 2, 2, 2, 64>(k, s);                    \

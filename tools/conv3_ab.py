@@ -8,8 +8,10 @@ from bs_yolo_amd import ops as O
 
 SHAPES = [(64, 320, 320, 32, 64, 2), (64, 160, 160, 128, 128, 2), (64, 80, 80, 256, 256, 2), (64, 40, 40, 256, 512, 2),
           (64, 80, 80, 64, 64, 1), (64, 80, 80, 128, 64, 1), (64, 40, 40, 64, 64, 1), (64, 40, 40, 128, 128, 1), (64, 20, 20, 128, 128, 1),
-          (64, 160, 160, 32, 32, 1)]
+          (64, 160, 160, 32, 32, 1), (64, 80, 80, 32, 64, 1), (64, 80, 80, 64, 32, 1), (64, 40, 40, 256, 64, 1), (64, 40, 40, 64, 128, 1)]
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1]
+if len(sys.argv) > 2:
+    SHAPES = [s for s in SHAPES if s[5] == int(sys.argv[2])]
 dev = "cuda:0"
 for (B, H, W, cin, cout, s) in SHAPES:
     x = (torch.randn(B, H, W, cin, device=dev) * 0.5).half()
