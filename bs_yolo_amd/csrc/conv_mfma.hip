@@ -716,37 +716,44 @@ static int launch_persist(const ConvK& k, hipStream_t s) {
 // writes, and measured MFMA utilisation stalls near 25-30 %.  A 3x3 stride-1 conv only needs each input pixel once
 // per workgroup: here a workgroup owns an 8 x 16 output tile, keeps the 10 x 18 input patch of the current 32-channel
 // chunk in LDS and reads all nine taps' B fragments from it (a tap is a constant entry offset); only the weights
-// (TN x 32 per (chunk, tap) step) stream through the 3-stage DMA ring.  Vector-memory bytes per MFMA drop ~2.5x.
-//   * K order: chunk-major, taps inside (the packed weights stay k = (kh, kw, c): step (chunk, tap) reads K offset
-//     tap * Cin + 32 * chunk).  That differs from the implicit-GEMM kernel's tap-major order, so results agree with it
+// (3 taps x TN x 32 per (chunk, kernel row) step) stream through the DMA ring.  Vector-memory bytes per MFMA drop ~2.5x.
+//   * K order: chunk-major, taps inside (the packed weights stay k = (kh, kw, c): tap (kh, kw) of a chunk reads K offset
+//     (3 kh + kw) * Cin + 32 * chunk).  That differs from the implicit-GEMM kernel's tap-major order, so results agree with it
 //     to fp32 accumulation rounding, not bit for bit.
 //   * patch: 192 entries (180 used) x 64 B, filled by LDS-DMA 16 entries per wave-instruction; slot s of entry q holds
 //     channel chunk s ^ ((q >> 2) & 3) (the DMA lane picks its source chunk), so 16 consecutive entries read
 //     conflict-free.  Double-buffered: chunk c + 1 is fetched at tap 0 of chunk c.
-//   * counted vmcnt: a wave has WIW weight DMAs per step in flight for two steps, plus PIW patch DMAs issued at tap 0.
+//   * counted vmcnt: a wave has WIW weight DMAs per step in flight for STAGES - 1 steps, plus PIW patch DMAs issued at
+//     kernel row 0 of every chunk.
 // Restrictions (conv_cfg_valid): 3x3, stride 1, one source, no upsample, Cin % 32 == 0, fp16 output.
 // ---------------------------------------------------------------------------------------------------------------------
-#define CP_TH 8
 #define CP_TW 16
 #define CP_PW (CP_TW + 2)
-#define CP_NPX ((CP_TH + 2) * CP_PW)  // 180
-#define CP_NPI 12                     // patch DMA wave-instructions per chunk (16 entries each)
-template <int NT>
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvK p) {
+// A K-step is one (32-channel chunk, kernel row): 3 taps x 32 channels = 6 MFMA sub-steps per wave tile.  (One tap per
+// step left 4-8 MFMAs between barriers and a two-step prefetch distance far below the L2 latency.)
+// WM = wave rows: 2 -> 8 x 16 output tile, 4 waves (the shipped form).  4 -> 16 x 16 tile, 8 waves: measured 8-25 % SLOWER
+// on every YOLO11s layer (r01 notes in DESIGN.md) and therefore not instantiated.
+template <int NT, int STAGES, int WM>
+__global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) {
+    constexpr int CP_TH = 4 * WM, NW = 2 * WM, NTHR = 64 * NW;
+    constexpr int CP_NPX = (CP_TH + 2) * CP_PW;             // 180 / 324 patch entries
+    constexpr int PIW = (CP_NPX + 16 * NW - 1) / (16 * NW);  // patch DMA wave-instructions per wave per chunk (16 entries each)
+    constexpr int CP_NPI = PIW * NW;
     constexpr int TN = 64 * NT, TM = CP_TH * CP_TW;
     constexpr int PBUF = CP_NPI * 16 * 32;  // halves per patch buffer
-    constexpr int WST = TN * 32;            // halves per weight stage
-    constexpr int STAGES = 3;
-    constexpr int PIW = CP_NPI / 4, WIW = TN / 64;  // DMA wave-instructions per wave: patch (per chunk) / weights (per step)
+    constexpr int WTAP = TN * 32;           // halves per tap of a weight stage
+    constexpr int WST = 3 * WTAP;           // halves per weight stage (3 taps)
+    constexpr int WIW = 3 * TN / 64;        // weight DMA wave-instructions per wave per step (4-wave form; counted waits)
     constexpr int OTILE = TM * (TN + 8);
     constexpr int RING = 2 * PBUF + STAGES * WST;
     constexpr int SMEM = RING > OTILE ? RING : OTILE;
+    static_assert(STAGES == 2 || (STAGES == 3 && WM == 2), "ring depth (the 8-wave form deals the weight DMA unevenly: vmcnt(0) only)");
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
     half_t* sW = smem + 2 * PBUF;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;  // wave grid WM x 2: 64 pixels (4 tile rows) x NT*32 couts each
     const int lrow = lane & 31, lh = lane >> 5;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tn_idx = wg % p.ntn;
@@ -762,35 +769,42 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvK p) {
     unsigned poff[PIW];
 #pragma unroll
     for (int i = 0; i < PIW; ++i) {
-        const int q = 16 * (wave + 4 * i) + (lane >> 2);
+        const int q = 16 * (wave + NW * i) + (lane >> 2);
         const int pr = q / CP_PW, pc = q - pr * CP_PW;
         const int y = oy0 - 1 + pr, x = ox0 - 1 + pc;
         const int chunk = (lane & 3) ^ ((q >> 2) & 3);
         poff[i] = (q < CP_NPX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                       ? 2u * ((unsigned)((n * p.H + y) * p.W + x) * (unsigned)p.ld0 + 8u * chunk) : BSY_OOB;
     }
-    // weight DMA coordinates: instruction j fills rows 16 (wave * WIW + j) .. +15 of the stage
-    unsigned woff[WIW];
+    // weight DMA coordinates: the stage is [tap kw][TN rows][64 B] = 3 * TN/16 wave-instructions of 16 rows.  Four waves:
+    // wave w takes row groups w, w+4, .. of every tap.  Eight waves: row group g of tap kw goes to wave (g & 3) + 4 * (kw & 1)
+    // (waves 0-3 serve taps 0 and 2, waves 4-7 tap 1).
+    constexpr int WPT = TN / 64;  // row groups per wave per tap
+    unsigned woff[WPT];
 #pragma unroll
-    for (int j = 0; j < WIW; ++j) {
-        const int r = 16 * (wave * WIW + j) + (lane >> 2);
+    for (int j = 0; j < WPT; ++j) {
+        const int r = 16 * (4 * j + (wave & 3)) + (lane >> 2);
         woff[j] = 2u * ((unsigned)(n0 + r) * (unsigned)p.Kpad + 8u * ((lane & 3) ^ ((r >> 2) & 3)));
     }
     const int Cin = p.Cin8 * 8;
-    const int nchunks = Cin >> 5, nsteps = 9 * nchunks;
+    const int nchunks = Cin >> 5, nsteps = 3 * nchunks;
 
     auto issue_patch = [&](int chunk) {
         half_t* dst = smem + (chunk & 1) * PBUF;
 #pragma unroll
-        for (int i = 0; i < PIW; ++i) dma16_buf(rs0, poff[i], 64u * (unsigned)chunk, dst + (wave + 4 * i) * 512);
+        for (int i = 0; i < PIW; ++i) dma16_buf(rs0, poff[i], 64u * (unsigned)chunk, dst + (wave + NW * i) * 512);
     };
-    int w_tap = 0, w_chunk = 0;  // (chunk, tap) of the next weight step to issue
+    int w_kh = 0, w_chunk = 0;  // (chunk, kernel row) of the next weight step to issue
     auto issue_weights = [&](int step) {
         half_t* dst = sW + (step % STAGES) * WST;
-        const unsigned koff = 2u * (unsigned)(w_tap * Cin + 32 * w_chunk);
 #pragma unroll
-        for (int j = 0; j < WIW; ++j) dma16_buf(rsw, woff[j], koff, dst + (wave * WIW + j) * 512);
-        if (++w_tap == 9) { w_tap = 0; ++w_chunk; }
+        for (int kw = 0; kw < 3; ++kw) {
+            if (WM == 4 && (kw & 1) != (wave >> 2)) continue;  // wave-uniform
+            const unsigned koff = 2u * (unsigned)((w_kh * 3 + kw) * Cin + 32 * w_chunk);
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) dma16_buf(rsw, woff[j], koff, dst + kw * WTAP + (4 * j + (wave & 3)) * 512);
+        }
+        if (++w_kh == 3) { w_kh = 0; ++w_chunk; }
     };
 
     f32x16 acc[NT][2];
@@ -804,16 +818,24 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvK p) {
     int lq[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) lq[b] = (wm * 4 + 2 * b + (lrow >> 4)) * CP_PW + (lrow & 15);
+    int arow[NT], asw[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        arow[a] = ((wn * NT + a) * 32 + lrow) * 32;
+        asw[a] = (lh ^ ((lrow >> 2) & 3)) << 3;
+    }
 
     issue_patch(0);
-    issue_weights(0);
-    if (nsteps > 1) issue_weights(1);
-    int tap = 0, chunk = 0;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nsteps) issue_weights(s);
+    int kh = 0, chunk = 0;
     for (int k = 0; k < nsteps; ++k) {
-        // wait for W(k) (and everything older: the patch of this chunk); younger: W(k+1) and, when this is tap 1, the
-        // next chunk's patch issued one step ago
-        const bool p_young = tap == 1 && chunk + 1 < nchunks;
-        if (k + 1 >= nsteps) {
+        // wait for W(k) (and everything older: this chunk's patch); younger: W(k+1 .. k+STAGES-2) and, when this is the
+        // kernel row after a patch issue, the next chunk's patch
+        const int younger = min(STAGES - 2, nsteps - 1 - k);
+        const bool p_young = STAGES > 2 ? (kh == 1 && chunk + 1 < nchunks) : false;
+        if (younger <= 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (p_young) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIW + PIW) : "memory");
@@ -821,37 +843,37 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvK p) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIW) : "memory");
         }
         __builtin_amdgcn_s_barrier();  // step k visible to every wave; every wave is done reading step k-1
-        if (tap == 0 && chunk + 1 < nchunks) issue_patch(chunk + 1);
-        if (k + 2 < nsteps) issue_weights(k + 2);
+        if (kh == 0 && chunk + 1 < nchunks) issue_patch(chunk + 1);
+        if (k + STAGES - 1 < nsteps) issue_weights(k + STAGES - 1);
         const half_t* sP = smem + (chunk & 1) * PBUF;
         const half_t* sWk = sW + (k % STAGES) * WST;
-        const int kh = tap / 3, kw = tap - kh * 3;
-        const int toff = kh * CP_PW + kw;
-        half8 bfr[2][2], afr[2][NT];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int q = lq[b] + toff;
-            const int s0 = lh ^ ((q >> 2) & 3);
-            const half_t* e = sP + q * 32;
-            bfr[0][b] = *reinterpret_cast<const half8*>(e + (s0 << 3));
-            bfr[1][b] = *reinterpret_cast<const half8*>(e + ((s0 ^ 2) << 3));
+        for (int kw = 0; kw < 3; ++kw) {
+            const int toff = kh * CP_PW + kw;
+            half8 bfr[2][2], afr[2][NT];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int q = lq[b] + toff;
+                const int s0 = lh ^ ((q >> 2) & 3);
+                const half_t* e = sP + q * 32;
+                bfr[0][b] = *reinterpret_cast<const half8*>(e + (s0 << 3));
+                bfr[1][b] = *reinterpret_cast<const half8*>(e + ((s0 ^ 2) << 3));
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const half_t* e = sWk + kw * WTAP + arow[a];
+                afr[0][a] = *reinterpret_cast<const half8*>(e + asw[a]);
+                afr[1][a] = *reinterpret_cast<const half8*>(e + (asw[a] ^ 16));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const int row = (wn * NT + a) * 32 + lrow;
-            const int s0 = lh ^ ((row >> 2) & 3);
-            afr[0][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + (s0 << 3));
-            afr[1][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + ((s0 ^ 2) << 3));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
-        if (++tap == 9) { tap = 0; ++chunk; }
+        if (++kh == 3) { kh = 0; ++chunk; }
     }
     __syncthreads();  // every wave has finished reading the last step: LDS becomes the output tile
 
@@ -877,11 +899,11 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvK p) {
         }
     }
     __syncthreads();
-    constexpr int CPRW = TN / 8, ITER = TM * CPRW / 256;
+    constexpr int CPRW = TN / 8, ITER = TM * CPRW / NTHR;
     half_t* dst = reinterpret_cast<half_t*>(p.dst);
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTHR * i;
         const int prow = id / CPRW, cc = (id % CPRW) * 8;
         const int oy = oy0 + (prow >> 4), ox = ox0 + (prow & 15), c = n0 + cc;
         if (oy >= p.H || ox >= p.W || c >= p.Cout) continue;
@@ -896,15 +918,15 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const ConvK p) {
     }
 }
 
-template <int NT>
+template <int NT, int STAGES, int WM>
 static int launch_patch(const ConvK& k, hipStream_t s) {
     ConvK p = k;
     p.ntn = ceil_div(k.Cout, 64 * NT);
     p.tiles_x = ceil_div(k.W, CP_TW);
-    p.tiles_y = ceil_div(k.H, CP_TH);
+    p.tiles_y = ceil_div(k.H, 4 * WM);
     const long long nblk = (long long)k.B * p.tiles_x * p.tiles_y * p.ntn;
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: tile count %lld out of range", nblk);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<NT>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<NT, STAGES, WM>), dim3((unsigned)nblk), dim3(128 * WM), 0, s, p);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
@@ -934,14 +956,15 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 //            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers);
 //            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128);
 //            8 = 128 x 128, 9 = 128 x 64 persistent 1x1 kernel (4 compute + 4 store waves, tiles walked per workgroup);
-//            10 = 8x16 px x 128 couts, 11 = 8x16 px x 64 couts: patch-based 3x3 stride-1 kernel (variant 1 only)
+//            10 = 8x16 px x 128 couts (2-stage weight ring), 11 = 8x16 px x 64 couts (variant 1: 3 stages, 2: 2 stages):
+//            patch-based 3x3 stride-1 kernel
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
     if (cfg < 0 || tile > 11 || var > 3) return false;
     if (tile >= 10) {  // patch-based 3x3 stride-1 kernel (TN 128 / 64)
-        return var == 1 && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
+        return (var == 1 || (var == 2 && tile == 11)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
                !(a.Cout & 7) && !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 &&
                (!a.res || (!(a.ldr & 7) && !((uintptr_t)a.res & 15))) && (tile == 10 ? a.Cout > 64 : true);
     }
@@ -986,7 +1009,7 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (t >= 8 && (M < 65536 || getenv("BSY_NO_PERSIST"))) continue;                      // persistent tiles need several tiles per workgroup
         for (int v = 1; v <= 3; ++v) add(t, v);
     }
-    if (a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) { add(10, 1); add(11, 1); }  // 3x3 s1 patch kernel (small maps waste tiles)
+    if (a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) { add(10, 1); add(11, 1); add(11, 2); }  // 3x3 s1 patch kernel (small maps waste tiles)
     return n;
 }
 
@@ -1046,8 +1069,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     } while (0)
 #define BSY_TILE(KS_)                                                                     \
     do {                                                                                  \
-        if (tile == 10) return launch_patch<2>(k, s);                                     \
-        if (tile == 11) return launch_patch<1>(k, s);                                     \
+        if (tile == 10) return launch_patch<2, 2, 2>(k, s);                               \
+        if (tile == 11 && var == 1) return launch_patch<1, 3, 2>(k, s);                   \
+        if (tile == 11) return launch_patch<1, 2, 2>(k, s);                               \
         if (tile == 8 && var == 1) return launch_persist<2, 2, 2, 2, 3, 32>(k, s);        \
         if (tile == 8 && var == 2) return launch_persist<2, 2, 2, 2, 2, 32>(k, s);        \
         if (tile == 8) return launch_persist<2, 2, 2, 2, 2, 64>(k, s);                    \

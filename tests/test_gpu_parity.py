@@ -94,6 +94,8 @@ PATCH_CASES = [
     (1, 80, 80, 128, 64, 177, False),     # Detect cv2[0][0] of YOLO11s
     (3, 20, 20, 256, 256, 161, True),     # 8 chunks, 2 cout tiles, residual
     (2, 33, 31, 64, 40, 177, False),
+    (2, 24, 40, 96, 64, 178, True),       # 2-stage weight ring, 3 chunks
+    (1, 33, 47, 128, 136, 161, False),    # ragged everywhere, 2 cout tiles of 128
 ]
 
 
