@@ -137,7 +137,8 @@ def main():
     value = world * B * args.steps / dt
 
     if rank == 0:
-        # ---- roofline of the dominant kernel family (conv_mfma_kernel): HIP events around every op on the stream ----
+        # ---- roofline of the dominant kernel family (the plan's OP_CONV launches, csrc/conv_mfma.hip): HIP events around
+        #      every op on the stream ----
         prof = None
         for _ in range(3):
             prof, plan = eng.profile(x)
@@ -147,12 +148,13 @@ def main():
         for o in plan.ops:
             if o["kind"] == L.OP_CONV:
                 cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
-                conv_flops += 2 * B * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2
+                conv_flops += 2 * B * o["OH"] * o["OW"] * o.get("cout", o["dst"].C) * cin * o["ksize"] ** 2
                 # algorithmic bytes: every operand read once, result written once
                 conv_bytes += B * o["H"] * o["W"] * o["src0"].C * 2 // (4 if o["src0"].up else 1)
                 if o.get("src1"):
                     conv_bytes += B * o["H"] * o["W"] * o["src1"].C * 2 // (4 if o["src1"].up else 1)
-                out_b = B * o["OH"] * o["OW"] * o["dst"].C * (4 if o.get("out_f32") else 2)
+                mode = o.get("out_f32", 0)  # 0 f16 map, 1 f32 map, 2 / 3 fused decoder: class rows / 4 box rows of y (f16)
+                out_b = B * o["OH"] * o["OW"] * ({2: o.get("cout", 0), 3: 4}.get(mode, o["dst"].C)) * (4 if mode == 1 else 2)
                 conv_bytes += out_b * (2 if o.get("res") else 1)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
         # HBM traffic of the same kernel family cannot be sampled from inside the process: it is the PMC measurement
@@ -178,7 +180,7 @@ def main():
                          "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_traffic.json)",
                          "algorithmic_bytes_per_launch_avg": round(conv_bytes / n_conv),
-                         "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": n_conv,
+                         "kernel": "conv family of csrc/conv_mfma.hip: conv_mfma_kernel + conv1x1_persist_kernel + conv3x3_patch_kernel (all OP_CONV launches)", "launches_per_step": n_conv,
                          "flops_per_launch_avg": round(conv_flops / n_conv), "avg_launch_ms": round(conv_ms / n_conv, 5),
                          "conv_ms_per_step": round(conv_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4)},
         }

@@ -49,6 +49,18 @@ struct ConvArgs {
     int act;
     int dst_scale, dst_dy, dst_dx;
     int cfg;  // kernel configuration id (tile << 4 | variant) chosen by the autotuner; < 0 = heuristic
+    // Fused Detect decoder (epi != 0: the conv is the last layer of a head branch and writes the decoded prediction tensor
+    // y (B, nrows, A) directly instead of a logit map; `dst` is then unused):
+    //   epi 2: class scores  y[n, 4 + c, a0 + pix] = sigmoid(logit)                 (head.py:147)
+    //   epi 3: boxes         y[n, 0..3, a0 + pix]  = dist2bbox(DFL(logits)) * stride (head.py:141-146, block.py:58-77)
+    // raw (optional, may be null): the level's raw map (B, rawC, OH, OW) that Detect.forward also returns (head.py:74),
+    // box logits at channels 0..63, class logits at 64...
+    int epi;
+    void* y;
+    int y_f32, A, a0, nrows;
+    float lvl_stride;
+    void* raw;
+    int raw_f32, rawC;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 #define BSY_CONV_MAX_CFG 32

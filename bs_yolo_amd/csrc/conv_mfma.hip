@@ -48,6 +48,10 @@ struct ConvK {
     int ntn;  // number of cout tiles
     int ntm;  // number of pixel tiles (persistent kernel)
     int tiles_x, tiles_y, B;  // patch kernel: 8 x 16 output tiles per image
+    int epi, y_f32, A, a0, nrows, raw_f32, rawC;  // fused Detect decoder (ConvArgs::epi)
+    float lvl_stride;
+    void* y;
+    void* raw;
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
     int dbg;  // ablation switches for profiling (BSY_CONV_DBG): 1 = no DMA, 4 = no epilogue
 };
@@ -196,6 +200,105 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[NT][
                         for (int e = 0; e < 4; ++e)
                             if (c + e < p.Cout) dp[e] = (half_t)v[e];
                     }
+                }
+            }
+        }
+    }
+}
+
+// Fused Detect decoder (ConvArgs::epi): the last conv of a head branch turns its accumulators straight into rows of the
+// prediction tensor y (B, 4 + nc, A) -- what Detect._inference (head.py:113-148) computes from the concatenated logit
+// maps -- instead of storing f32 logits for a separate decode kernel to read back (0.3 GB per batch of 64, and the
+// decode launch itself).  In the accumulator layout a lane owns ONE pixel (= anchor), so for a fixed register the 32
+// lanes of a half-wave write 32 consecutive anchors of one y row: coalesced without staging.
+//   epi 2 (class logits): sigmoid, rows 4 + c.
+//   epi 3 (box logits, 4 sides x 16 DFL bins = 64 couts in one wave: WAVES_N == 1, NT == 2): a side's 16 bins sit in
+//          8 registers of this lane and 8 of lane ^ 32 -> softmax expectation with three cross-lane exchanges, then
+//          dist2bbox (xywh) * stride, rows 0..3.
+// The raw logits go to the level's raw map (B, 64 + nc, h, w) when the caller bound one.
+template <typename T>
+__device__ __forceinline__ void head_store(void* base, size_t idx, float v) { reinterpret_cast<T*>(base)[idx] = (T)v; }
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_head(const ConvK& p, f32x16 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
+                                                   int lrow, int lh) {
+    const int hw = p.OH * p.OW;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int m = m0 + (wm * MT + b) * 32 + lrow;
+        const bool mv = m < p.M;
+        const int mm = mv ? m : 0;
+        const int n = mm / hw, pix = mm - n * hw;
+        const size_t ybase = (size_t)n * p.nrows * p.A + p.a0 + pix;
+        const size_t rbase = (size_t)n * p.rawC * hw + pix;
+        if (p.epi == 2) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const int cl = n0 + (wn * NT + a) * 32;
+                if (cl >= p.Cout) continue;  // wave-uniform
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = cl + 8 * g + 4 * lh;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c0);  // bias is padded to CoutPad
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = c0 + e;
+                        if (!mv || c >= p.Cout) continue;
+                        const float v = acc[a][b][4 * g + e] + bv[e];
+                        const float sg = 1.0f / (1.0f + __expf(-v));
+                        const size_t yi = ybase + (size_t)(4 + c) * p.A;
+                        if (p.y_f32) head_store<float>(p.y, yi, sg); else head_store<half_t>(p.y, yi, sg);
+                        if (p.raw) {
+                            const size_t ri = rbase + (size_t)(64 + c) * hw;
+                            if (p.raw_f32) head_store<float>(p.raw, ri, v); else head_store<half_t>(p.raw, ri, v);
+                        }
+                    }
+                }
+            }
+        } else if (NT == 2) {  // epi 3; host guarantees WAVES_N == 1, n0 == 0, Cout == 64
+            float dist[4];
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd) {
+                const int a = sd >> 1, rb = 8 * (sd & 1);
+                float v[8];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 16 * sd + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[a & (NT - 1)][b][rb + 4 * g + e] + bv[e];
+                }
+                if (p.raw && mv) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const size_t ri = rbase + (size_t)(16 * sd + (i & 3) + 8 * (i >> 2) + 4 * lh) * hw;
+                        if (p.raw_f32) head_store<float>(p.raw, ri, v[i]); else head_store<half_t>(p.raw, ri, v[i]);
+                    }
+                }
+                float mx = v[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) mx = fmaxf(mx, v[i]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float den = 0.f, num = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float ex = __expf(v[i] - mx);
+                    den += ex;
+                    num += ex * (float)((i & 3) + 8 * (i >> 2) + 4 * lh);  // bin index of this register
+                }
+                den += __shfl_xor(den, 32, 64);
+                num += __shfl_xor(num, 32, 64);
+                dist[sd] = num / den;
+            }
+            if (mv && lh == 0) {
+                const int ay_i = pix / p.OW, ax_i = pix - ay_i * p.OW;
+                const float ax = (float)ax_i + 0.5f, ay = (float)ay_i + 0.5f;
+                const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+                const float o[4] = {((x1 + x2) * 0.5f) * p.lvl_stride, ((y1 + y2) * 0.5f) * p.lvl_stride,
+                                    (x2 - x1) * p.lvl_stride, (y2 - y1) * p.lvl_stride};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t yi = ybase + (size_t)r * p.A;
+                    if (p.y_f32) head_store<float>(p.y, yi, o[r]); else head_store<half_t>(p.y, yi, o[r]);
                 }
             }
         }
@@ -474,6 +577,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     }
     if (p.dbg & 4) {
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.dst)[0] = 1.f;  // keep the accumulators live
+        return;
+    }
+    if (p.epi) {  // fused Detect decoder
+        conv_epilogue_head<MT, NT>(p, acc, m0, n0, wm, wn, lrow, lh);
         return;
     }
     const bool lds_epi = !p.out_f32 && !(p.Cout & 7) && !(p.ldd & 7) && !((uintptr_t)p.dst & 15) && p.dst_scale == 1 &&
@@ -963,6 +1070,8 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
     if (cfg < 0 || tile > 11 || var > 3) return false;
+    if (a.epi && tile >= 8) return false;           // fused decoder: implicit-GEMM kernel only
+    if (a.epi == 3 && tile != 1) return false;      // DFL needs all 64 box couts in one wave: the 256 x 64 tile (4 x 1 waves, NT 2)
     if (tile >= 10) {  // patch-based 3x3 stride-1 kernel (TN 128 / 64)
         return (var == 1 || (var == 2 && tile == 11)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
                !(a.Cout & 7) && !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 &&
@@ -985,7 +1094,7 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
     const int Cin = a.C0 + a.C1;
     const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
     const long long M = (long long)a.B * a.OH * a.OW;
-    const int tile = a.Cout > 64 ? 2 : (a.Cout > 32 ? 1 : 0);  // heuristic default: widest cout tile that is not wasted
+    const int tile = a.epi == 3 ? 1 : (a.Cout > 64 ? 2 : (a.Cout > 32 ? 1 : 0));  // heuristic default: widest cout tile that is not wasted
     int n = 0;
     auto add = [&](int t, int v) {
         const int c = (t << 4) | v;
@@ -1030,6 +1139,13 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         BSY_FAIL(BSY_ERR_ARG, "conv: output extent mismatch");
     const long long M = (long long)a.B * a.OH * a.OW;
     if (M <= 0 || M > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: M out of range");
+    if (a.epi) {
+        if ((a.epi != 2 && a.epi != 3) || !a.y || a.A <= 0 || a.a0 < 0 || a.a0 + a.OH * a.OW > a.A || a.dst_scale > 1 || a.res)
+            BSY_FAIL(BSY_ERR_ARG, "conv: bad fused-decoder arguments (epi %d)", a.epi);
+        if (a.epi == 3 && (a.Cout != 64 || a.nrows < 4)) BSY_FAIL(BSY_ERR_ARG, "conv: DFL epilogue needs 64 box channels");
+        if (a.epi == 2 && a.nrows < 4 + a.Cout) BSY_FAIL(BSY_ERR_ARG, "conv: y has %d rows, class epilogue needs %d", a.nrows, 4 + a.Cout);
+        if (a.raw && a.rawC < (a.epi == 3 ? 64 : 64 + a.Cout)) BSY_FAIL(BSY_ERR_ARG, "conv: raw map has too few channels");
+    }
     ConvK k;
     k.src0 = a.src0; k.src1 = a.src1; k.ld0 = a.ld0; k.ld1 = a.ld1; k.C0 = a.C0; k.C1 = a.C1;
     k.up0 = a.up0; k.up1 = a.up1; k.H = a.H; k.W = a.W; k.OH = a.OH; k.OW = a.OW; k.stride = a.stride; k.pad = a.pad;
@@ -1037,6 +1153,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     k.Kpad = round_up(a.ksize * a.ksize * Cin, 32); k.nk = k.Kpad / 32;
     k.wgt = a.wgt; k.bias = a.bias; k.dst = a.dst; k.ldd = a.ldd; k.Cout = a.Cout; k.out_f32 = a.out_f32;
     k.res = a.res; k.ldr = a.ldr; k.act = a.act; k.B = a.B; k.tiles_x = k.tiles_y = 0;
+    k.epi = a.epi; k.y = a.y; k.y_f32 = a.y_f32; k.A = a.A; k.a0 = a.a0; k.nrows = a.nrows; k.lvl_stride = a.lvl_stride;
+    k.raw = a.raw; k.raw_f32 = a.raw_f32; k.rawC = a.rawC;
     k.dst_scale = a.dst_scale > 0 ? a.dst_scale : 1; k.dst_dy = a.dst_dy; k.dst_dx = a.dst_dx; k.ntn = 1;
     // ---- configuration: explicit (autotuned, ConvArgs::cfg) or heuristic -----------------------------------------
     if (a.ksize == 3 && (a.up0 || a.up1)) BSY_FAIL(BSY_ERR_ARG, "conv: upsampled source only with ksize 1");

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -28,6 +29,7 @@ struct bsy_plan {
     // side streams ("lanes") for independent op chains + the events that fork / join them
     std::vector<hipStream_t> lanes;      // index 0 unused (lane 0 = caller's stream)
     std::vector<hipEvent_t> lane_done;   // per lane: recorded at its tail before a join
+    float last_event_overhead_ms = 0.f;  // bsy_plan_profile: median empty event interval of the last call
     hipEvent_t fork_ev = nullptr;
 };
 
@@ -184,6 +186,15 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             a.ldd = op.dst.ld; a.Cout = op.dst.C; a.out_f32 = op.out_f32;
             a.res = R.h(op.res); a.ldr = op.res.buf >= 0 ? op.res.ld : 0;
             a.act = op.act; a.dst_scale = op.dst_scale; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
+            a.epi = 0; a.y = nullptr; a.raw = nullptr; a.y_f32 = a.raw_f32 = a.A = a.a0 = a.nrows = a.rawC = 0; a.lvl_stride = 0.f;
+            if (op.out_f32 >= 2) {  // fused Detect decoder: dst = the prediction tensor y, box[0] = the level's raw map (optional)
+                a.epi = op.out_f32; a.out_f32 = 0; a.dst = nullptr; a.ldd = 8; a.Cout = op.nl;
+                a.y = R.base(op.dst); a.y_f32 = op.out_dtype == BSY_F32; a.A = op.A; a.a0 = op.lvl_h[1]; a.nrows = op.dst.C;
+                a.lvl_stride = op.lvl_stride[0];
+                const bsy_view& rv = op.box[0];
+                const bool bound = rv.buf >= BSY_EXT_BASE && rv.buf - BSY_EXT_BASE < R.n_ext && R.ext[rv.buf - BSY_EXT_BASE];
+                a.raw = bound ? R.base(rv) : nullptr; a.raw_f32 = a.y_f32; a.rawC = rv.C;
+            }
             a.cfg = op.tuned_cfg - 1;  // 0 = not tuned -> heuristic
             if (!R.ok) return BSY_ERR_ARG;
             if (cargs) { *cargs = a; return BSY_OK; }
@@ -358,7 +369,8 @@ extern "C" int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_st
     if (!p || !ms_per_op || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_profile: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = p->ops.size();
-    while (p->events.size() < n + 1) {
+    constexpr size_t NCAL = 16;  // empty event intervals recorded after the ops: the cost of the event pair itself
+    while (p->events.size() < n + 1 + NCAL) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev));
         p->events.push_back(ev);
@@ -370,8 +382,20 @@ extern "C" int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_st
         if (rc != BSY_OK) return rc;
         HIP_TRY(hipEventRecord(p->events[i + 1], s));
     }
-    HIP_TRY(hipEventSynchronize(p->events[n]));
-    for (size_t i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms_per_op[i], p->events[i], p->events[i + 1]));
+    for (size_t i = 0; i < NCAL; ++i) HIP_TRY(hipEventRecord(p->events[n + 1 + i], s));
+    HIP_TRY(hipEventSynchronize(p->events[n + NCAL]));
+    // An interval between two recorded events holds the kernel AND the event packet between it and its neighbour (a few
+    // microseconds that a normal run, which records no events between kernels, does not pay: rocprofv3's kernel
+    // durations are that much shorter).  The median empty interval measures it; it is subtracted from every op.
+    float cal[NCAL];
+    for (size_t i = 0; i < NCAL; ++i) HIP_TRY(hipEventElapsedTime(&cal[i], p->events[n + i], p->events[n + 1 + i]));
+    std::sort(cal, cal + NCAL);
+    const float ev_ms = cal[NCAL / 2];
+    for (size_t i = 0; i < n; ++i) {
+        HIP_TRY(hipEventElapsedTime(&ms_per_op[i], p->events[i], p->events[i + 1]));
+        ms_per_op[i] = ms_per_op[i] > ev_ms ? ms_per_op[i] - ev_ms : 0.f;
+    }
+    p->last_event_overhead_ms = ev_ms;
     return BSY_OK;
 }
 

@@ -81,11 +81,12 @@ class Plan:
     EXT_PROTO = 5
 
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
-                 fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None):
+                 fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
+        self.fuse_head = (os.environ.get("BSY_FUSE_HEAD", "1") != "0") if fuse_head is None else bool(fuse_head)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -125,7 +126,7 @@ class Plan:
         key = self._wrec(name, name=name, kind="plain" if plain else "conv", cout=cout, cin=cin, k=k, perm=perm)
         self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
                              src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
-                             act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane))
+                             act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane, cout=cout))
         self.flops += 2 * self.B * OH * OW * cout * cin * k * k
         return dst
 
@@ -253,11 +254,28 @@ class Plan:
         self.meta.update(proto_hw=(p.H, p.W))
         return p
 
+    def _head_conv(self, name: str, src: T, cout: int, mode: int, level: int, a0: int, A: int, nc: int, stride: float):
+        """Last 1x1 conv of a Detect branch with the decoder fused into its epilogue (out_f32 = mode 2 / 3)."""
+        key = self._wrec(name, name=name, kind="plain", cout=cout, cin=src.C, k=1, perm=None)
+        y = T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc, 0, 0)
+        raw = T(L.BSY_EXT_BASE + self.EXT_RAW0 + level, 0, 0, 64 + nc, 0, 0)
+        self.ops.append(dict(kind=L.OP_CONV, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, src1=None, dst=y, res=None,
+                             ksize=1, stride=1, pad=0, act=0, out_f32=mode, wkey=key, dst_scale=1, name=name, cout=cout,
+                             lane=self._lane, nl=cout, nc=nc, nm=0, A=A, box=[raw], cls=[], msk=[], level=level,
+                             lvl_h=[src.H, a0], lvl_w=[src.W], lvl_stride=[stride], out_dtype=self.out_dtype))
+        self.flops += 2 * self.B * src.H * src.W * cout * src.C
+
     def detect(self, name: str, xs: List[T], nc: int, legacy: bool, nm: int = 0, npr: int = 0):
         """head.py:21-148 (+ Segment :175-197)."""
         ch = [t.C for t in xs]
         c2, c3 = max(16, ch[0] // 4, 64), max(ch[0], min(nc, 100))
         boxes, clss, msks = [], [], []
+        A = sum(t.H * t.W for t in xs)
+        a0 = [sum(t.H * t.W for t in xs[:i]) for i in range(len(xs))]
+        strides = [float(self.H // t.H) for t in xs]
+        # Detect without mask coefficients: the last conv of every branch decodes in its epilogue (conv_mfma.hip
+        # conv_epilogue_head) -- no f32 logit maps, no decode launch, no raw-map transposes
+        fused = self.fuse_head and nm == 0 and len(xs) <= 3
         # every (level, branch) chain is independent until the decoder: give each its own lane so the engine runs them
         # concurrently (the 40x40 / 20x20 chains are far too small to fill 256 CUs on their own)
         for i, x in enumerate(xs):
@@ -265,7 +283,10 @@ class Plan:
             self._lane = 2 * i
             t = self.conv(f"{name}.cv2.{i}.0", x, c2, 3, 1)
             t = self.conv(f"{name}.cv2.{i}.1", t, c2, 3, 1)
-            boxes.append(self.conv(f"{name}.cv2.{i}.2", t, 64, 1, 1, act=False, plain=True, out_f32=True))
+            if fused:
+                self._head_conv(f"{name}.cv2.{i}.2", t, 64, 3, i, a0[i], A, nc, strides[i])
+            else:
+                boxes.append(self.conv(f"{name}.cv2.{i}.2", t, 64, 1, 1, act=False, plain=True, out_f32=True))
             self._lane = 2 * i + 1
             if legacy:
                 t = self.conv(f"{name}.cv3.{i}.0", x, c3, 3, 1)
@@ -275,7 +296,10 @@ class Plan:
                 t = self.conv(f"{name}.cv3.{i}.0.1", t, c3, 1, 1)
                 t = self.dwconv(f"{name}.cv3.{i}.1.0", t, act=True)
                 t = self.conv(f"{name}.cv3.{i}.1.1", t, c3, 1, 1)
-            clss.append(self.conv(f"{name}.cv3.{i}.2", t, nc, 1, 1, act=False, plain=True, out_f32=True))
+            if fused:
+                self._head_conv(f"{name}.cv3.{i}.2", t, nc, 2, i, a0[i], A, nc, strides[i])
+            else:
+                clss.append(self.conv(f"{name}.cv3.{i}.2", t, nc, 1, 1, act=False, plain=True, out_f32=True))
             if nm:
                 self._lane = 2 * len(xs) + i
                 c4 = max(ch[0] // 4, nm)
@@ -283,8 +307,9 @@ class Plan:
                 t = self.conv(f"{name}.cv4.{i}.1", t, c4, 3, 1)
                 msks.append(self.conv(f"{name}.cv4.{i}.2", t, nm, 1, 1, act=False, plain=True, out_f32=True))
         self._lane = 0
-        A = sum(t.H * t.W for t in xs)
-        strides = [float(self.H // t.H) for t in xs]
+        self.meta.update(A=A, nc=nc, nm=nm, no=64 + nc, strides=strides, levels=[(t.H, t.W) for t in xs])
+        if fused:
+            return
         self.ops.append(dict(kind=L.OP_DECODE, join=1, H=self.H, W=self.W, OH=0, OW=0, nl=len(xs), nc=nc, nm=nm, A=A, box=boxes,
                              cls=clss, msk=msks, lvl_h=[t.H for t in xs], lvl_w=[t.W for t in xs], lvl_stride=strides,
                              dst=T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc + nm, 0, 0), out_dtype=self.out_dtype,

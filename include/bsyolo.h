@@ -78,7 +78,13 @@ typedef struct bsy_op {
     bsy_view res;           /* residual added AFTER the activation (Bottleneck / PSABlock shortcut); buf<0 if none */
     int32_t ksize, stride, pad;
     int32_t act;            /* 0 identity, 1 SiLU */
-    int32_t out_f32;        /* dst holds f32 instead of f16 (final head convs) */
+    int32_t out_f32;        /* output mode.  0: dst f16.  1: dst f32 (final head convs feeding BSY_OP_DECODE).
+                             * 2 / 3: fused Detect decoder -- the conv is the last layer of a class (2) / box (3) branch
+                             * of level `level` and writes rows of the prediction tensor directly: dst = y view
+                             * (external slot, C = 4 + nc), nl = the conv's output channels (64 / nc), box[0] = that
+                             * level's raw map (external slot, optional),
+                             * A = anchors of all levels, lvl_h[1] = first anchor of this level, lvl_stride[0] = stride,
+                             * out_dtype = dtype of y and of the raw map */
     int32_t dst_scale, dst_dy, dst_dx; /* ConvTranspose2d(2,2,s2) as 4 scattered 1x1 convs: out pixel (s*oh+dy, s*ow+dx); scale 1 = plain */
     int64_t w_off, b_off;   /* byte offsets into the engine's weight blob (packed f16 weights / f32 bias) */
     int32_t heads, key_dim, head_dim; /* ATTN */
@@ -116,7 +122,9 @@ int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream strea
 int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n_ops);
 /* Debug/test aid: synchronous copy of one workspace buffer to HOST memory (bytes <= the buffer's size). */
 int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes);
-/* Per-op device time of the last bsy_plan_profile call (ms, HIP events on `stream`); runs the plan once, syncs. */
+/* Per-op device time (ms): runs the plan once with a HIP event recorded after every op on `stream`, syncs.  The cost of
+ * the event packet itself (median of 16 empty intervals recorded in the same call, a few microseconds) is subtracted
+ * from every op, so that the figures agree with rocprofv3's kernel durations. */
 int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, float* ms_per_op /* n_ops */);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -436,6 +436,36 @@ def test_engine_stem_fusion_is_bit_identical(scale):
     plain.close()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_engine_fused_decoder_matches_decode_kernel(dtype):
+    """Detect._inference (head.py:113-148) fused into the last conv of every head branch (conv_epilogue_head) against the
+    separate decode kernel on f32 logit maps: same y and same raw maps, with and without the raw maps requested."""
+    m = R.Model("yolo11", "s", 80, "detect")
+    P = R.synth_params(m, 0)
+    cfg = stock_cfg("yolo11", "s")
+    fused = YoloEngine(cfg, P, fuse_head=True, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_head=False, autotune=False)
+    x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(5)).to(dtype).to(DEV)
+    pf, _ = fused.plan_for(2, 96, 160, dtype, dtype)
+    pp, _ = plain.plan_for(2, 96, 160, dtype, dtype)
+    assert not any(o["kind"] in (L.OP_DECODE, L.OP_RAW_NCHW) for o in pf.ops)
+    assert sum(1 for o in pf.ops if o["kind"] == L.OP_CONV and o.get("out_f32", 0) >= 2) == 6
+    assert any(o["kind"] == L.OP_DECODE for o in pp.ops)
+    yf, rf = fused(x)
+    yp, rp = plain(x)
+    yn, rn = fused(x, want_raw=False)
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-3, atol=1e-3)
+    # boxes: fp32 DFL with a different summation order; scores: identical formula on identical logits
+    np.testing.assert_allclose(yf.float().cpu().numpy(), yp.float().cpu().numpy(), **tol)
+    assert torch.equal(yn, yf) and all(r is None for r in rn)
+    for a, b in zip(rf, rp):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a.float().cpu().numpy(), b.float().cpu().numpy(), rtol=1e-3, atol=1e-3)
+    fused.close()
+    plain.close()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # NMS: bit-exact against the oracle (and the reference's golden outputs)
 # ------------------------------------------------------------------------------------------------------------

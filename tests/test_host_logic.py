@@ -65,7 +65,7 @@ def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     for o in p.ops:
         if o["kind"] in (L.OP_CONV, L.OP_CONV_FIRST):
             cin = 3 if o["kind"] == L.OP_CONV_FIRST else o["src0"].C + (o["src1"].C if o.get("src1") else 0)
-            dense += 2 * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2
+            dense += 2 * o["OH"] * o["OW"] * o.get("cout", o["dst"].C) * cin * o["ksize"] ** 2
             n += 1
     assert n == nconv
     assert abs(dense / 1e9 - gflops) < 0.01 * gflops

@@ -99,11 +99,12 @@ def timing(scale="s", B=64, S=640, dt=torch.float16):
         fl = by = 0
         if kind in (L.OP_CONV, L.OP_DWCONV):
             cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
-            fl = 2 * B * o["OH"] * o["OW"] * o["dst"].C * cin * o["ksize"] ** 2 if kind == L.OP_CONV else 0
+            fl = 2 * B * o["OH"] * o["OW"] * o.get("cout", o["dst"].C) * cin * o["ksize"] ** 2 if kind == L.OP_CONV else 0
             ins = B * o["H"] * o["W"] * o["src0"].C * 2 // (4 if o["src0"].up else 1)
             if o.get("src1"):
                 ins += B * o["H"] * o["W"] * o["src1"].C * 2 // (4 if o["src1"].up else 1)
-            outs = B * o["OH"] * o["OW"] * o["dst"].C * (4 if o.get("out_f32") else 2)
+            mode = o.get("out_f32", 0)
+            outs = B * o["OH"] * o["OW"] * ({2: o.get("cout", 0), 3: 4}.get(mode, o["dst"].C)) * (4 if mode == 1 else 2)
             if o.get("res"):
                 ins += outs
             by = ins + outs
@@ -117,7 +118,7 @@ def timing(scale="s", B=64, S=640, dt=torch.float16):
         shape = ""
         if kind == L.OP_CONV:
             cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
-            shape = f"{o['ksize']}x{o['ksize']}s{o['stride']} {cin:4d}->{o['dst'].C:4d} @{o['OH']}x{o['OW']}"
+            shape = f"{o['ksize']}x{o['ksize']}s{o['stride']} {cin:4d}->{o.get('cout', o['dst'].C):4d} @{o['OH']}x{o['OW']}"
         print(f"  {t:8.4f} ms kind {kind} {name:26s} {shape:30s} {fl / t / 1e9 if t > 0 else 0:7.1f} TF/s {by / t / 1e6 if t > 0 else 0:8.1f} GB/s cfg {hex(tun.get(name, -1)) if name in tun else ''}")
     eng.close()
 

@@ -2,32 +2,35 @@
 # HBM traffic of one bench step per kernel family: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes
 # (MI355X_MICROARCH.md "HBM": FETCH_SIZE reports exactly half of a wide coalesced read stream on gfx950 -> doubled;
 # WRITE_SIZE is exact; both in KiB).  Writes gpurun_out/traffic.json; copy it to profiles/ to have bench.py report it.
+# usage: tools/pmc_bench_traffic.sh <conv launches per forward>   ("conv_mfma_kernel" below = the whole conv family)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench_$c -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "$c rc=$?"
 done
-python3 - $R <<'PY'
+python3 - $R ${1:-76} <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]
+NCONV = int(sys.argv[2])  # conv launches per forward = roofline.launches_per_step of bench.py
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{R}/gpurun_out/pmc_bench_{c}/*/*counter_collection.csv")[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    conv = [r for r in rows if "conv_mfma_kernel" in r["Kernel_Name"]]
-    last = conv[-79:]  # the last forward (bench's final profile pass): 79 conv launches
+    CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel")  # kernels behind the plan's OP_CONV ops
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in CONV)]
+    last = conv[-NCONV:]  # the last forward (bench's final profile pass)
     t0 = int(last[0]["Start_Timestamp"])
     fam = {}
     for r in rows:
         if int(r["Start_Timestamp"]) < t0: continue
         n = r["Kernel_Name"]
-        key = "conv_mfma_kernel" if "conv_mfma_kernel" in n else n.split("(")[0].split("<")[0][-40:]
+        key = "conv_mfma_kernel" if any(k in n for k in CONV) else n.split("(")[0].split("<")[0][-40:]
         fam[key] = fam.get(key, 0.0) + float(r["Counter_Value"]) * 1024.0
     out[c] = fam
 conv_bytes = 2.0 * out["FETCH_SIZE"]["conv_mfma_kernel"] + out["WRITE_SIZE"]["conv_mfma_kernel"]
-res = {"conv_mfma_hbm_bytes_per_step": conv_bytes, "conv_launches_per_step": 79,
-       "conv_mfma_hbm_bytes_per_launch_avg": conv_bytes / 79,
+res = {"conv_mfma_hbm_bytes_per_step": conv_bytes, "conv_launches_per_step": NCONV,
+       "conv_mfma_hbm_bytes_per_launch_avg": conv_bytes / NCONV,
        "fetch_bytes_raw": out["FETCH_SIZE"]["conv_mfma_kernel"], "write_bytes": out["WRITE_SIZE"]["conv_mfma_kernel"],
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py, last forward; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction)",
        "all_families_fetch_x2_plus_write": {k: 2 * out["FETCH_SIZE"].get(k, 0) + out["WRITE_SIZE"].get(k, 0) for k in set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"])}}

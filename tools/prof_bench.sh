@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 --kernel-trace --stats of bench.py + per-family summary (tools/prof_summary.py); outputs under gpurun_out/prof_<tag>/.
+# usage: tools/prof_bench.sh <tag> [steps=20]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-x}; STEPS=${2:-20}
+cd /tmp && export TMPDIR=/tmp
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_$TAG/bench_under_rocprof.json 2> $R/gpurun_out/prof_$TAG/bench.err
+echo "rocprof rc=$?"
+NCONV=$(python3 -c "import json,sys; print(json.loads(open('$R/gpurun_out/prof_$TAG/bench_under_rocprof.json').read().strip().splitlines()[-1])['roofline']['launches_per_step'])")
+CSV=$(ls $R/gpurun_out/prof_$TAG/*/*kernel_trace.csv | head -1)
+python3 $R/tools/prof_summary.py $CSV $STEPS $NCONV > $R/gpurun_out/prof_$TAG/kernel_summary.txt
+cp $(ls $R/gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -1) $R/gpurun_out/prof_$TAG/kernel_stats.csv
+cat $R/gpurun_out/prof_$TAG/kernel_summary.txt
+python3 -c "
+import json
+d=json.loads(open('$R/gpurun_out/prof_$TAG/bench_under_rocprof.json').read().strip().splitlines()[-1])
+r=d['roofline']; print('bench (under rocprof): ms/step', d['ms_per_step'], 'conv avg launch us', r['avg_launch_ms']*1e3, 'conv ms/step', r['conv_ms_per_step'], 'achieved', r['achieved'], 'frac', r['frac'])"

@@ -2,17 +2,21 @@
 """Summarise a rocprofv3 --kernel-trace CSV of bench.py: per-step time of every kernel family over the LAST `steps`
 steps (the timed region; earlier dispatches include warm-up and the autotuner's trial launches).
 
-    python tools/prof_summary.py <kernel_trace.csv> <steps> [launches_of_conv_per_step=79]
+    python tools/prof_summary.py <kernel_trace.csv> <steps> <conv launches per step: roofline.launches_per_step of bench.py>
+
+"conv family" = the kernels behind the plan's OP_CONV ops: conv_mfma_kernel (implicit GEMM), conv1x1_persist_kernel and
+conv3x3_patch_kernel (bs_yolo_amd/csrc/conv_mfma.hip) -- the set bench.py's `roofline` object prices.
 """
 import csv
 import sys
 from collections import defaultdict
 
 path, steps = sys.argv[1], int(sys.argv[2])
-per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 79
+per_step = int(sys.argv[3])
+CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel")
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-conv = [r for r in rows if "conv_mfma_kernel" in r["Kernel_Name"]]
+conv = [r for r in rows if any(k in r["Kernel_Name"] for k in CONV)]
 tail = conv[-steps * per_step:]
 t0 = int(tail[0]["Start_Timestamp"])
 fam = defaultdict(lambda: [0, 0])
@@ -22,9 +26,10 @@ for r in rows:
     n = r["Kernel_Name"]
     key = n.split("<")[0].split("(")[0].replace("void ", "")
     if key.startswith("_Z"):
-        for k in ("conv_first", "dwconv3x3", "sppf_pool", "attention", "decode", "nms_filter", "nms_sort", "nms_greedy", "raw_nchw"):
+        for k in CONV + ("stem_fused", "bneck_fused", "conv_first", "dwconv3x3", "sppf_pool", "attention", "decode", "nms_filter",
+                  "nms_sort", "nms_greedy", "raw_nchw"):
             if k in key:
-                key = k + "_kernel"
+                key = k if k.endswith("_kernel") else k + "_kernel"
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     fam[key][0] += 1
     fam[key][1] += d
@@ -35,5 +40,6 @@ for k, (c, d) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print(f"{k:40s} {c / steps:14.1f} {d / c / 1e3:10.2f} {d / steps / 1e6:10.4f}")
     tot += d
 print(f"{'TOTAL device time':40s} {'':14s} {'':10s} {tot / steps / 1e6:10.4f}")
-c, d = fam["conv_mfma_kernel"]
-print(f"conv_mfma_kernel: {c / steps:.0f} launches/step, average launch {d / c / 1e3:.2f} us, {d / steps / 1e6:.4f} ms/step")
+c = sum(fam[k][0] for k in CONV if k in fam)
+d = sum(fam[k][1] for k in CONV if k in fam)
+print(f"conv family ({' + '.join(k for k in CONV if k in fam)}): {c / steps:.0f} launches/step, average launch {d / c / 1e3:.2f} us, {d / steps / 1e6:.4f} ms/step")
