@@ -16,10 +16,32 @@ __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
 #define DW_PX 2   // output pixels per thread along x
 #define DW_RY 8   // output rows per thread: a rolling 3-row register window -> 2 vector loads per output instead of 9,
                   // and the 9 x 8 weights are fetched once per 16 outputs
+// Loads go through a buffer descriptor: a lane whose pixel lies outside the image gets voffset = out-of-range and
+// receives zeros -- the conv's zero padding without a branch per load (the flat-load version spent more instructions
+// on exec-mask juggling and 64-bit addresses than on the 9 FMAs per output).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t dw_rsrc_t;
+__device__ __forceinline__ dw_rsrc_t dw_make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ half8 dw_load16(dw_rsrc_t r, unsigned voff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    union { u32x4 u; half8 h; } v;
+    v.u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return v.h;
+}
+#else
+typedef int dw_rsrc_t;
+__device__ __forceinline__ dw_rsrc_t dw_make_rsrc(const void*, unsigned) { return 0; }
+__device__ __forceinline__ half8 dw_load16(dw_rsrc_t, unsigned) { return half8{0, 0, 0, 0, 0, 0, 0, 0}; }
+#endif
+#define DW_OOB 0xFFFFFFF0u
+
+template <bool ACT, bool RES>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W,
                                                         int C, const float* __restrict__ w,
                                                         const float* __restrict__ bias, half_t* __restrict__ dst,
-                                                        int ldd, int act, const half_t* __restrict__ res, int ldr) {
+                                                        int ldd, const half_t* __restrict__ res, int ldr, unsigned span) {
     const int C8 = C >> 3;
     const int WG = (W + DW_PX - 1) / DW_PX, HG = (H + DW_RY - 1) / DW_RY;
     const long long total = (long long)B * HG * WG * C8;
@@ -43,16 +65,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
     }
-    const half_t* ip = src + (size_t)n * H * W * lds_ + c;
+    const dw_rsrc_t rs = dw_make_rsrc(src, span);
+    // byte offsets of the 4 window columns inside a row (or out-of-range), row part added per row
+    unsigned coloff[DW_PX + 2];
+#pragma unroll
+    for (int q = 0; q < DW_PX + 2; ++q) {
+        const int ix = x0 + q - 1;
+        coloff[q] = (unsigned)ix < (unsigned)W ? 2u * ((unsigned)ix * (unsigned)lds_ + (unsigned)c) : DW_OOB;
+    }
+    const unsigned rowbytes = 2u * (unsigned)W * (unsigned)lds_;
     auto load_row = [&](int iy, half8 (&r)[DW_PX + 2]) {
         const bool rowok = (unsigned)iy < (unsigned)H;
+        const unsigned rb = (unsigned)(n * H + iy) * rowbytes;
 #pragma unroll
-        for (int q = 0; q < DW_PX + 2; ++q) {
-            const int ix = x0 + q - 1;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (rowok && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const half8*>(ip + ((size_t)iy * W + ix) * lds_);
-            r[q] = v;
-        }
+        for (int q = 0; q < DW_PX + 2; ++q)
+            r[q] = dw_load16(rs, (rowok && coloff[q] != DW_OOB) ? rb + coloff[q] : DW_OOB);
     };
     half8 top[DW_PX + 2], mid[DW_PX + 2], bot[DW_PX + 2];
     load_row(y0 - 1, top);
@@ -79,18 +106,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict
 #pragma unroll
         for (int p = 0; p < DW_PX; ++p) {
             const int x = x0 + p;
-            if (x >= W) continue;
-            const size_t pix = (size_t)(n * H + y) * W + x;
+            const size_t pix = (size_t)(n * H + y) * W + (x < W ? x : W - 1);
             half8 o;
-            if (res) {
+            if (RES) {
                 const half8 r = *reinterpret_cast<const half8*>(res + pix * ldr + c);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)((act ? silu_f(acc[p][j]) : acc[p][j]) + (float)r[j]);
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)((ACT ? silu_f(acc[p][j]) : acc[p][j]) + (float)r[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)(act ? silu_f(acc[p][j]) : acc[p][j]);
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)(ACT ? silu_f(acc[p][j]) : acc[p][j]);
             }
-            *reinterpret_cast<half8*>(dst + pix * ldd + c) = o;
+            if (x < W) *reinterpret_cast<half8*>(dst + pix * ldd + c) = o;
         }
 #pragma unroll
         for (int q = 0; q < DW_PX + 2; ++q) { top[q] = mid[q]; mid[q] = bot[q]; }
@@ -103,8 +129,18 @@ int launch_dwconv(const DwArgs& a, hipStream_t s) {
         BSY_FAIL(BSY_ERR_ARG, "dwconv: channels/strides must be multiples of 8 and pointers 16-byte aligned");
     const long long total = (long long)a.B * ((a.H + DW_RY - 1) / DW_RY) * ((a.W + DW_PX - 1) / DW_PX) * (a.C / 8);
     if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "dwconv: empty");
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H,
-                       a.W, a.C, a.w, a.b, a.dst, a.ldd, a.act, a.res, a.ldr);
+    const long long elems = (long long)a.B * a.H * a.W * a.lds;
+    if (elems >= (1LL << 31)) BSY_FAIL(BSY_ERR_ARG, "dwconv: source view exceeds 2^31 elements (split the batch)");
+    const unsigned span = (unsigned)((((long long)a.B * a.H * a.W - 1) * a.lds + a.C) * 2);  // bytes from the view's first element
+    const dim3 grid((unsigned)((total + 255) / 256));
+#define DW_LAUNCH(ACT_, RES_)                                                                                              \
+    hipLaunchKernelGGL((dwconv3x3_kernel<ACT_, RES_>), grid, dim3(256), 0, s, a.src, a.lds, a.B, a.H, a.W, a.C, a.w, a.b, \
+                       a.dst, a.ldd, a.res, a.ldr, span)
+    if (a.act && a.res) DW_LAUNCH(true, true);
+    else if (a.act) DW_LAUNCH(true, false);
+    else if (a.res) DW_LAUNCH(false, true);
+    else DW_LAUNCH(false, false);
+#undef DW_LAUNCH
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
