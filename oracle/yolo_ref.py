@@ -62,7 +62,21 @@ GRAPHS = {
         (-1, 1, "Conv", (512, 3, 2)), ((-1, 9), 1, "Concat", ()), (-1, 3, "C2f", (1024,)),
     ],
 }
-HEAD_FROM = {"yolo11": (16, 19, 22), "yolov8": (15, 18, 21)}
+# BS-YOLO: cfg/models/11/yolo11.yaml:15-52 of the fork (the repo's namesake graph): C3k2_gai / SCDown / MSCAAttention in the
+# backbone, an ELA gate after every neck C3k2; Detect reads the ELA outputs.  Layer 21 concatenates layer 13 -- itself a
+# Concat (the yaml kept the stock index after inserting layers) -- so that Concat has three tensors behind it.
+GRAPHS["bsyolo11"] = [
+    (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "Conv", (128, 3, 2)), (-1, 2, "C3k2_gai", (256, False, 0.25)),
+    (-1, 1, "Conv", (256, 3, 2)), (-1, 2, "C3k2_gai", (512, False, 0.25)), (-1, 1, "SCDown", (512, 3, 2)),
+    (-1, 2, "C3k2_gai", (512, True)), (-1, 1, "SCDown", (1024, 3, 2)), (-1, 2, "C3k2_gai", (1024, True)),
+    (-1, 1, "SPPF", (1024, 5)), (-1, 2, "C2PSA", (1024,)), (-1, 1, "MSCAAttention", ()),
+    (-1, 1, "Upsample", ()), ((-1, 6), 1, "Concat", ()), (-1, 2, "C3k2", (512, False)), (-1, 1, "ELA", (512,)),
+    (-1, 1, "Upsample", ()), ((-1, 4), 1, "Concat", ()), (-1, 2, "C3k2", (256, False)), (-1, 1, "ELA", (256,)),
+    (-1, 1, "Conv", (256, 3, 2)), ((-1, 13), 1, "Concat", ()), (-1, 2, "C3k2", (512, False)), (-1, 1, "ELA", (512,)),
+    (-1, 1, "SCDown", (512, 3, 2)), ((-1, 10), 1, "Concat", ()), (-1, 2, "C3k2", (1024, True)), (-1, 1, "ELA", (1024,)),
+]
+SCALES["bsyolo11"] = SCALES["yolo11"]
+HEAD_FROM = {"yolo11": (16, 19, 22), "yolov8": (15, 18, 21), "bsyolo11": (19, 23, 27)}
 
 
 def make_divisible(x, d):  # utils/ops.py:130-143
@@ -306,6 +320,178 @@ class C2PSA:
         return self.cv2(P, torch.cat((a, b), 1))
 
 
+class PMSFA:
+    """block.py:3035-3054: 3x3 conv -> half of it through a depthwise 5x5 -> half of that through a depthwise 7x7 ->
+    cat([7x7 out, other 5x5 half, other 3x3 half]) -> 1x1 conv, + x."""
+
+    def __init__(self, name, inc):
+        self.inc = inc
+        self.conv1 = Conv(name + ".conv1", inc, inc, 3)
+        self.conv2 = Conv(name + ".conv2", inc // 2, inc // 2, 5, g=inc // 2)
+        self.conv3 = Conv(name + ".conv3", inc // 4, inc // 4, 7, g=inc // 4)
+        self.conv4 = Conv(name + ".conv4", inc, inc, 1)
+
+    def specs(self):
+        for m in (self.conv1, self.conv2, self.conv3, self.conv4):
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        a1, a2 = self.conv1(P, x).chunk(2, 1)
+        b1, b2 = self.conv2(P, a1).chunk(2, 1)
+        c = self.conv3(P, b1)
+        cat = torch.cat([c, b2, a2], 1)
+        if FP16_EMULATION:
+            return self.conv4(P, cat, res=x)
+        return self.conv4(P, cat) + x
+
+
+class C3k_gai:
+    """block.py:3079-3086: C3 (block.py:3320-3334) whose inner chain is n x PMSFA(c_)."""
+
+    def __init__(self, name, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        c_ = int(c2 * e)
+        self.cv1 = Conv(name + ".cv1", c1, c_, 1, 1)
+        self.cv2 = Conv(name + ".cv2", c1, c_, 1, 1)
+        self.cv3 = Conv(name + ".cv3", 2 * c_, c2, 1)
+        self.m = Seq(PMSFA(f"{name}.m.{i}", c_) for i in range(n))
+
+    def specs(self):
+        for m in (self.cv1, self.cv2, self.cv3, self.m):
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        return self.cv3(P, torch.cat((self.m(P, self.cv1(P, x)), self.cv2(P, x)), 1))
+
+
+class C3k2_gai:
+    """block.py:3087-3095: C2f whose inner modules are PMSFA(c) (c3k False) or C3k_gai(c, c, 2) (c3k True)."""
+
+    def __init__(self, name, c1, c2, n=1, c3k=False, e=0.5, g=1, shortcut=True):
+        self.c = int(c2 * e)
+        self.cv1 = Conv(name + ".cv1", c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv(name + ".cv2", (2 + n) * self.c, c2, 1)
+        self.m = [C3k_gai(f"{name}.m.{i}", self.c, self.c, 2, shortcut, g) if c3k else PMSFA(f"{name}.m.{i}", self.c)
+                  for i in range(n)]
+
+    def specs(self):
+        yield from self.cv1.specs()
+        yield from self.cv2.specs()
+        for m in self.m:
+            yield from m.specs()
+
+    def __call__(self, P, x):
+        y = list(self.cv1(P, x).chunk(2, 1))
+        y.extend(m(P, y[-1]) for m in self.m)
+        return self.cv2(P, torch.cat(y, 1))
+
+
+class SCDown:
+    """block.py:4503-4535: pointwise Conv (BN + SiLU) then depthwise k x k stride-s Conv (BN, no activation)."""
+
+    def __init__(self, name, c1, c2, k, s):
+        self.cv1 = Conv(name + ".cv1", c1, c2, 1, 1)
+        self.cv2 = Conv(name + ".cv2", c2, c2, k, s, g=c2, act=False)
+
+    def specs(self):
+        yield from self.cv1.specs()
+        yield from self.cv2.specs()
+
+    def __call__(self, P, x):
+        return self.cv2(P, self.cv1(P, x))
+
+
+class MSCAAttention:
+    """nn/Addmodules/MSCA.py:19-88 (SegNeXt MSCA with learned branch weights): depthwise 5x5, four strip-conv branches
+    (1x5/5x1, 1x7/7x1, 1x11/11x1, 1x21/21x1; the first three followed by the SAME depthwise 1x1 `dilconv`), branch weights
+    = softmax over the 4 branches of sigmoid(SE_i(GAP(branch_i))), 1x1 conv of the weighted sum, times the input.
+    All convs are bare nn.Conv2d with bias (no BN, no activation)."""
+
+    STRIPS = ((5, "conv0"), (7, "conv1"), (11, "conv2"), (21, "conv3"))
+
+    def __init__(self, name, dim):
+        self.name, self.dim = name, dim
+
+    def specs(self):
+        n, d = self.name, self.dim
+        yield (n + ".conv0.weight", (d, 1, 5, 5))
+        yield (n + ".conv0.bias", (d,))
+        for k, base in self.STRIPS:
+            yield (f"{n}.{base}_1.weight", (d, 1, 1, k))
+            yield (f"{n}.{base}_1.bias", (d,))
+            yield (f"{n}.{base}_2.weight", (d, 1, k, 1))
+            yield (f"{n}.{base}_2.bias", (d,))
+            if base == "conv0":  # registration order of MSCA.py:26-39
+                yield (n + ".dilconv.weight", (d, 1, 1, 1))
+                yield (n + ".dilconv.bias", (d,))
+        yield (n + ".conv4.weight", (d, d, 1, 1))
+        yield (n + ".conv4.bias", (d,))
+        for i in range(1, 5):
+            yield (f"{n}.SE{i}.conv.0.weight", (d, d, 1, 1))
+            yield (f"{n}.SE{i}.conv.0.bias", (d,))
+
+    def __call__(self, P, x):
+        n, d = self.name, self.dim
+        x = _q(x)
+        attn = _q(F.conv2d(x, P[n + ".conv0.weight"], P[n + ".conv0.bias"], 1, 2, 1, d))
+        branches = []
+        for i, (k, base) in enumerate(self.STRIPS):
+            a = _q(F.conv2d(attn, P[f"{n}.{base}_1.weight"], P[f"{n}.{base}_1.bias"], 1, (0, k // 2), 1, d))
+            w2, b2 = P[f"{n}.{base}_2.weight"], P[f"{n}.{base}_2.bias"]
+            if i < 3 and FP16_EMULATION:  # the engine folds the depthwise 1x1 into the column conv (one rounding)
+                dw, db = P[n + ".dilconv.weight"].view(d), P[n + ".dilconv.bias"]
+                a = F.conv2d(a, w2 * dw.view(d, 1, 1, 1), b2 * dw + db, 1, (k // 2, 0), 1, d)
+            else:
+                a = F.conv2d(a, w2, b2, 1, (k // 2, 0), 1, d)
+                if i < 3:
+                    a = F.conv2d(a, P[n + ".dilconv.weight"], P[n + ".dilconv.bias"], 1, 0, 2, d)  # k = 1: dilation is moot
+            branches.append(_q(a))
+        ws = [F.conv2d(_q(b.mean((2, 3), keepdim=True)), _q(P[f"{n}.SE{i + 1}.conv.0.weight"]), P[f"{n}.SE{i + 1}.conv.0.bias"])
+              for i, b in enumerate(branches)]                               # (B, d, 1, 1) each
+        weight = torch.softmax(torch.sigmoid(torch.cat(ws, 2)), 2)           # (B, d, 4, 1): softmax over the branches
+        x_att = sum(weight[:, :, i:i + 1] * b for i, b in enumerate(branches))
+        out = F.conv2d(_q(x_att), _q(P[n + ".conv4.weight"]), P[n + ".conv4.bias"])
+        return _q(_q(out) * x)
+
+
+class ELA:
+    """nn/Addmodules/ELA.py:33-101: x * (sig(ch_w) * channel gate + sig(sp_w) * row gate * column gate) + sig(res_w) * x.
+    Channel gate: sigmoid of a depthwise Conv1d applied to the length-1 sequence of the channel's global mean (only the
+    centre tap ever meets data).  Row / column gates: mean over W / H -> depthwise Conv1d (dilation 2) -> GroupNorm
+    (channel // 16 groups) -> sigmoid; one conv and one norm shared by both directions."""
+
+    def __init__(self, name, channel, b=1, gamma=2):
+        self.name, self.c = name, channel
+        k = int(abs((math.log(channel, 2) + b) / gamma))
+        self.k = k if k % 2 else k + 1
+        self.groups = max(1, channel // 16)
+
+    def specs(self):
+        n = self.name
+        yield (n + ".ch_weight", (1,))
+        yield (n + ".sp_weight", (1,))
+        yield (n + ".res_weight", (1,))
+        yield (n + ".ch_att.2.weight", (self.c, 1, self.k))
+        yield (n + ".spatial_conv.weight", (self.c, 1, self.k))
+        yield (n + ".gn.weight", (self.c,))
+        yield (n + ".gn.bias", (self.c,))
+
+    def __call__(self, P, x):
+        n, k = self.name, self.k
+        x = _q(x)
+        B, C, H, W = x.shape
+        ch = torch.sigmoid(F.conv1d(x.mean((2, 3)).view(B, C, 1), P[n + ".ch_att.2.weight"], None, 1, (k - 1) // 2, 1, C))
+        ch = ch.view(B, C, 1, 1)
+
+        def gate(v):  # v (B, C, L)
+            v = F.conv1d(v, P[n + ".spatial_conv.weight"], None, 1, (k - 1) * 2 // 2, 2, C)
+            return torch.sigmoid(F.group_norm(v, self.groups, P[n + ".gn.weight"], P[n + ".gn.bias"], 1e-5))
+
+        h_att = gate(x.mean(3)).view(B, C, H, 1)
+        w_att = gate(x.mean(2)).view(B, C, 1, W)
+        mask = torch.sigmoid(P[n + ".ch_weight"]) * ch + torch.sigmoid(P[n + ".sp_weight"]) * (h_att * w_att)
+        return _q(x * mask + torch.sigmoid(P[n + ".res_weight"]) * x)
+
+
 def make_anchors(feats, strides, offset=0.5):  # utils/tal.py:371-383
     pts, st = [], []
     for f, s in zip(feats, strides):
@@ -433,7 +619,7 @@ class Model:
         for i, (f, n, t, args) in enumerate(GRAPHS[family]):
             name = f"model.{i}"
             n = max(round(n * depth), 1) if n > 1 else n  # tasks.py:972
-            if t in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA"):
+            if t in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA", "C3k2_gai", "SCDown"):
                 c1 = chans[f] if chans else ch  # tasks.py:1014 (ch[f]; the first layer sees the image)
                 c2 = make_divisible(min(args[0], max_ch) * width, 8)  # tasks.py:1016
                 if t == "Conv":
@@ -444,12 +630,22 @@ class Model:
                     if scale in "mlx":
                         a[0] = True
                     m = C3k2(name, c1, c2, n, *a)
+                elif t == "C3k2_gai":  # tasks.py:1038 (repeat count inserted; no m/l/x override, no legacy switch)
+                    m = C3k2_gai(name, c1, c2, n, *args[1:])
+                elif t == "SCDown":
+                    m = SCDown(name, c1, c2, *args[1:])
                 elif t == "C2f":
                     m = C2f(name, c1, c2, n, *args[1:])
                 elif t == "SPPF":
                     m = SPPF(name, c1, c2, *args[1:])
                 else:
                     m = C2PSA(name, c1, c2, n)
+            elif t == "MSCAAttention":  # tasks.py:1052-1054
+                c2 = chans[f]
+                m = MSCAAttention(name, c2)
+            elif t == "ELA":  # tasks.py:1066-1070: built on the INPUT channels; args[0] only feeds the channel bookkeeping
+                c2 = make_divisible(min(args[0], max_ch) * width, 8)
+                m = ELA(name, chans[f])
             elif t == "Upsample":
                 m, c2 = "up", chans[f]
             elif t == "Concat":
@@ -510,7 +706,7 @@ def synth_param(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor:
     shape = tuple(int(s) for s in shape)
     if name.endswith("dfl.conv.weight"):
         return torch.arange(16, dtype=torch.float32).view(shape)
-    if name.endswith("bn.weight"):
+    if name.endswith("bn.weight") or name.endswith("gn.weight"):
         a = rng.uniform(0.7, 1.3, shape)
     elif name.endswith("bn.bias") or name.endswith("running_mean"):
         a = rng.uniform(-0.3, 0.3, shape)

