@@ -21,6 +21,7 @@ SOURCES = {
     "conv_first.hip": [],
     "stem_fused.hip": [],
     "bneck_fused.hip": [],
+    "bsyolo_ops.hip": [],
     "elementwise.hip": [],
     "attention.hip": [],
     "detect.hip": [],

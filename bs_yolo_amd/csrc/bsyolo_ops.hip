@@ -1,0 +1,387 @@
+// Kernels for the modules only the BS-YOLO graph uses (cfg/models/11/yolo11.yaml of the fork):
+//   dwconv_generic_kernel : depthwise kh x kw conv, stride 1 / 2, "same" padding, + bias (+SiLU on the first act_c
+//                           channels: PMSFA's 7x7 runs on half of its input and passes the other half through)  -- PMSFA's 5x5 / 7x7
+//                           (block.py:3035-3054), SCDown.cv2 (block.py:4503-4535), MSCAAttention's 5x5 and strip convs
+//                           1x5 .. 21x1 (nn/Addmodules/MSCA.py:26-39)
+//   copy_view_kernel      : materialise one operand of a Concat (optionally through nearest x2) into a channel slice
+//   gap_kernel            : per (image, channel) mean over H x W                  (MSCA.py:69-72, ELA.py:50)
+//   msca_mix_kernel       : softmax_i(sigmoid(l_i)) weighted sum of the four branch maps   (MSCA.py:74-82)
+//   mul_kernel            : elementwise product of two maps                        (MSCA.py:86 `attn * u`)
+//   ela_stats / ela_gate / ela_apply : ELA (nn/Addmodules/ELA.py:77-101)
+// All NHWC f16 channel-slice views (8-channel = 16-byte pieces); reductions and gates in f32.  These layers are a few
+// percent of the BS-YOLO forward; the kernels are written for clarity and coalescing, not tuned.
+#include "common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t bo_rsrc_t;
+__device__ __forceinline__ bo_rsrc_t bo_make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ half8 bo_load16(bo_rsrc_t r, unsigned voff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    union { u32x4 u; half8 h; } v;
+    v.u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return v.h;
+}
+#else
+typedef int bo_rsrc_t;
+__device__ __forceinline__ bo_rsrc_t bo_make_rsrc(const void*, unsigned) { return 0; }
+__device__ __forceinline__ half8 bo_load16(bo_rsrc_t, unsigned) { return half8{0, 0, 0, 0, 0, 0, 0, 0}; }
+#endif
+#define BO_OOB 0xFFFFFFF0u
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depthwise kh x kw, stride s, pad (kh/2, kw/2).  thread = (image, output pixel, 8-channel chunk); weights f32
+// [kh*kw][wld] (wld = channels of the whole weight tensor: a launch may cover a channel sub-range of it).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_generic_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W,
+                                                             int C, int OH, int OW, int kh, int kw, int stride,
+                                                             const float* __restrict__ w, int wld,
+                                                             const float* __restrict__ bias, half_t* __restrict__ dst,
+                                                             int ldd, int act_c, unsigned span) {
+    const int C8 = C >> 3;
+    const long long total = (long long)B * OH * OW * C8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8) * 8;
+    long long t = idx / C8;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const bo_rsrc_t rs = bo_make_rsrc(src, span);
+    float acc[8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c), b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = b0[j]; acc[4 + j] = b1[j]; }
+    }
+    const int iy0 = oy * stride - kh / 2, ix0 = ox * stride - kw / 2;
+    for (int dy = 0; dy < kh; ++dy) {
+        const int iy = iy0 + dy;
+        const bool rowok = (unsigned)iy < (unsigned)H;
+        for (int dx = 0; dx < kw; ++dx) {
+            const int ix = ix0 + dx;
+            const unsigned off = (rowok && (unsigned)ix < (unsigned)W)
+                                     ? 2u * ((unsigned)((n * H + iy) * W + ix) * (unsigned)lds_ + (unsigned)c) : BO_OOB;
+            const half8 v = bo_load16(rs, off);
+            const float* wp = w + (size_t)(dy * kw + dx) * wld + c;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = fmaf((float)v[j], w0[j], acc[j]);
+                acc[4 + j] = fmaf((float)v[4 + j], w1[j], acc[4 + j]);
+            }
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(c + j < act_c ? silu_f(acc[j]) : acc[j]);  // SiLU on the first act_c channels
+    *reinterpret_cast<half8*>(dst + ((size_t)(n * OH + oy) * OW + ox) * ldd + c) = o;
+}
+
+int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s) {
+    if (!a.src || !a.dst || !a.w || !a.b) BSY_FAIL(BSY_ERR_ARG, "dwconv: null pointer");
+    if ((a.C & 7) || (a.lds & 7) || (a.ldd & 7) || (a.wld & 3) || ((uintptr_t)a.src & 15) || ((uintptr_t)a.dst & 15) ||
+        ((uintptr_t)a.w & 15) || ((uintptr_t)a.b & 15))
+        BSY_FAIL(BSY_ERR_ARG, "dwconv: channels/strides must be multiples of 8 and pointers 16-byte aligned");
+    if (a.kh < 1 || a.kw < 1 || a.kh > 31 || a.kw > 31 || !(a.kh & 1) || !(a.kw & 1) || (a.stride != 1 && a.stride != 2))
+        BSY_FAIL(BSY_ERR_ARG, "dwconv: kernel %d x %d stride %d unsupported (odd sizes up to 31, stride 1 or 2)", a.kh, a.kw, a.stride);
+    const int OH = (a.H + 2 * (a.kh / 2) - a.kh) / a.stride + 1, OW = (a.W + 2 * (a.kw / 2) - a.kw) / a.stride + 1;
+    if (a.OH != OH || a.OW != OW) BSY_FAIL(BSY_ERR_ARG, "dwconv: output extent mismatch");
+    const long long elems = (long long)a.B * a.H * a.W * a.lds;
+    if (elems >= (1LL << 31)) BSY_FAIL(BSY_ERR_ARG, "dwconv: source view exceeds 2^31 elements (split the batch)");
+    const unsigned span = (unsigned)((((long long)a.B * a.H * a.W - 1) * a.lds + a.C) * 2);
+    const long long total = (long long)a.B * OH * OW * (a.C / 8);
+    if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "dwconv: empty");
+    hipLaunchKernelGGL(dwconv_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H,
+                       a.W, a.C, OH, OW, a.kh, a.kw, a.stride, a.w, a.wld, a.b, a.dst, a.ldd, a.act_c, span);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dst[n, y, x, 0:C] = src[n, y >> up, x >> up, 0:C]
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_view_kernel(const half_t* __restrict__ src, int lds_, int up, int B, int H,
+                                                        int W, int C, half_t* __restrict__ dst, int ldd) {
+    const int C8 = C >> 3;
+    const long long total = (long long)B * H * W * C8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8) * 8;
+    long long t = idx / C8;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const int SH = H >> up, SW = W >> up;
+    const half8 v = *reinterpret_cast<const half8*>(src + ((size_t)(n * SH + (y >> up)) * SW + (x >> up)) * lds_ + c);
+    *reinterpret_cast<half8*>(dst + ((size_t)(n * H + y) * W + x) * ldd + c) = v;
+}
+
+int launch_copy_view(const half_t* src, int lds_, int up, int B, int H, int W, int C, half_t* dst, int ldd, hipStream_t s) {
+    if (!src || !dst || (C & 7) || (lds_ & 7) || (ldd & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) ||
+        (up && ((H | W) & 1)) || B <= 0 || H <= 0 || W <= 0)
+        BSY_FAIL(BSY_ERR_ARG, "copy_view: bad layout");
+    const long long total = (long long)B * H * W * (C / 8);
+    hipLaunchKernelGGL(copy_view_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, lds_, up, B, H, W, C, dst, ldd);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Global average pool: out[n, c] = mean over H*W (f16 vector (B, ldo), f32 accumulation).  One workgroup per
+// (image, 8-channel chunk): 256 threads stride the pixels, LDS tree.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_kernel(const half_t* __restrict__ src, int lds_, int HW, half_t* __restrict__ out, int ldo) {
+    __shared__ float red[256][8];
+    const int c = blockIdx.x * 8, n = blockIdx.y, tid = threadIdx.x;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = tid; p < HW; p += 256) {
+        const half8 v = *reinterpret_cast<const half8*>(src + ((size_t)n * HW + p) * lds_ + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid][j] = a[j];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid][j] += red[tid + st][j];
+        __syncthreads();
+    }
+    if (tid < 8) out[(size_t)n * ldo + c + tid] = (half_t)(red[0][tid] / (float)HW);
+}
+
+int launch_gap(const half_t* src, int lds_, int B, int H, int W, int C, half_t* out, int ldo, hipStream_t s) {
+    if (!src || !out || (C & 7) || (lds_ & 7) || ((uintptr_t)src & 15) || B <= 0 || H <= 0 || W <= 0 || ldo < C)
+        BSY_FAIL(BSY_ERR_ARG, "gap: bad layout");
+    hipLaunchKernelGGL(gap_kernel, dim3(C / 8, B), dim3(256), 0, s, src, lds_, H * W, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MSCA branch mix: weight_i[n, c] = softmax over i of sigmoid(logit_i[n, c]); out = sum_i weight_i * branch_i
+// ---------------------------------------------------------------------------------------------------------------------
+struct MixK {
+    const half_t* br[4];
+    int ldb[4];
+    const float* lg[4];
+    int ldl[4];
+};
+__global__ __launch_bounds__(256) void msca_mix_kernel(const MixK k, int B, int HW, int C, half_t* __restrict__ dst, int ldd) {
+    const int C8 = C >> 3;
+    const long long total = (long long)B * HW * C8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8) * 8;
+    const long long pix = idx / C8;
+    const int n = (int)(pix / HW);
+    float w[4][8], den[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) den[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sg = 1.0f / (1.0f + __expf(-k.lg[i][(size_t)n * k.ldl[i] + c + j]));
+            w[i][j] = __expf(sg);  // sigmoid output is in (0, 1): no max subtraction needed
+            den[j] += w[i][j];
+        }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const half8 v = *reinterpret_cast<const half8*>(k.br[i] + (size_t)pix * k.ldb[i] + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[i][j] / den[j], (float)v[j], acc[j]);
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+    *reinterpret_cast<half8*>(dst + (size_t)pix * ldd + c) = o;
+}
+
+int launch_msca_mix(const MixArgs& a, hipStream_t s) {
+    MixK k;
+    for (int i = 0; i < 4; ++i) {
+        if (!a.br[i] || !a.lg[i] || (a.ldb[i] & 7) || ((uintptr_t)a.br[i] & 15)) BSY_FAIL(BSY_ERR_ARG, "msca_mix: branch %d bad layout", i);
+        k.br[i] = a.br[i]; k.ldb[i] = a.ldb[i]; k.lg[i] = a.lg[i]; k.ldl[i] = a.ldl[i];
+    }
+    if (!a.dst || (a.C & 7) || (a.ldd & 7) || ((uintptr_t)a.dst & 15) || a.B <= 0 || a.HW <= 0) BSY_FAIL(BSY_ERR_ARG, "msca_mix: bad layout");
+    const long long total = (long long)a.B * a.HW * (a.C / 8);
+    hipLaunchKernelGGL(msca_mix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, a.B, a.HW, a.C, a.dst, a.ldd);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const half_t* __restrict__ a, int lda, const half_t* __restrict__ b, int ldb,
+                                                  long long npix, int C, half_t* __restrict__ dst, int ldd) {
+    const int C8 = C >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * C8) return;
+    const int c = (int)(idx % C8) * 8;
+    const long long pix = idx / C8;
+    const half8 x = *reinterpret_cast<const half8*>(a + (size_t)pix * lda + c), y = *reinterpret_cast<const half8*>(b + (size_t)pix * ldb + c);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)x[j] * (float)y[j]);
+    *reinterpret_cast<half8*>(dst + (size_t)pix * ldd + c) = o;
+}
+
+int launch_mul(const half_t* a, int lda, const half_t* b, int ldb, long long npix, int C, half_t* dst, int ldd, hipStream_t s) {
+    if (!a || !b || !dst || (C & 7) || (lda & 7) || (ldb & 7) || (ldd & 7) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst) & 15) || npix <= 0)
+        BSY_FAIL(BSY_ERR_ARG, "mul: bad layout");
+    const long long total = npix * (C / 8);
+    hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, lda, b, ldb, npix, C, dst, ldd);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ELA.  scratch (f32) per image: [rowmean H*C][colmean W*C][gmean C][hgate H*C][wgate W*C][cgate C]
+//   ela_stats : row means (over W), column means (over H), global mean.  One workgroup per (image, 8-channel chunk).
+//   ela_gate  : v = dilated (2) depthwise conv1d of the means (k taps, zero pad k-1) -> GroupNorm over (16 channels x L)
+//               -> sigmoid; plus the channel gate sigmoid(w_centre * gmean).  One workgroup per (image, group, direction).
+//   ela_apply : out = x * (a * cgate[c] + b * hgate[y, c] * wgate[x, c]) + r * x
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ela_stats_kernel(const half_t* __restrict__ src, int lds_, int H, int W, int C,
+                                                        float* __restrict__ scratch, size_t per_img) {
+    const int c = blockIdx.x * 8, n = blockIdx.y, tid = threadIdx.x;
+    float* row = scratch + (size_t)n * per_img;
+    float* col = row + (size_t)H * C;
+    float* gm = col + (size_t)W * C;
+    const half_t* ip = src + (size_t)n * H * W * lds_ + c;
+    __shared__ float part[256][8];
+    float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int y = tid; y < H; y += 256) {  // row means: thread per row
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int x = 0; x < W; ++x) {
+            const half8 v = *reinterpret_cast<const half8*>(ip + ((size_t)y * W + x) * lds_);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { row[(size_t)y * C + c + j] = a[j] / (float)W; tot[j] += a[j]; }
+    }
+    for (int x = tid; x < W; x += 256) {  // column means: thread per column
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int y = 0; y < H; ++y) {
+            const half8 v = *reinterpret_cast<const half8*>(ip + ((size_t)y * W + x) * lds_);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) col[(size_t)x * C + c + j] = a[j] / (float)H;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[tid][j] = tot[j];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[tid][j] += part[tid + st][j];
+        __syncthreads();
+    }
+    if (tid < 8) gm[c + tid] = part[0][tid] / (float)(H * W);
+}
+
+// grid (groups, B, 2): z = 0 rows (L = H), 1 columns (L = W).  LDS: conv output of the group [L][16].
+__global__ __launch_bounds__(256) void ela_gate_kernel(float* __restrict__ scratch, size_t per_img, int H, int W, int C, int k,
+                                                       int gsz, const float* __restrict__ wsp, const float* __restrict__ wch,
+                                                       const float* __restrict__ gnw, const float* __restrict__ gnb) {
+    extern __shared__ float sv[];  // [L][gsz] + reduction scratch [256][2]
+    const int g = blockIdx.x, n = blockIdx.y, dir = blockIdx.z, tid = threadIdx.x;
+    const int L = dir ? W : H;
+    float* base = scratch + (size_t)n * per_img;
+    const float* mean = dir ? base + (size_t)H * C : base;
+    float* gate = base + (size_t)(H + W + 1) * C + (dir ? (size_t)H * C : 0);
+    const int c0 = g * gsz;
+    float* red = sv + (size_t)L * gsz;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < L * gsz; i += 256) {
+        const int l = i / gsz, cc = i - l * gsz, c = c0 + cc;
+        float v = 0.f;
+        for (int t = 0; t < k; ++t) {  // padding (k-1)*2/2 = k-1, dilation 2: tap t reads position l - (k-1) + 2t
+            const int p = l - (k - 1) + 2 * t;
+            if ((unsigned)p < (unsigned)L) v = fmaf(wsp[(size_t)c * k + t], mean[(size_t)p * C + c], v);
+        }
+        sv[i] = v;
+        s1 += v;
+        s2 += v * v;
+    }
+    red[2 * tid] = s1;
+    red[2 * tid + 1] = s2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { red[2 * tid] += red[2 * (tid + st)]; red[2 * tid + 1] += red[2 * (tid + st) + 1]; }
+        __syncthreads();
+    }
+    const float cnt = (float)(L * gsz);
+    const float mu = red[0] / cnt;
+    const float var = fmaxf(red[1] / cnt - mu * mu, 0.f);  // biased variance (F.group_norm)
+    const float rstd = rsqrtf(var + 1e-5f);
+    for (int i = tid; i < L * gsz; i += 256) {
+        const int l = i / gsz, c = c0 + (i - l * gsz);
+        const float z = (sv[i] - mu) * rstd * gnw[c] + gnb[c];
+        gate[(size_t)l * C + c] = 1.0f / (1.0f + __expf(-z));
+    }
+    if (dir == 0 && tid < gsz) {  // channel gate: the Conv1d sees a length-1 sequence -> only its centre tap contributes
+        const int c = c0 + tid;
+        const float gmv = base[(size_t)(H + W) * C + c];
+        base[(size_t)(2 * (H + W) + 1) * C + c] = 1.0f / (1.0f + __expf(-(wch[(size_t)c * k + (k - 1) / 2] * gmv)));
+    }
+}
+
+__global__ __launch_bounds__(256) void ela_apply_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W, int C,
+                                                        const float* __restrict__ scratch, size_t per_img, float ca, float sb,
+                                                        float rr, half_t* __restrict__ dst, int ldd) {
+    const int C8 = C >> 3;
+    const long long total = (long long)B * H * W * C8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8) * 8;
+    long long t = idx / C8;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const float* base = scratch + (size_t)n * per_img + (size_t)(H + W + 1) * C;
+    const float* hg = base + (size_t)y * C + c;
+    const float* wg = base + (size_t)H * C + (size_t)x * C + c;
+    const float* cg = base + (size_t)(H + W) * C + c;
+    const size_t pix = (size_t)(n * H + y) * W + x;
+    const half8 v = *reinterpret_cast<const half8*>(src + pix * lds_ + c);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xv = (float)v[j];
+        o[j] = (half_t)(xv * (ca * cg[j] + sb * (hg[j] * wg[j])) + rr * xv);
+    }
+    *reinterpret_cast<half8*>(dst + pix * ldd + c) = o;
+}
+
+size_t ela_scratch_floats(int H, int W, int C) { return (size_t)(2 * (H + W) + 2) * C; }
+
+int launch_ela(const ElaArgs& a, hipStream_t s) {
+    if (!a.src || !a.dst || !a.scratch || !a.wsp || !a.wch || !a.gnw || !a.gnb) BSY_FAIL(BSY_ERR_ARG, "ela: null pointer");
+    if ((a.C & 15) || (a.lds & 7) || (a.ldd & 7) || (((uintptr_t)a.src | (uintptr_t)a.dst) & 15) || a.k < 1 || !(a.k & 1) || a.k > 15 ||
+        a.B <= 0 || a.H <= 0 || a.W <= 0)
+        BSY_FAIL(BSY_ERR_ARG, "ela: bad layout (C must be a multiple of 16, odd kernel <= 15)");
+    const int gsz = a.C >= 16 ? 16 : a.C;  // GroupNorm(max(1, C // 16), C)
+    const int groups = a.C / gsz;
+    const size_t per_img = ela_scratch_floats(a.H, a.W, a.C);
+    const int Lmax = a.H > a.W ? a.H : a.W;
+    const size_t lds = ((size_t)Lmax * gsz + 512) * sizeof(float);
+    if (lds > 64 * 1024) BSY_FAIL(BSY_ERR_ARG, "ela: map side %d too long for the gate kernel", Lmax);
+    hipLaunchKernelGGL(ela_stats_kernel, dim3(a.C / 8, a.B), dim3(256), 0, s, a.src, a.lds, a.H, a.W, a.C, a.scratch, per_img);
+    hipLaunchKernelGGL(ela_gate_kernel, dim3(groups, a.B, 2), dim3(256), lds, s, a.scratch, per_img, a.H, a.W, a.C, a.k, gsz, a.wsp,
+                       a.wch, a.gnw, a.gnb);
+    const long long total = (long long)a.B * a.H * a.W * (a.C / 8);
+    hipLaunchKernelGGL(ela_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H, a.W, a.C,
+                       a.scratch, per_img, a.ch_coef, a.sp_coef, a.res_coef, a.dst, a.ldd);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}

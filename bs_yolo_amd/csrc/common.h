@@ -108,6 +108,44 @@ struct BneckArgs {
 bool bneck_fused_supported(int C, int CH);
 int launch_bneck_fused(const BneckArgs& a, hipStream_t s);
 
+// ---- BS-YOLO-only modules (bsyolo_ops.hip) ----------------------------------------------------------------------------
+struct DwGenArgs {       // depthwise kh x kw, stride 1 / 2, "same" padding, + bias (+SiLU)
+    const half_t* src;
+    int lds;
+    int B, H, W, C, OH, OW, kh, kw, stride;
+    const float* w;      // [kh*kw][wld] (already offset to this launch's first channel)
+    int wld;
+    const float* b;
+    half_t* dst;
+    int ldd, act_c;      // SiLU on channels [0, act_c) of this launch, identity on the rest
+};
+int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s);
+int launch_copy_view(const half_t* src, int lds_, int up, int B, int H, int W, int C, half_t* dst, int ldd, hipStream_t s);
+int launch_gap(const half_t* src, int lds_, int B, int H, int W, int C, half_t* out, int ldo, hipStream_t s);
+struct MixArgs {
+    const half_t* br[4];
+    int ldb[4];
+    const float* lg[4];  // branch logits (B, ldl) f32
+    int ldl[4];
+    int B, HW, C;
+    half_t* dst;
+    int ldd;
+};
+int launch_msca_mix(const MixArgs& a, hipStream_t s);
+int launch_mul(const half_t* a, int lda, const half_t* b, int ldb, long long npix, int C, half_t* dst, int ldd, hipStream_t s);
+struct ElaArgs {
+    const half_t* src;
+    int lds;
+    int B, H, W, C, k;
+    const float *wsp, *wch, *gnw, *gnb;  // spatial_conv [C][k], ch_att conv [C][k], GroupNorm weight / bias [C]
+    float ch_coef, sp_coef, res_coef;    // sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight)
+    float* scratch;                      // ela_scratch_floats(H, W, C) * B floats
+    half_t* dst;
+    int ldd;
+};
+size_t ela_scratch_floats(int H, int W, int C);
+int launch_ela(const ElaArgs& a, hipStream_t s);
+
 struct DwArgs {
     const half_t* src;
     int lds;

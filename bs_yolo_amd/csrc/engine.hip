@@ -173,6 +173,55 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok) return BSY_ERR_ARG;
             return launch_bneck_fused(a, s);
         }
+        case BSY_OP_DWCONV_G: {
+            DwGenArgs a;
+            a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C;
+            a.OH = op.OH; a.OW = op.OW; a.kh = op.ksize; a.kw = op.pad; a.stride = op.stride;
+            a.wld = op.heads; a.w = (const float*)(wb + op.w_off) + op.key_dim; a.b = (const float*)(wb + op.b_off) + op.key_dim;
+            a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.act_c = op.act;  // act = number of leading channels with SiLU
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_dwconv_generic(a, s);
+        }
+        case BSY_OP_COPY: {
+            const half_t* src = R.h(op.src0);
+            half_t* dst = R.h(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_copy_view(src, op.src0.ld, op.up0, op.B, op.H, op.W, op.src0.C, dst, op.dst.ld, s);
+        }
+        case BSY_OP_GAP: {
+            const half_t* src = R.h(op.src0);
+            half_t* dst = R.h(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_gap(src, op.src0.ld, op.B, op.H, op.W, op.src0.C, dst, op.dst.ld, s);
+        }
+        case BSY_OP_MSCA_MIX: {
+            MixArgs a;
+            for (int i = 0; i < 4; ++i) {
+                const bsy_view& bv = i < 3 ? op.box[i] : op.res;
+                const bsy_view& lv = i < 3 ? op.cls[i] : op.msk[0];
+                a.br[i] = R.h(bv); a.ldb[i] = bv.ld; a.lg[i] = R.f(lv); a.ldl[i] = lv.ld;
+            }
+            a.B = op.B; a.HW = op.H * op.W; a.C = op.dst.C; a.dst = R.h(op.dst); a.ldd = op.dst.ld;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_msca_mix(a, s);
+        }
+        case BSY_OP_MUL: {
+            const half_t* x = R.h(op.src0);
+            const half_t* y = R.h(op.src1);
+            half_t* dst = R.h(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_mul(x, op.src0.ld, y, op.src1.ld, (long long)op.B * op.H * op.W, op.dst.C, dst, op.dst.ld, s);
+        }
+        case BSY_OP_ELA: {
+            ElaArgs a;
+            a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C; a.k = op.ksize;
+            const float* blob = (const float*)(wb + op.w_off);
+            a.wsp = blob; a.wch = blob + (size_t)a.C * a.k; a.gnw = a.wch + (size_t)a.C * a.k; a.gnb = a.gnw + a.C;
+            a.ch_coef = op.scale; a.sp_coef = op.lvl_stride[0]; a.res_coef = op.lvl_stride[1];
+            a.scratch = R.f(op.res); a.dst = R.h(op.dst); a.ldd = op.dst.ld;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_ela(a, s);
+        }
         case BSY_OP_CONV: {
             ConvArgs a;
             a.src0 = R.h(op.src0); a.src1 = R.h(op.src1);
@@ -461,6 +510,31 @@ extern "C" int bsy_bottleneck_fused(const void* x, int ldx, int B, int H, int W,
 }
 
 extern "C" int bsy_bottleneck_fused_supported(int C, int CH) { return bneck_fused_supported(C, CH) ? 1 : 0; }
+
+extern "C" int bsy_dwconv(const void* x, int ldx, int B, int H, int W, int C, int kh, int kw, int stride, const float* w,
+                          int wld, const float* b, void* y, int ldy, int act, bsy_stream stream) {
+    DwGenArgs a;
+    a.src = (const half_t*)x; a.lds = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.kh = kh; a.kw = kw; a.stride = stride;
+    if (kh < 1 || kw < 1 || (stride != 1 && stride != 2)) BSY_FAIL(BSY_ERR_ARG, "dwconv: bad kernel / stride");
+    a.OH = (H + 2 * (kh / 2) - kh) / stride + 1; a.OW = (W + 2 * (kw / 2) - kw) / stride + 1;
+    a.w = w; a.wld = wld; a.b = b; a.dst = (half_t*)y; a.ldd = ldy; a.act_c = act ? C : 0;
+    return launch_dwconv_generic(a, (hipStream_t)stream);
+}
+
+extern "C" size_t bsy_ela_scratch_bytes(int B, int H, int W, int C) {
+    return (B > 0 && H > 0 && W > 0 && C > 0) ? ela_scratch_floats(H, W, C) * (size_t)B * sizeof(float) : 0;
+}
+
+extern "C" int bsy_ela(const void* x, int ldx, int B, int H, int W, int C, int k, const float* wsp, const float* wch,
+                       const float* gnw, const float* gnb, const float* coef, void* scratch, void* y, int ldy,
+                       bsy_stream stream) {
+    if (!coef) BSY_FAIL(BSY_ERR_ARG, "ela: null coefficient pointer");
+    ElaArgs a;
+    a.src = (const half_t*)x; a.lds = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.k = k;
+    a.wsp = wsp; a.wch = wch; a.gnw = gnw; a.gnb = gnb; a.ch_coef = coef[0]; a.sp_coef = coef[1]; a.res_coef = coef[2];
+    a.scratch = (float*)scratch; a.dst = (half_t*)y; a.ldd = ldy;
+    return launch_ela(a, (hipStream_t)stream);
+}
 
 extern "C" int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y,
                              int ldy, int act, const void* res, int ldr, bsy_stream stream) {

@@ -51,7 +51,26 @@ _YOLOV8 = {
     "detect_from": [15, 18, 21],
 }
 
-_FAMILIES = {"yolo11": _YOLO11, "yolov8": _YOLOV8}
+# The fork's own graph, cfg/models/11/yolo11.yaml:15-52 (nc = 12 there): C3k2_gai / SCDown / MSCAAttention in the backbone,
+# an ELA gate after every neck C3k2, Detect on the ELA outputs.  Layer 21 concatenates layer 13, itself a Concat.
+_BSYOLO11 = {
+    "scales": _YOLO11["scales"],
+    "backbone": [
+        [-1, 1, "Conv", [64, 3, 2]], [-1, 1, "Conv", [128, 3, 2]], [-1, 2, "C3k2_gai", [256, False, 0.25]],
+        [-1, 1, "Conv", [256, 3, 2]], [-1, 2, "C3k2_gai", [512, False, 0.25]], [-1, 1, "SCDown", [512, 3, 2]],
+        [-1, 2, "C3k2_gai", [512, True]], [-1, 1, "SCDown", [1024, 3, 2]], [-1, 2, "C3k2_gai", [1024, True]],
+        [-1, 1, "SPPF", [1024, 5]], [-1, 2, "C2PSA", [1024]], [-1, 1, "MSCAAttention", []],
+    ],
+    "head": [
+        _UP, _cat(6), [-1, 2, "C3k2", [512, False]], [-1, 1, "ELA", [512]],
+        _UP, _cat(4), [-1, 2, "C3k2", [256, False]], [-1, 1, "ELA", [256]],
+        [-1, 1, "Conv", [256, 3, 2]], _cat(13), [-1, 2, "C3k2", [512, False]], [-1, 1, "ELA", [512]],
+        [-1, 1, "SCDown", [512, 3, 2]], _cat(10), [-1, 2, "C3k2", [1024, True]], [-1, 1, "ELA", [1024]],
+    ],
+    "detect_from": [19, 23, 27],
+}
+
+_FAMILIES = {"yolo11": _YOLO11, "yolov8": _YOLOV8, "bsyolo11": _BSYOLO11}
 
 
 def stock_cfg(family: str = "yolo11", scale: str = "s", nc: int = 80, task: str = "detect") -> dict:

@@ -102,6 +102,33 @@ def bottleneck_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: to
     return out
 
 
+def dwconv_nhwc(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, stride: int = 1, act: bool = False) -> torch.Tensor:
+    """Depthwise kh x kw conv, padding k/2 (csrc/bsyolo_ops.hip).  x (B,H,W,C) fp16; w (C,1,kh,kw) fp32; b (C)."""
+    B, H, W, Cc = x.shape
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    wp = w.detach().float().cpu().view(Cc, kh * kw).t().contiguous().to(x.device)
+    bp = b.detach().float().contiguous().to(x.device)
+    OH, OW = (H + 2 * (kh // 2) - kh) // stride + 1, (W + 2 * (kw // 2) - kw) // stride + 1
+    out = torch.empty((B, OH, OW, Cc), dtype=torch.float16, device=x.device)
+    L.check(L.lib.bsy_dwconv(_p(x), Cc, B, H, W, Cc, kh, kw, stride, _p(wp), Cc, _p(bp), _p(out), Cc, int(act), _stream(x)))
+    return out
+
+
+def ela_nhwc(x: torch.Tensor, wsp: torch.Tensor, wch: torch.Tensor, gnw: torch.Tensor, gnb: torch.Tensor, coef) -> torch.Tensor:
+    """ELA.forward (nn/Addmodules/ELA.py:77-101).  x (B,H,W,C) fp16; wsp / wch (C,1,k) Conv1d weights; coef = the three
+    sigmoids (ch, sp, res)."""
+    B, H, W, Cc = x.shape
+    k = int(wsp.shape[-1])
+    dev = x.device
+    f = lambda t: t.detach().float().reshape(-1).contiguous().to(dev)  # noqa: E731
+    a, b_, c, d = f(wsp), f(wch), f(gnw), f(gnb)
+    scratch = torch.empty(int(L.lib.bsy_ela_scratch_bytes(B, H, W, Cc)) // 4, dtype=torch.float32, device=dev)
+    out = torch.empty_like(x)
+    cf = (C.c_float * 3)(*[float(v) for v in coef])
+    L.check(L.lib.bsy_ela(_p(x), Cc, B, H, W, Cc, k, _p(a), _p(b_), _p(c), _p(d), cf, _p(scratch), _p(out), Cc, _stream(x)))
+    return out
+
+
 def dwconv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: bool = True,
                    res: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x (B,H,W,C) fp16; w (C,1,3,3) fp32.  DWConv (conv.py:224-229)."""

@@ -60,6 +60,9 @@ class WRec:
     k: int
     perm: Optional[List[int]] = None   # output-channel permutation (qkv)
     tap: Optional[Tuple[int, int]] = None  # deconv: (dy, dx)
+    kw: Optional[int] = None           # dwg: kernel width when != k (strip convs)
+    post: Optional[str] = None         # dwg: name of a depthwise 1x1 conv folded in after this one (MSCA dilconv)
+    coef: Tuple[float, float, float] = (0.0, 0.0, 0.0)  # ela: sigmoid(ch_weight / sp_weight / res_weight), set when packed
     w_off: int = -1
     b_off: int = -1
 
@@ -94,7 +97,7 @@ class Plan:
         self.meta: Dict = {}
         self._lane = 0
         self._build()
-        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK) for o in self.ops)
+        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK, L.OP_DWCONV_G) for o in self.ops)
 
     # ---- buffers -------------------------------------------------------------------------------------------
     def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
@@ -151,6 +154,25 @@ class Plan:
         self.flops += 2 * self.B * src.H * src.W * src.C * 9
         return dst
 
+    def dwconv_g(self, name: str, src: T, kh: int, kw: int, s: int, act_c: int, dst: Optional[T] = None, kind: str = "dwg",
+                 post: Optional[str] = None) -> T:
+        """Depthwise kh x kw conv with "same" padding (csrc/bsyolo_ops.hip); SiLU on the first act_c channels.
+        kind: "dwg" (Conv + BN), "dwg_plain" (bare nn.Conv2d with bias), "dwg_ext" (PMSFA.conv3, see pmsfa())."""
+        assert not src.up and not src.f32
+        OH, OW = (src.H + 2 * (kh // 2) - kh) // s + 1, (src.W + 2 * (kw // 2) - kw) // s + 1
+        if dst is None:
+            dst = self.alloc(src.C, OH, OW)
+        assert dst.C == src.C and dst.H == OH and dst.W == OW
+        key = self._wrec(name, name=name, kind=kind, cout=src.C, cin=1, k=kh, kw=kw, post=post)
+        self.ops.append(dict(kind=L.OP_DWCONV_G, H=src.H, W=src.W, OH=OH, OW=OW, src0=src, dst=dst, ksize=kh, pad=kw, stride=s,
+                             act=int(act_c), wkey=key, heads=src.C, key_dim=0, name=name, lane=self._lane))
+        self.flops += 2 * self.B * OH * OW * src.C * kh * kw
+        return dst
+
+    def copy(self, name: str, src: T, dst: T):
+        assert dst.C == src.C and dst.H == src.H and dst.W == src.W and not dst.up
+        self.ops.append(dict(kind=L.OP_COPY, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, dst=dst, name=name, lane=self._lane))
+
     # ---- module expansions -----------------------------------------------------------------------------------
     def bottleneck(self, name: str, x: T, dst: T, shortcut: bool, k=(3, 3), e=0.5):
         """block.py:3405-3419: x + cv2(cv1(x))."""
@@ -187,13 +209,81 @@ class Plan:
         self.conv(name + ".cv1", xs, 2 * c, 1, 1, dst=cat.slice(0, 2 * c))
         for i in range(n):
             src, dst = cat.slice((1 + i) * c, c), cat.slice((2 + i) * c, c)
-            if inner == "c3k":
+            if inner == "pmsfa":
+                self.pmsfa(f"{name}.m.{i}", src, dst)
+            elif inner == "c3k_gai":
+                self.c3k_gai(f"{name}.m.{i}", src, dst, 2)
+            elif inner == "c3k":
                 self.c3k(f"{name}.m.{i}", src, dst, 2, shortcut)
             elif inner == "c2f":
                 self.bottleneck(f"{name}.m.{i}", src, dst, shortcut, (3, 3), 1.0)
             else:
                 self.bottleneck(f"{name}.m.{i}", src, dst, shortcut, (3, 3), 0.5)
         return self.conv(name + ".cv2", cat, c2, 1, 1)
+
+    def pmsfa(self, name: str, x: T, dst: T):
+        """block.py:3035-3054.  conv1 -> P = [p1 | p2]; depthwise 5x5 on p1 -> Q = [q1 | q2]; the depthwise 7x7 runs on ALL
+        of Q with weights extended by an identity kernel for the q2 half (weights.py kind "dwg_ext": exact pass-through,
+        SiLU only on the q1 half) -> S = [conv3(q1) | q2]; conv4 reads the virtual concat [S | p2] = the reference's
+        cat([conv3_out, conv2_out_2, conv1_out_2]) and adds x."""
+        c = x.C
+        assert dst.C == c and c % 16 == 0, "PMSFA width must be a multiple of 16 (8-channel pieces of its halves)"
+        P = self.conv(name + ".conv1", x, c, 3, 1)
+        Q = self.dwconv_g(name + ".conv2", P.slice(0, c // 2), 5, 5, 1, c // 2)
+        S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, c // 4, kind="dwg_ext")
+        self.conv(name + ".conv4", [S, P.slice(c // 2, c // 2)], c, 1, 1, dst=dst, res=x)
+
+    def c3k_gai(self, name: str, x: T, dst: T, n: int):
+        """block.py:3079-3086: C3 (cv3(cat(m(cv1 x), cv2 x))) with m = n x PMSFA(c_)."""
+        c_ = int(dst.C * 0.5)
+        cat = self.alloc(2 * c_, x.H, x.W)
+        cur = self.conv(name + ".cv1", x, c_, 1, 1)
+        self.conv(name + ".cv2", x, c_, 1, 1, dst=cat.slice(c_, c_))
+        for i in range(n):
+            out = cat.slice(0, c_) if i == n - 1 else self.alloc(c_, x.H, x.W)
+            self.pmsfa(f"{name}.m.{i}", cur, out)
+            cur = out
+        self.conv(name + ".cv3", cat, dst.C, 1, 1, dst=dst)
+
+    def scdown(self, name: str, x: T, c2: int, k: int, s: int) -> T:
+        """block.py:4503-4535."""
+        t = self.conv(name + ".cv1", x, c2, 1, 1)
+        return self.dwconv_g(name + ".cv2", t, k, k, s, 0)
+
+    def msca(self, name: str, x: T) -> T:
+        """nn/Addmodules/MSCA.py:19-88.  The depthwise 1x1 `dilconv` that follows the first three branches' column convs is
+        folded into their weights; the four SE convs run on (B, 1, 1, C) maps through the ordinary 1x1 conv kernel."""
+        assert not x.up
+        C, H, W = x.C, x.H, x.W
+        attn = self.dwconv_g(name + ".conv0", x, 5, 5, 1, 0, kind="dwg_plain")
+        branches, logits = [], []
+        for i, (k, base) in enumerate(((5, "conv0"), (7, "conv1"), (11, "conv2"), (21, "conv3"))):
+            a = self.dwconv_g(f"{name}.{base}_1", attn, 1, k, 1, 0, kind="dwg_plain")
+            a = self.dwconv_g(f"{name}.{base}_2", a, k, 1, 1, 0, kind="dwg_plain", post=(name + ".dilconv") if i < 3 else None)
+            branches.append(a)
+            g = self.alloc(C, 1, 1)
+            self.ops.append(dict(kind=L.OP_GAP, H=H, W=W, OH=1, OW=1, src0=a, dst=g, name=f"{name}.gap{i}", lane=self._lane))
+            logits.append(self.conv(f"{name}.SE{i + 1}.conv.0", g, C, 1, 1, act=False, plain=True, out_f32=True))
+        mix = self.alloc(C, H, W)
+        self.ops.append(dict(kind=L.OP_MSCA_MIX, H=H, W=W, OH=H, OW=W, dst=mix, box=branches[:3], res=branches[3], cls=logits[:3],
+                             msk=[logits[3]], name=name + ".mix", lane=self._lane))
+        t = self.conv(name + ".conv4", mix, C, 1, 1, act=False, plain=True)
+        out = self.alloc(C, H, W)
+        self.ops.append(dict(kind=L.OP_MUL, H=H, W=W, OH=H, OW=W, src0=t, src1=x, dst=out, name=name + ".mul", lane=self._lane))
+        return out
+
+    def ela(self, name: str, x: T) -> T:
+        """nn/Addmodules/ELA.py:33-101."""
+        assert not x.up and x.C % 16 == 0
+        k = int(abs((math.log(x.C, 2) + 1) / 2))
+        k = k if k % 2 else k + 1
+        key = self._wrec(name, name=name, kind="ela", cout=x.C, cin=1, k=k)
+        self.buf_bytes.append(self.B * (2 * (x.H + x.W) + 2) * x.C * 4)
+        scratch = T(len(self.buf_bytes) - 1, x.C, 0, x.C, 1, 1, False, True)
+        dst = self.alloc(x.C, x.H, x.W)
+        self.ops.append(dict(kind=L.OP_ELA, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=x, dst=dst, res=scratch, ksize=k, wkey=key,
+                             name=name, lane=self._lane))
+        return dst
 
     def sppf(self, name: str, x: T, c2: int) -> T:
         """block.py:3114-3149."""
@@ -346,7 +436,7 @@ class Plan:
             n = max(round(n * depth), 1) if n > 1 else n
             if f != -1:
                 x = outs[f] if isinstance(f, int) else [x if j == -1 else outs[j] for j in f]
-            if m in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA"):
+            if m in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA", "C3k2_gai", "SCDown"):
                 c2 = make_divisible(min(args[0], max_ch) * width, 8)
                 if m == "Conv":
                     k = args[1] if len(args) > 1 else 1
@@ -363,6 +453,13 @@ class Plan:
                     if scale and scale in "mlx":
                         c3k = True
                     y = self.c2f(name, x, c2, n, True, e, "c3k" if c3k else "bottleneck")
+                elif m == "C3k2_gai":  # tasks.py:1038: repeat count inserted, no m/l/x override, `legacy` untouched
+                    c3k = bool(args[1]) if len(args) > 1 else False
+                    e = args[2] if len(args) > 2 else 0.5
+                    y = self.c2f(name, x, c2, n, True, e, "c3k_gai" if c3k else "pmsfa")
+                elif m == "SCDown":
+                    assert isinstance(x, T)
+                    y = self.scdown(name, x, c2, args[1], args[2])
                 elif m == "C2f":
                     shortcut = bool(args[1]) if len(args) > 1 else False
                     y = self.c2f(name, x, c2, n, shortcut, 0.5, "c2f")
@@ -373,13 +470,31 @@ class Plan:
                     assert isinstance(x, T)
                     y = self.c2psa(name, x, c2, n)
                 cout = c2
+            elif m == "MSCAAttention":  # tasks.py:1052-1054
+                assert isinstance(x, T)
+                y = self.msca(name, x)
+                cout = x.C
+            elif m == "ELA":  # tasks.py:1066-1070: built on the input's channels
+                assert isinstance(x, T)
+                y = self.ela(name, x)
+                cout = x.C
             elif m == "nn.Upsample":
                 assert isinstance(x, T) and not x.up and args[1] == 2 and args[2] == "nearest"
                 y = T(x.buf, x.ld, x.coff, x.C, x.H * 2, x.W * 2, True)
                 cout = x.C
             elif m == "Concat":
-                assert isinstance(x, list) and len(x) == 2 and all(isinstance(t, T) for t in x), \
-                    "only two-operand Concat feeding a conv is accelerated"
+                assert isinstance(x, list) and len(x) == 2, "only two-operand Concat feeding a conv is accelerated"
+                # an operand that is itself a (lazy) Concat -- BS-YOLO's layer 21 reads layer 13 -- is materialised once
+                for j, t in enumerate(x):
+                    if isinstance(t, list):
+                        assert all(isinstance(u, T) for u in t)
+                        real = self.alloc(sum(u.C for u in t), t[0].H, t[0].W)
+                        c0 = 0
+                        for u in t:
+                            self.copy(f"{name}.cat{j}", u, real.slice(c0, u.C))
+                            c0 += u.C
+                        x[j] = real
+                assert all(isinstance(t, T) for t in x)
                 y = list(x)
                 cout = sum(t.C for t in x)
             elif m in ("Detect", "Segment"):
@@ -451,6 +566,9 @@ class Plan:
                 assert w.w_off >= 0, "pack weights before serialising"
                 o.w2_off, o.b2_off = w.w_off, w.b_off
             o.mid_c = d.get("mid_c", 0)
+            if d["kind"] == L.OP_ELA:
+                cf = self.wrecs[d["wkey"]].coef
+                d = dict(d, scale=cf[0], lvl_stride=[cf[1], cf[2]])
             o.heads, o.key_dim, o.head_dim, o.scale = d.get("heads", 0), d.get("key_dim", 0), d.get("head_dim", 0), \
                 d.get("scale", 0.0)
             o.nl, o.nc, o.nm, o.A = d.get("nl", 0), d.get("nc", 0), d.get("nm", 0), d.get("A", 0)

@@ -46,7 +46,15 @@ def _align(n: int, a: int = 256) -> int:
 
 def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
     """-> (weight bytes, bias bytes) for one op."""
-    if r.kind == "plain":
+    if r.kind == "ela":
+        # ELA (nn/Addmodules/ELA.py:36-72): [spatial_conv (C,k)][ch_att.2 (C,k)][gn.weight][gn.bias]; the three scalar mixing
+        # weights enter the op record as their sigmoids
+        c, k = r.cout, r.k
+        wsp, wch = _f32(sd[r.name + ".spatial_conv.weight"]).reshape(c, k), _f32(sd[r.name + ".ch_att.2.weight"]).reshape(c, k)
+        gw, gb = _f32(sd[r.name + ".gn.weight"]), _f32(sd[r.name + ".gn.bias"])
+        r.coef = tuple(float(torch.sigmoid(_f32(sd[r.name + "." + s]).view(-1)[0])) for s in ("ch_weight", "sp_weight", "res_weight"))
+        return torch.cat([wsp.reshape(-1), wch.reshape(-1), gw, gb]).contiguous().numpy().tobytes(), b""
+    if r.kind in ("plain", "dwg_plain"):
         w, b = _f32(sd[r.name + ".weight"]), _f32(sd[r.name + ".bias"])
     elif r.kind == "deconv":
         # nn.ConvTranspose2d(c, c, 2, 2, 0) (block.py:91): out[2i+dy, 2j+dx] = W[:, :, dy, dx]^T x[i, j] + b, i.e. one
@@ -72,6 +80,23 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
         bp = torch.zeros(cp, dtype=torch.float32)
         bp[:cout] = b
         return wp.numpy().tobytes(), bp.numpy().tobytes()
+    if r.kind in ("dwg", "dwg_plain", "dwg_ext"):
+        # generic depthwise (csrc/bsyolo_ops.hip): f32 [kh*kw][C] + bias [C]
+        kh, kw = r.k, r.kw or r.k
+        if r.kind == "dwg_ext":
+            # PMSFA.conv3 (block.py:3042): a depthwise 7x7 over the first half of its input, extended with an identity
+            # kernel (centre tap 1, bias 0, no activation) so the second half passes through untouched
+            half = r.cout // 2
+            assert tuple(w.shape) == (half, 1, kh, kw), (r.name, tuple(w.shape))
+            ident = torch.zeros(r.cout - half, 1, kh, kw)
+            ident[:, 0, kh // 2, kw // 2] = 1.0
+            w, b = torch.cat([w, ident]), torch.cat([b, torch.zeros(r.cout - half)])
+        assert tuple(w.shape) == (r.cout, 1, kh, kw), (r.name, tuple(w.shape), (r.cout, kh, kw))
+        if r.post:  # a following depthwise 1x1 conv (MSCAAttention.dilconv, MSCA.py:31): y -> a*y + d, folded in
+            a, d = _f32(sd[r.post + ".weight"]).view(-1), _f32(sd[r.post + ".bias"])
+            w, b = w * a.view(-1, 1, 1, 1), a * b + d
+        wp = w.view(r.cout, kh * kw).t().contiguous()
+        return wp.numpy().tobytes(), b.contiguous().numpy().tobytes()
     if r.kind == "dw":
         assert tuple(w.shape) == (r.cout, 1, 3, 3), (r.name, tuple(w.shape))
         wp = w.view(r.cout, 9).t().contiguous()
@@ -102,7 +127,7 @@ def adopt_offsets(plan: Plan, packed: Plan) -> None:
     for k, r in plan.wrecs.items():
         src = packed.wrecs[k]
         assert (src.kind, src.cout, src.cin, src.k) == (r.kind, r.cout, r.cin, r.k)
-        r.w_off, r.b_off = src.w_off, src.b_off
+        r.w_off, r.b_off, r.coef = src.w_off, src.b_off, src.coef
 
 
 def synth_state_dict(plan: Plan, seed: int = 0, cls_gain: float = 0.1, cls_bias: float = -4.21) -> Dict[str, torch.Tensor]:
@@ -117,6 +142,31 @@ def synth_state_dict(plan: Plan, seed: int = 0, cls_gain: float = 0.1, cls_bias:
             if r.name + ".weight" not in sd:
                 sd[r.name + ".weight"] = torch.randn(r.cin, r.cout, 2, 2, generator=g) * (2.0 / r.cin) ** 0.5
                 sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) * 0.4 - 0.2
+            continue
+        if r.kind == "ela":
+            for s_ in ("ch_weight", "sp_weight", "res_weight"):
+                sd[f"{r.name}.{s_}"] = torch.randn(1, generator=g)
+            sd[r.name + ".spatial_conv.weight"] = torch.randn(r.cout, 1, r.k, generator=g) * (2.0 / r.k) ** 0.5
+            sd[r.name + ".ch_att.2.weight"] = torch.randn(r.cout, 1, r.k, generator=g) * (2.0 / r.k) ** 0.5
+            sd[r.name + ".gn.weight"] = torch.rand(r.cout, generator=g) * 0.6 + 0.7
+            sd[r.name + ".gn.bias"] = torch.rand(r.cout, generator=g) * 0.6 - 0.3
+            continue
+        if r.kind == "dwg_plain":
+            kh, kw = r.k, r.kw or r.k
+            sd[r.name + ".weight"] = torch.randn(r.cout, 1, kh, kw, generator=g) * (2.0 / (kh * kw)) ** 0.5
+            sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) * 0.4 - 0.2
+            if r.post and r.post + ".weight" not in sd:
+                sd[r.post + ".weight"] = torch.rand(r.cout, 1, 1, 1, generator=g) + 0.5
+                sd[r.post + ".bias"] = torch.rand(r.cout, generator=g) * 0.4 - 0.2
+            continue
+        if r.kind in ("dwg", "dwg_ext"):
+            kh, kw = r.k, r.kw or r.k
+            co = r.cout // 2 if r.kind == "dwg_ext" else r.cout
+            sd[r.name + ".conv.weight"] = torch.randn(co, 1, kh, kw, generator=g) * (2.0 / (kh * kw)) ** 0.5
+            sd[r.name + ".bn.weight"] = torch.rand(co, generator=g) * 0.6 + 0.7
+            sd[r.name + ".bn.bias"] = torch.rand(co, generator=g) * 0.6 - 0.3
+            sd[r.name + ".bn.running_mean"] = torch.rand(co, generator=g) * 0.6 - 0.3
+            sd[r.name + ".bn.running_var"] = torch.rand(co, generator=g) + 0.5
             continue
         if r.kind == "plain":
             fan = r.cin * r.k * r.k

@@ -64,8 +64,21 @@ enum bsy_op_kind {
     BSY_OP_NHWC2NCHW = 7,  /* NHWC f16 view -> BCHW tensor (Segment protos, block.py:80-97 output)            */
     BSY_OP_STEM = 8,       /* layers 0 + 1 fused: image -> Conv 3x3 s2 (3 -> mid_c) -> Conv 3x3 s2 (mid_c -> dst.C);
                             * w_off/b_off = layer 0, w2_off/b2_off = layer 1; the layer-0 map never reaches HBM   */
-    BSY_OP_BNECK = 9       /* Bottleneck(c, c, shortcut, k=(3,3), e=0.5) fused: dst = src0 + cv2(cv1(src0)), hidden
+    BSY_OP_BNECK = 9,      /* Bottleneck(c, c, shortcut, k=(3,3), e=0.5) fused: dst = src0 + cv2(cv1(src0)), hidden
                             * width mid_c; w_off/b_off = cv1, w2_off/b2_off = cv2                                  */
+    /* ---- modules of the BS-YOLO graph (cfg/models/11/yolo11.yaml of the fork; csrc/bsyolo_ops.hip) ---- */
+    BSY_OP_DWCONV_G = 10,  /* depthwise ksize (height) x pad (WIDTH; padding is always k/2) conv, stride 1/2, + bias,
+                            * SiLU on the first `act` channels: PMSFA 5x5/7x7, SCDown.cv2, MSCAAttention strips.  heads = channels of the whole
+                            * weight tensor (row length of the f32 [kh*kw][heads] weights), key_dim = first channel    */
+    BSY_OP_COPY = 11,      /* dst slice <- src0 view (through nearest x2 when up0): materialises a Concat operand      */
+    BSY_OP_GAP = 12,       /* dst (B,1,1,C) f16 <- mean over H x W of src0                                              */
+    BSY_OP_MSCA_MIX = 13,  /* dst = sum_i softmax_i(sigmoid(logit_i)) * branch_i; branches box[0..2] + res, logits (f32
+                            * (B,1,1,C) maps) cls[0..2] + msk[0]   (nn/Addmodules/MSCA.py:69-82)                        */
+    BSY_OP_MUL = 14,       /* dst = src0 * src1 elementwise                                                             */
+    BSY_OP_ELA = 15        /* ELA (nn/Addmodules/ELA.py:77-101): ksize = Conv1d taps; w_off -> f32 blob [spatial_conv C*k]
+                            * [ch_att conv C*k][gn.weight C][gn.bias C]; scale, lvl_stride[0], lvl_stride[1] =
+                            * sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight);
+                            * res = f32 scratch buffer of (2 (H + W) + 2) * C floats per image                          */
 };
 
 typedef struct bsy_op {
@@ -161,6 +174,18 @@ int bsy_stem_fused_supported(int C0, int C1, int H, int W);
 int bsy_bottleneck_fused(const void* x, int ldx, int B, int H, int W, int C, int CH, const void* w1, const float* b1,
                          const void* w2, const float* b2, void* y, int ldy, int act, bsy_stream stream);
 int bsy_bottleneck_fused_supported(int C, int CH);
+
+/* Modules of the BS-YOLO graph (csrc/bsyolo_ops.hip), NHWC f16 views.
+ * bsy_dwconv: depthwise kh x kw conv (odd sizes <= 31), stride 1 / 2, padding k/2, + bias (+SiLU when act);
+ *   w f32 [kh*kw][wld] offset to the first channel of this call, b f32 [C].
+ * bsy_ela: ELA.forward (nn/Addmodules/ELA.py:77-101); wsp/wch (C,k) Conv1d weights, gnw/gnb GroupNorm affine,
+ *   coef[3] HOST floats = sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight); scratch: device f32,
+ *   bsy_ela_scratch_bytes(B, H, W, C) bytes. */
+int bsy_dwconv(const void* x, int ldx, int B, int H, int W, int C, int kh, int kw, int stride, const float* w, int wld,
+               const float* b, void* y, int ldy, int act, bsy_stream stream);
+size_t bsy_ela_scratch_bytes(int B, int H, int W, int C);
+int bsy_ela(const void* x, int ldx, int B, int H, int W, int C, int k, const float* wsp, const float* wch,
+            const float* gnw, const float* gnb, const float* coef, void* scratch, void* y, int ldy, bsy_stream stream);
 
 /* DWConv (conv.py:224-229) 3x3 s1: w f32 [9][C], b f32 [C]. */
 int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y, int ldy,

@@ -259,6 +259,40 @@ def test_bottleneck_fused_rejects_unsupported():
         O.bottleneck_fused(x, torch.zeros(32, 64, 3, 3), torch.zeros(32), torch.zeros(64, 32, 3, 3), torch.zeros(64))
 
 
+@pytest.mark.parametrize("kh,kw,stride,act", [(5, 5, 1, True), (7, 7, 1, True), (3, 3, 2, False), (1, 21, 1, False),
+                                              (21, 1, 1, False), (1, 5, 1, False), (11, 1, 1, False)])
+def test_dwconv_generic_matches_oracle(kh, kw, stride, act):
+    """Depthwise kh x kw conv (PMSFA 5x5 / 7x7, block.py:3040-3042; SCDown.cv2, block.py:4529; MSCAAttention strips,
+    MSCA.py:26-39) on maps smaller than the kernel and with odd extents."""
+    g = torch.Generator().manual_seed(31)
+    x = h16(torch.randn(2, 24, 9, 13, generator=g))
+    w = torch.randn(24, 1, kh, kw, generator=g) * (1.0 / (kh * kw)) ** 0.5
+    b = torch.randn(24, generator=g) * 0.2
+    ref = F.conv2d(x, w, b, stride, (kh // 2, kw // 2), 1, 24)
+    if act:
+        ref = F.silu(ref)
+    out = O.dwconv_nhwc(nhwc(x).half().to(DEV), w, b, stride, act)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("tag", ["ela64", "ela256"])
+def test_ela_matches_reference_golden(tag):
+    """ELA (nn/Addmodules/ELA.py:33-101) through bsy_ela against the fork's own module output (modules_bsyolo.npz)."""
+    z = np.load(GOLDEN / "modules_bsyolo.npz", allow_pickle=False)
+    cases = json.loads(str(z["cases"]))
+    mod = R.ELA("m", cases[tag][1])
+    P = {n: R.synth_param(n, s, 9) for n, s in mod.specs()}
+    x = torch.from_numpy(z[tag + ".x"])
+    coef = [torch.sigmoid(P[f"m.{k}"]).item() for k in ("ch_weight", "sp_weight", "res_weight")]
+    out = O.ela_nhwc(nhwc(h16(x)).half().to(DEV), P["m.spatial_conv.weight"], P["m.ch_att.2.weight"], P["m.gn.weight"],
+                     P["m.gn.bias"], coef)
+    torch.cuda.synchronize()
+    got = nchw(out.float().cpu()).numpy()
+    ref = z[tag + ".y"]
+    assert np.abs(got - ref).max() < 4e-3 * max(1.0, np.abs(ref).max())  # fp16 input / output rounding only
+
+
 @pytest.mark.parametrize("act,use_res", [(True, False), (False, True)])
 def test_dwconv_matches_oracle(act, use_res):
     g = torch.Generator().manual_seed(5)
@@ -353,7 +387,7 @@ def _engine_vs_oracle(tag, dtype):
 
 
 @pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
-                                 "yolov8n_segment"])
+                                 "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_engine_matches_reference_golden(tag, dtype):
     """Whole graph through the engine vs (a) the REFERENCE's own fp32 CPU outputs (golden) and (b) the oracle run
@@ -364,13 +398,18 @@ def test_engine_matches_reference_golden(tag, dtype):
     few anchors (measured: max 3.8e-3, mean <= 1.9e-5).  (a) adds the fp16 storage error itself, which a pure-CPU fp16
     emulation shows too (4.1e-3 on the 96x160 case): measured max 5.8e-3 / mean 2.7e-5 on scores, 0.49 px on boxes.
     Box error scales with stride x DFL-bin error (not with image size): 0.5 px = 7.8e-4 of a 640 image."""
+    # The BS-YOLO graph (MSCA / ELA gates, nc = 12, these random weights) is more sensitive to fp16 storage: the pure-CPU
+    # fp16-storage emulation of the oracle already differs from the fp32 reference by 1.31 px max / 0.074 px mean on boxes
+    # and 1.5e-4 mean on scores (stock graphs: 0.41 px / 0.02 px / 2.5e-5), so its bounds are 3x wider.  Per-layer outputs
+    # agree with the reference to ~1e-3 of each layer's range in both families (tools/gpu_explore.py layers).
+    k = 3.0 if tag.startswith("bsyolo") else 1.0
     for y, yref, yq, raws, rawref, nc in _engine_vs_oracle(tag, dtype):
         es, eb = np.abs(y[:, 4:4 + nc] - yref[:, 4:4 + nc]), np.abs(y[:, :4] - yref[:, :4])
-        assert es.max() < 1e-2 and es.mean() < 1e-4, (es.max(), es.mean())
-        assert eb.max() < 1.0 and eb.mean() < 0.05, (eb.max(), eb.mean())
+        assert es.max() < k * 1e-2 and es.mean() < k * 1e-4, (es.max(), es.mean())
+        assert eb.max() < k * 1.0 and eb.mean() < k * 0.05, (eb.max(), eb.mean())
         qs, qb = np.abs(y[:, 4:4 + nc] - yq[:, 4:4 + nc]), np.abs(y[:, :4] - yq[:, :4])
-        assert qs.max() < 1e-2 and qs.mean() < 5e-5, (qs.max(), qs.mean())
-        assert qb.max() < 1.0 and qb.mean() < 0.03, (qb.max(), qb.mean())
+        assert qs.max() < k * 1e-2 and qs.mean() < k * 5e-5, (qs.max(), qs.mean())
+        assert qb.max() < k * 1.0 and qb.mean() < k * 0.03, (qb.max(), qb.mean())
         if y.shape[1] > 4 + nc:  # mask coefficients (raw conv outputs, O(1..10) magnitude)
             em = np.abs(y[:, 4 + nc:] - yref[:, 4 + nc:])
             assert em.max() < 2e-2 * np.abs(yref[:, 4 + nc:]).max(), em.max()

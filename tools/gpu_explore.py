@@ -71,10 +71,10 @@ def per_layer(tag="yolo11n_detect"):
     eng.close()
 
 
-def timing(scale="s", B=64, S=640, dt=torch.float16):
+def timing(scale="s", B=64, S=640, dt=torch.float16, family="yolo11"):
     from bs_yolo_amd.plan import Plan
     from bs_yolo_amd.weights import synth_state_dict
-    cfg = stock_cfg("yolo11", scale)
+    cfg = stock_cfg(family, scale, 12 if family == "bsyolo11" else 80)
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), 0)
     eng = YoloEngine(cfg, sd)
     x = torch.rand(B, 3, S, S, device=DEV).to(dt)
@@ -88,7 +88,7 @@ def timing(scale="s", B=64, S=640, dt=torch.float16):
     torch.cuda.synchronize()
     dtm = (time.perf_counter() - t0) / n
     plan, _ = eng.plan_for(B, S, S, dt, dt)
-    print(f"yolo11{scale} B={B} {S}x{S}: {dtm * 1e3:.3f} ms/batch  {B / dtm:.0f} img/s  {plan.flops / dtm / 1e12:.1f} TFLOP/s")
+    print(f"{family}{scale} B={B} {S}x{S}: {dtm * 1e3:.3f} ms/batch  {B / dtm:.0f} img/s  {plan.flops / dtm / 1e12:.1f} TFLOP/s")
     ops, plan = eng.profile(x)
     ops2, _ = eng.profile(x)
     tot = sum(t for _, _, t in ops2)
@@ -126,7 +126,7 @@ def timing(scale="s", B=64, S=640, dt=torch.float16):
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("layers", "all"):
-        per_layer("yolo11n_detect")
-        per_layer("yolo11s_detect")
+        for tag in (sys.argv[2:] or ["yolo11n_detect", "yolo11s_detect"]):
+            per_layer(tag)
     if what in ("time", "all"):
-        timing("s", int(sys.argv[2]) if len(sys.argv) > 2 else 64, 640)
+        timing("s", int(sys.argv[2]) if len(sys.argv) > 2 else 64, 640, family=sys.argv[3] if len(sys.argv) > 3 else "yolo11")
