@@ -80,6 +80,73 @@ __global__ __launch_bounds__(256) void dwconv_generic_kernel(const half_t* __res
     *reinterpret_cast<half8*>(dst + ((size_t)(n * OH + oy) * OW + ox) * ldd + c) = o;
 }
 
+// Same conv, 4 consecutive outputs per thread along x with the input row segment they share held in registers: a row
+// costs 3*S + KW loads and KW weight fetches instead of 4*KW of each.  KW / stride are compile-time so the window is a
+// register array; instantiated for the kernel widths the BS-YOLO graph uses (1, 3 s2, 5, 7, 11, 21).
+#define DWG_PX 4
+template <int KW, int S>
+__global__ __launch_bounds__(256) void dwconv_win_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W, int C,
+                                                         int OH, int OW, int kh, const float* __restrict__ w, int wld,
+                                                         const float* __restrict__ bias, half_t* __restrict__ dst, int ldd,
+                                                         int act_c, unsigned span) {
+    constexpr int NWIN = (DWG_PX - 1) * S + KW;
+    const int C8 = C >> 3, OWG = (OW + DWG_PX - 1) / DWG_PX;
+    const long long total = (long long)B * OH * OWG * C8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C8) * 8;
+    long long t = idx / C8;
+    const int ox0 = (int)(t % OWG) * DWG_PX;
+    t /= OWG;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const bo_rsrc_t rs = bo_make_rsrc(src, span);
+    float acc[DWG_PX][8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c), b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);
+#pragma unroll
+        for (int p = 0; p < DWG_PX; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[p][j] = b0[j]; acc[p][4 + j] = b1[j]; }
+    }
+    const int iy0 = oy * S - kh / 2, ix0 = ox0 * S - KW / 2;
+    unsigned coloff[NWIN];
+#pragma unroll
+    for (int q = 0; q < NWIN; ++q) {
+        const int ix = ix0 + q;
+        coloff[q] = (unsigned)ix < (unsigned)W ? 2u * ((unsigned)ix * (unsigned)lds_ + (unsigned)c) : BO_OOB;
+    }
+    const unsigned rowbytes = 2u * (unsigned)W * (unsigned)lds_;
+    for (int dy = 0; dy < kh; ++dy) {
+        const int iy = iy0 + dy;
+        const bool rowok = (unsigned)iy < (unsigned)H;
+        const unsigned rb = (unsigned)(n * H + iy) * rowbytes;
+        half8 win[NWIN];
+#pragma unroll
+        for (int q = 0; q < NWIN; ++q) win[q] = bo_load16(rs, (rowok && coloff[q] != BO_OOB) ? rb + coloff[q] : BO_OOB);
+#pragma unroll
+        for (int dx = 0; dx < KW; ++dx) {
+            const float* wp = w + (size_t)(dy * KW + dx) * wld + c;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+            for (int p = 0; p < DWG_PX; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[p][j] = fmaf((float)win[p * S + dx][j], w0[j], acc[p][j]);
+                    acc[p][4 + j] = fmaf((float)win[p * S + dx][4 + j], w1[j], acc[p][4 + j]);
+                }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < DWG_PX; ++p) {
+        if (ox0 + p >= OW) break;
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(c + j < act_c ? silu_f(acc[p][j]) : acc[p][j]);
+        *reinterpret_cast<half8*>(dst + ((size_t)(n * OH + oy) * OW + ox0 + p) * ldd + c) = o;
+    }
+}
+
 int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s) {
     if (!a.src || !a.dst || !a.w || !a.b) BSY_FAIL(BSY_ERR_ARG, "dwconv: null pointer");
     if ((a.C & 7) || (a.lds & 7) || (a.ldd & 7) || (a.wld & 3) || ((uintptr_t)a.src & 15) || ((uintptr_t)a.dst & 15) ||
@@ -94,8 +161,20 @@ int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s) {
     const unsigned span = (unsigned)((((long long)a.B * a.H * a.W - 1) * a.lds + a.C) * 2);
     const long long total = (long long)a.B * OH * OW * (a.C / 8);
     if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "dwconv: empty");
-    hipLaunchKernelGGL(dwconv_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H,
-                       a.W, a.C, OH, OW, a.kh, a.kw, a.stride, a.w, a.wld, a.b, a.dst, a.ldd, a.act_c, span);
+    const long long totw = (long long)a.B * OH * ((OW + DWG_PX - 1) / DWG_PX) * (a.C / 8);
+#define DWG_WIN(KW_, S_)                                                                                                     \
+    hipLaunchKernelGGL((dwconv_win_kernel<KW_, S_>), dim3((unsigned)((totw + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, \
+                       a.H, a.W, a.C, OH, OW, a.kh, a.w, a.wld, a.b, a.dst, a.ldd, a.act_c, span)
+    if (a.kw == 1 && a.stride == 1) DWG_WIN(1, 1);
+    else if (a.kw == 3 && a.stride == 2) DWG_WIN(3, 2);
+    else if (a.kw == 5 && a.stride == 1) DWG_WIN(5, 1);
+    else if (a.kw == 7 && a.stride == 1) DWG_WIN(7, 1);
+    else if (a.kw == 11 && a.stride == 1) DWG_WIN(11, 1);
+    else if (a.kw == 21 && a.stride == 1) DWG_WIN(21, 1);
+    else
+        hipLaunchKernelGGL(dwconv_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H,
+                           a.W, a.C, OH, OW, a.kh, a.kw, a.stride, a.w, a.wld, a.b, a.dst, a.ldd, a.act_c, span);
+#undef DWG_WIN
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
@@ -242,50 +321,46 @@ int launch_mul(const half_t* a, int lda, const half_t* b, int ldb, long long npi
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ELA.  scratch (f32) per image: [rowmean H*C][colmean W*C][gmean C][hgate H*C][wgate W*C][cgate C]
-//   ela_stats : row means (over W), column means (over H), global mean.  One workgroup per (image, 8-channel chunk).
+//   ela_stats : row means (over W) and column means (over H).  One workgroup per (row | column, image).
 //   ela_gate  : v = dilated (2) depthwise conv1d of the means (k taps, zero pad k-1) -> GroupNorm over (16 channels x L)
-//               -> sigmoid; plus the channel gate sigmoid(w_centre * gmean).  One workgroup per (image, group, direction).
+//               -> sigmoid; plus the channel gate sigmoid(w_centre * global mean).  One workgroup per (image, group, direction).
 //   ela_apply : out = x * (a * cgate[c] + b * hgate[y, c] * wgate[x, c]) + r * x
 // ---------------------------------------------------------------------------------------------------------------------
+// grid (max(H, W), B, 2): z = 0 -> workgroup = one row (mean over W), z = 1 -> one column (mean over H).  Threads cover
+// (position along the line, 8-channel chunk): `nslot` positions in flight per chunk, then a serial fold over the slots.
 __global__ __launch_bounds__(256) void ela_stats_kernel(const half_t* __restrict__ src, int lds_, int H, int W, int C,
                                                         float* __restrict__ scratch, size_t per_img) {
-    const int c = blockIdx.x * 8, n = blockIdx.y, tid = threadIdx.x;
-    float* row = scratch + (size_t)n * per_img;
-    float* col = row + (size_t)H * C;
-    float* gm = col + (size_t)W * C;
-    const half_t* ip = src + (size_t)n * H * W * lds_ + c;
+    const int line = blockIdx.x, n = blockIdx.y, dir = blockIdx.z, tid = threadIdx.x;
+    const int L = dir ? W : H, R = dir ? H : W;  // lines of this direction, positions per line
+    if (line >= L) return;
+    const int C8 = C >> 3;
+    const int nslot = 256 / C8 > 0 ? 256 / C8 : 1;
+    float* out = scratch + (size_t)n * per_img + (dir ? (size_t)H * C : 0) + (size_t)line * C;
+    const half_t* ip = src + (size_t)n * H * W * lds_;
+    const size_t lstep = dir ? (size_t)W * lds_ : (size_t)lds_;             // step between positions of a line
+    const size_t lbase = dir ? (size_t)line * lds_ : (size_t)line * W * lds_;
     __shared__ float part[256][8];
-    float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int y = tid; y < H; y += 256) {  // row means: thread per row
+    {
+        const int c8 = tid % C8, slot = tid / C8;  // threads past nslot * C8 (256 not a multiple of C8) contribute zeros
         float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int x = 0; x < W; ++x) {
-            const half8 v = *reinterpret_cast<const half8*>(ip + ((size_t)y * W + x) * lds_);
+        if (slot < nslot)
+            for (int r = slot; r < R; r += nslot) {
+                const half8 v = *reinterpret_cast<const half8*>(ip + lbase + (size_t)r * lstep + c8 * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
-        }
+                for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+            }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { row[(size_t)y * C + c + j] = a[j] / (float)W; tot[j] += a[j]; }
+        for (int j = 0; j < 8; ++j) part[tid][j] = a[j];
     }
-    for (int x = tid; x < W; x += 256) {  // column means: thread per column
-        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int y = 0; y < H; ++y) {
-            const half8 v = *reinterpret_cast<const half8*>(ip + ((size_t)y * W + x) * lds_);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) col[(size_t)x * C + c + j] = a[j] / (float)H;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) part[tid][j] = tot[j];
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (tid < st)
+    if (tid < C8) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int sl = 0; sl < nslot; ++sl)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part[tid][j] += part[tid + st][j];
-        __syncthreads();
+            for (int j = 0; j < 8; ++j) a[j] += part[sl * C8 + tid][j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[tid * 8 + j] = a[j] / (float)R;
     }
-    if (tid < 8) gm[c + tid] = part[0][tid] / (float)(H * W);
 }
 
 // grid (groups, B, 2): z = 0 rows (L = H), 1 columns (L = W).  LDS: conv output of the group [L][16].
@@ -330,7 +405,9 @@ __global__ __launch_bounds__(256) void ela_gate_kernel(float* __restrict__ scrat
     }
     if (dir == 0 && tid < gsz) {  // channel gate: the Conv1d sees a length-1 sequence -> only its centre tap contributes
         const int c = c0 + tid;
-        const float gmv = base[(size_t)(H + W) * C + c];
+        float gmv = 0.f;  // global mean = mean of the row means (rows have equal length)
+        for (int l = 0; l < H; ++l) gmv += base[(size_t)l * C + c];
+        gmv /= (float)H;
         base[(size_t)(2 * (H + W) + 1) * C + c] = 1.0f / (1.0f + __expf(-(wch[(size_t)c * k + (k - 1) / 2] * gmv)));
     }
 }
@@ -376,7 +453,8 @@ int launch_ela(const ElaArgs& a, hipStream_t s) {
     const int Lmax = a.H > a.W ? a.H : a.W;
     const size_t lds = ((size_t)Lmax * gsz + 512) * sizeof(float);
     if (lds > 64 * 1024) BSY_FAIL(BSY_ERR_ARG, "ela: map side %d too long for the gate kernel", Lmax);
-    hipLaunchKernelGGL(ela_stats_kernel, dim3(a.C / 8, a.B), dim3(256), 0, s, a.src, a.lds, a.H, a.W, a.C, a.scratch, per_img);
+    if (a.C / 8 > 256) BSY_FAIL(BSY_ERR_ARG, "ela: more than 2048 channels");
+    hipLaunchKernelGGL(ela_stats_kernel, dim3(Lmax, a.B, 2), dim3(256), 0, s, a.src, a.lds, a.H, a.W, a.C, a.scratch, per_img);
     hipLaunchKernelGGL(ela_gate_kernel, dim3(groups, a.B, 2), dim3(256), lds, s, a.scratch, per_img, a.H, a.W, a.C, a.k, gsz, a.wsp,
                        a.wch, a.gnw, a.gnb);
     const long long total = (long long)a.B * a.H * a.W * (a.C / 8);
