@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", default="s")
+    ap.add_argument("--family", default="yolo11", choices=["yolo11", "yolov8", "bsyolo11"],
+                    help="graph: stock YOLO11 (the headline config), YOLOv8, or the fork's own BS-YOLO graph (nc = 12)")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -43,11 +45,14 @@ def parse():
     return ap.parse_args()
 
 
+NAMES = {"yolo11": "YOLO11", "yolov8": "YOLOv8", "bsyolo11": "BS-YOLO11"}
+
+
 def cpu_baseline(args, cfg_sd):
     """The oracle (torch-CPU fp32 restatement of the reference path, oracle/) timed on this host: forward + NMS."""
     from oracle import postproc_ref as PP
     from oracle import yolo_ref as R
-    m = R.Model("yolo11", args.scale, 80, "detect")
+    m = R.Model(args.family, args.scale, 12 if args.family == "bsyolo11" else 80, "detect")
     P = {k: v.float() for k, v in cfg_sd.items()}
     P[f"model.{len(m.layers) - 1}.dfl.conv.weight"] = torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)
     x = torch.rand(args.cpu_batch, 3, args.imgsz, args.imgsz, generator=torch.Generator().manual_seed(0))
@@ -63,7 +68,7 @@ def cpu_baseline(args, cfg_sd):
         dt = time.perf_counter() - t0
     return {"value": round(args.cpu_batch * args.cpu_runs / dt, 3), "unit": "images/sec", "cores": cores,
             "kind": "port",
-            "sample": f"{args.cpu_runs} x batch {args.cpu_batch} YOLO11{args.scale} {args.imgsz}x{args.imgsz} fp32 "
+            "sample": f"{args.cpu_runs} x batch {args.cpu_batch} {NAMES[args.family]}{args.scale} {args.imgsz}x{args.imgsz} fp32 "
                       f"forward + NMS, torch CPU {cores} threads, after 1 warm-up ({dt:.1f} s)"}
 
 
@@ -95,7 +100,7 @@ def main():
     from bs_yolo_amd.plan import Plan
     from bs_yolo_amd.weights import synth_state_dict
 
-    cfg = stock_cfg("yolo11", args.scale, 80, "detect")
+    cfg = stock_cfg(args.family, args.scale, 12 if args.family == "bsyolo11" else 80, "detect")
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
     eng = YoloEngine(cfg, sd, device=local)
     B, S = args.batch, args.imgsz
@@ -162,14 +167,14 @@ def main():
         # passes, gfx950 correction), per launch like `achieved`; only valid for the default workload
         traffic = None
         tfile = ROOT / "profiles" / "r01_traffic.json"
-        if tfile.exists() and args.scale == "s" and S == 640 and B == 64:
+        if tfile.exists() and args.family == "yolo11" and args.scale == "s" and S == 640 and B == 64:
             traffic = round(json.load(open(tfile))["conv_mfma_hbm_bytes_per_launch_avg"])
         fwd_ms = sum(t for (_, _, t) in prof)
         out = {
-            "metric": "images/sec YOLO11s 640x640 bs=64 (forward + NMS)", "value": round(value, 1), "unit": "images/sec",
+            "metric": f"images/sec {NAMES[args.family]}{args.scale} {S}x{S} bs={B} (forward + NMS)", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"YOLO11{args.scale} detect {S}x{S} fp16, batch {B} per GPU, seeded random weights, "
+            "config": {"workload": f"{NAMES[args.family]}{args.scale} detect {S}x{S} fp16, batch {B} per GPU, seeded random weights, "
                                    f"engine forward + HIP NMS (conf 0.25, iou 0.7, max_det 300)"
                                    + (" + RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": world * B, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",

@@ -1,7 +1,7 @@
 """Stock model descriptions in the reference's yaml-dict schema (what ``model.yaml`` holds on a live reference model).
 
-The reference ships these graphs as cfg/models/11/yolo11-seg.yaml:15-47 (stock YOLO11 backbone+neck; note that
-cfg/models/11/yolo11.yaml is the modified BS-YOLO graph) and cfg/models/v8/yolov8-seg.yaml:15-46.  They are
+The reference ships these graphs as cfg/models/11/yolo11-seg.yaml:15-47 (stock YOLO11 backbone+neck),
+cfg/models/v8/yolov8-seg.yaml:15-46 and cfg/models/11/yolo11.yaml:15-52 (the modified BS-YOLO graph, family "bsyolo11").  They are
 restated here as data so the engine can be built where the reference is not installed (benchmarks, GPU box).
 """
 from __future__ import annotations

@@ -227,7 +227,9 @@ class Plan:
         SiLU only on the q1 half) -> S = [conv3(q1) | q2]; conv4 reads the virtual concat [S | p2] = the reference's
         cat([conv3_out, conv2_out_2, conv1_out_2]) and adds x."""
         c = x.C
-        assert dst.C == c and c % 16 == 0, "PMSFA width must be a multiple of 16 (8-channel pieces of its halves)"
+        assert dst.C == c
+        if c % 16:
+            raise NotImplementedError(f"PMSFA width {c}: must be a multiple of 16 (8-channel pieces of its halves)")
         P = self.conv(name + ".conv1", x, c, 3, 1)
         Q = self.dwconv_g(name + ".conv2", P.slice(0, c // 2), 5, 5, 1, c // 2)
         S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, c // 4, kind="dwg_ext")
@@ -274,7 +276,9 @@ class Plan:
 
     def ela(self, name: str, x: T) -> T:
         """nn/Addmodules/ELA.py:33-101."""
-        assert not x.up and x.C % 16 == 0
+        assert not x.up
+        if x.C % 16:
+            raise NotImplementedError(f"ELA on {x.C} channels: must be a multiple of 16 (GroupNorm groups of 16)")
         k = int(abs((math.log(x.C, 2) + 1) / 2))
         k = k if k % 2 else k + 1
         key = self._wrec(name, name=name, kind="ela", cout=x.C, cin=1, k=k)
