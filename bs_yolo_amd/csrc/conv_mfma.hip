@@ -325,11 +325,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvK& p, f32x16 (&acc)[
                 const int c = cl + 8 * g + 4 * lh;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
                 half4 o;
+                f32x4 t = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                if (p.act) t = silu4_f(t);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[a][b][4 * g + e] + bv[e];
-                    o[e] = (half_t)(p.act ? silu_f(t) : t);
-                }
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)t[e];
                 *reinterpret_cast<half4*>(stile + prow * LDT + c) = o;
             }
         }
@@ -782,10 +781,11 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
                         const int c = cl + 8 * g + 4 * lh;
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + n0 + c);
                         half4 o;
+                        f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                        if (p.act) tv = silu4_f(tv);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float tv = acc[a][b][4 * g + e] + bv[e];
-                            o[e] = (half_t)(p.act ? silu_f(tv) : tv);
+                            o[e] = (half_t)tv[e];
                             acc[a][b][4 * g + e] = 0.f;
                         }
                         *reinterpret_cast<half4*>(otile + prow * LDT + c) = o;
@@ -996,11 +996,10 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
                 const int c = cl + 8 * g + 4 * lh;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
                 half4 o;
+                f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                if (p.act) tv = silu4_f(tv);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float tv = acc[a][b][4 * g + e] + bv[e];
-                    o[e] = (half_t)(p.act ? silu_f(tv) : tv);
-                }
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)tv[e];
                 *reinterpret_cast<half4*>(smem + prow * LDT + c) = o;
             }
         }
