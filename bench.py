@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how `roofline` a
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -106,6 +107,19 @@ def main():
     B, S = args.batch, args.imgsz
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(B, 3, S, S, generator=g).half().to(dev)
+    if not (args.family == "yolo11" and args.scale == "s"):
+        # The class-head bias of synth_state_dict is calibrated for the headline graph (1.5 % of the anchors above
+        # conf 0.25).  Other graphs: shift it so that the same share passes (1-2 %), else NMS sees either
+        # nothing or max_det-saturated images.  One probe forward on 8 images, one rebuild.
+        yp, _ = eng(x[:8], want_raw=False)
+        top = yp[:, 4:].float().amax(1).flatten()
+        sq = torch.quantile(top.cpu(), 1.0 - 0.015).clamp(1e-6, 1 - 1e-6).item()
+        shift = math.log(0.25 / 0.75) - math.log(sq / (1.0 - sq))
+        for k in sd:
+            if ".cv3." in k and k.endswith(".2.bias"):
+                sd[k] = sd[k] + shift
+        eng.close()
+        eng = YoloEngine(cfg, sd, device=local)
     gathered = None
 
     def step():
