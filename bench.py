@@ -108,16 +108,19 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(B, 3, S, S, generator=g).half().to(dev)
     if not (args.family == "yolo11" and args.scale == "s"):
-        # The class-head bias of synth_state_dict is calibrated for the headline graph (1.5 % of the anchors above
-        # conf 0.25).  Other graphs: shift it so that the same share passes (1-2 %), else NMS sees either
-        # nothing or max_det-saturated images.  One probe forward on 8 images, one rebuild.
-        yp, _ = eng(x[:8], want_raw=False)
-        top = yp[:, 4:].float().amax(1).flatten()
-        sq = torch.quantile(top.cpu(), 1.0 - 0.015).clamp(1e-6, 1 - 1e-6).item()
-        shift = math.log(0.25 / 0.75) - math.log(sq / (1.0 - sq))
-        for k in sd:
-            if ".cv3." in k and k.endswith(".2.bias"):
-                sd[k] = sd[k] + shift
+        # The class head of synth_state_dict is calibrated for the headline graph (1.5 % of the anchors above conf 0.25).
+        # Other graphs: rescale and shift it from the raw class logits of one probe forward (8 images) so that the same
+        # share passes (1-2 %) -- else NMS sees either nothing or max_det-saturated images.
+        _, raws = eng(x[:8], want_raw=True)
+        bias0 = float(next(v for k, v in sd.items() if ".cv3." in k and k.endswith(".2.bias")).flatten()[0])
+        lc = torch.cat([r[:, 64:].float().flatten(2) for r in raws], 2) - bias0          # centred logits (8, nc, A)
+        gain = 1.0 / max(float(lc.std()), 1e-6)
+        q = float(torch.quantile((lc * gain).amax(1).flatten().cpu(), 1.0 - 0.015))
+        for k in list(sd):
+            if ".cv3." in k and k.endswith(".2.weight"):
+                sd[k] = sd[k] * gain
+            elif ".cv3." in k and k.endswith(".2.bias"):
+                sd[k] = torch.full_like(sd[k], math.log(0.25 / 0.75) - q)
         eng.close()
         eng = YoloEngine(cfg, sd, device=local)
     gathered = None

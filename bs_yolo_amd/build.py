@@ -28,6 +28,7 @@ SOURCES = {
     "nms.hip": ["-ffp-contract=off"],
     "letterbox.hip": ["-ffp-contract=off"],
     "masks.hip": ["-ffp-contract=off"],
+    "val_match.hip": ["-ffp-contract=off"],
     "engine.hip": [],
 }
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_destroy",
     "bsy_plan_run", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_conv2d", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_dwconv", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
     "bsy_sppf_pool", "bsy_attention", "bsy_detect_decode", "bsy_nms_workspace_bytes", "bsy_nms", "bsy_scale_boxes",
-    "bsy_letterbox", "bsy_process_mask", "bsy_last_error", "bsy_version",
+    "bsy_letterbox", "bsy_process_mask", "bsy_val_match", "bsy_last_error", "bsy_version",
 ]
 
 
@@ -91,6 +91,7 @@ def _load() -> C.CDLL:
     lib.bsy_conv_first.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.bsy_stem_fused.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, vp]
     lib.bsy_stem_fused_supported.argtypes = [i32, i32, i32, i32]
+    lib.bsy_val_match.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_float), i32, vp, vp]
     lib.bsy_bottleneck_fused.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.bsy_bottleneck_fused_supported.argtypes = [i32, i32]
     lib.bsy_dwconv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp]

@@ -11,6 +11,8 @@ Three hooks, each using an extension point the reference already has (see INTEGR
   install_nms(ops_module)  ``ultralytics.utils.ops.non_max_suppression`` is looked up as a module attribute on every
                            call (models/yolo/detect/predict.py:25, detect/val.py:95): replacing the attribute suffices.
   install_masks(ops_module) same for ``ultralytics.utils.ops.process_mask`` (models/yolo/segment/predict.py:53).
+  install_val_metrics(v)   rebinds ``DetectionValidator._process_batch`` (models/yolo/detect/val.py:209-228) on a validator
+                           instance: true-positive matching on the device.
   install_preprocess(p)    rebinds ``BasePredictor.preprocess`` (engine/predictor.py:116-134) on a predictor instance so
                            lists of HWC BGR uint8 images are letterboxed on the device.
 """
@@ -127,6 +129,21 @@ def install_masks(ops_module):
     process_mask._bsy_orig = orig
     ops_module.process_mask = process_mask
     return process_mask
+
+
+def install_val_metrics(validator):
+    """validator = a DetectionValidator instance: its per-image `_process_batch` (models/yolo/detect/val.py:209-228:
+    box_iou + match_predictions, numpy on the host in the reference) goes to the device kernel for CUDA detections."""
+    from . import val as _val
+    orig = validator._process_batch
+
+    def _process_batch(self, detections, gt_bboxes, gt_cls):
+        if not (isinstance(detections, torch.Tensor) and detections.is_cuda) or detections.shape[0] > 1024:
+            return orig(detections, gt_bboxes, gt_cls)
+        return _val.process_batch(detections, gt_bboxes, gt_cls, self.iouv)
+
+    validator._process_batch = types.MethodType(_process_batch, validator)
+    return validator
 
 
 def install_preprocess(predictor):

@@ -250,6 +250,15 @@ int bsy_process_mask(const void* protos, int proto_dtype, int nm, int mh, int mw
                      const float* boxes, int ldb, int n, int ih, int iw, int upsample, float* lowres, void* out,
                      int out_dtype, bsy_stream stream);
 
+/* Validator matching (engine/validator.py:222-258 match_predictions on utils/metrics.py:52-70 box_iou, as called by
+ * DetectionValidator._process_batch, models/yolo/detect/val.py:209-228), whole batch at once.
+ * det (B, max_det, row >= 6) f32 rows [x1 y1 x2 y2 conf cls ...] + counts (B): the layout bsy_nms writes;
+ * gt_boxes (B, Lmax, 4) f32 xyxy, gt_cls (B, Lmax) f32, gt_counts (B); iouv: HOST array of n_iou <= 16 thresholds;
+ * out (B, max_det, n_iou) uint8: 1 = true positive at that threshold.  max_det <= 1024, Lmax <= 8192. */
+int bsy_val_match(const float* det, int row, const int32_t* counts, int B, int max_det, const float* gt_boxes,
+                  const float* gt_cls, const int32_t* gt_counts, int Lmax, const float* iouv, int n_iou,
+                  unsigned char* out, bsy_stream stream);
+
 const char* bsy_last_error(void);
 int bsy_version(void);
 

@@ -277,6 +277,48 @@ def bsyolo_module_fixtures():
     print("wrote bsyolo modules", len(cases), "cases")
 
 
+def val_match_fixtures():
+    """Known answers of the validator's matching step: the reference's own box_iou (utils/metrics.py:52-70) and
+    BaseValidator.match_predictions (engine/validator.py:222-258) through DetectionValidator._process_batch
+    (models/yolo/detect/val.py:209-228) on synthetic detections / labels (continuous random boxes: no exact IoU ties)."""
+    from ultralytics.engine.validator import BaseValidator
+    from ultralytics.utils.metrics import box_iou
+    v = object.__new__(BaseValidator)
+    v.iouv = torch.linspace(0.5, 0.95, 10)
+    rng = np.random.default_rng(77)
+    out, cases = {}, []
+    for ci, (nd, nl, ncls, jitter) in enumerate([(40, 12, 3, 4.0), (300, 60, 80, 6.0), (7, 1, 1, 2.0), (1, 9, 2, 3.0), (120, 120, 5, 1.0),
+                                                 (25, 0, 3, 1.0), (0, 5, 3, 1.0), (64, 30, 1, 12.0)]):
+        lab = np.zeros((nl, 4), np.float32)
+        if nl:
+            xy = rng.uniform(0, 560, (nl, 2)); wh = rng.uniform(12, 120, (nl, 2))
+            lab = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        lcls = rng.integers(0, ncls, nl).astype(np.float32)
+        det = np.zeros((nd, 6), np.float32)
+        if nd:
+            if nl:  # most detections are jittered copies of labels (several per label), the rest random
+                src = rng.integers(0, nl, nd)
+                det[:, :4] = lab[src] + rng.normal(0, jitter, (nd, 4)).astype(np.float32)
+                det[:, 5] = np.where(rng.random(nd) < 0.8, lcls[src], rng.integers(0, ncls, nd))
+                rnd = rng.random(nd) < 0.2
+                xy = rng.uniform(0, 560, (nd, 2)); wh = rng.uniform(12, 120, (nd, 2))
+                det[rnd, :4] = np.concatenate([xy, xy + wh], 1).astype(np.float32)[rnd]
+            else:
+                xy = rng.uniform(0, 560, (nd, 2)); wh = rng.uniform(12, 120, (nd, 2))
+                det[:, :4] = np.concatenate([xy, xy + wh], 1)
+                det[:, 5] = rng.integers(0, ncls, nd)
+            det[:, 4] = np.sort(rng.uniform(0.25, 1.0, nd))[::-1]
+        d, l, c = torch.from_numpy(det), torch.from_numpy(lab), torch.from_numpy(lcls)
+        iou = box_iou(l, d[:, :4])
+        correct = v.match_predictions(d[:, 5], c, iou) if nl and nd else torch.zeros(nd, 10, dtype=torch.bool)
+        out[f"c{ci}.det"], out[f"c{ci}.lab"], out[f"c{ci}.lcls"] = det, lab, lcls
+        out[f"c{ci}.iou"], out[f"c{ci}.correct"] = iou.numpy(), correct.numpy()
+        cases.append(ci)
+    out["cases"] = json.dumps(cases)
+    np.savez_compressed(HERE / "val_match.npz", **out)
+    print("wrote val_match", len(cases), "cases")
+
+
 def synth_pred(b, nc, a, nm, seed, peaky, dtype=torch.float32):
     """(B, 4+nc+nm, A) prediction tensor in Detect's output format with duplicated / overlapping boxes."""
     g = torch.Generator().manual_seed(seed)
@@ -378,6 +420,9 @@ def letterbox_fixtures():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "val":  # only the validator-matching vectors
+        val_match_fixtures()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bsyolo":  # only the BS-YOLO graph vectors (added after the stock set)
         graph_fixture("bsyolo11n_detect", "bsyolo11", "n", "detect", [(2, 64, 64), (1, 96, 160)], nc=12, keep_layers=True)
         graph_fixture("bsyolo11s_detect", "bsyolo11", "s", "detect", [(1, 64, 96)], nc=12)
@@ -391,3 +436,4 @@ if __name__ == "__main__":
     module_fixtures()
     nms_fixtures()
     letterbox_fixtures()
+    val_match_fixtures()

@@ -505,6 +505,53 @@ def test_engine_fused_decoder_matches_decode_kernel(dtype):
     plain.close()
 
 
+def test_val_match_golden_and_random():
+    """Validator matching on the device (csrc/val_match.hip) == the reference's own match_predictions on its own box_iou
+    (val_match.npz), case by case and as one padded batch; then random batches against the oracle restatement."""
+    from bs_yolo_amd import val as HV
+    from oracle import val_ref as V
+    z = np.load(GOLDEN / "val_match.npz", allow_pickle=False)
+    iouv = torch.linspace(0.5, 0.95, 10)
+    cases = json.loads(str(z["cases"]))
+    for ci in cases:
+        det, lab, lcls = (torch.from_numpy(z[f"c{ci}.{k}"]) for k in ("det", "lab", "lcls"))
+        got = HV.process_batch(det.to(DEV), lab.to(DEV), lcls.to(DEV), iouv)
+        assert got.shape == (det.shape[0], 10) and (got.cpu().numpy() == z[f"c{ci}.correct"]).all(), ci
+    # all cases as ONE batch (max_det 300, ragged counts)
+    B, md = len(cases), 300
+    Lmax = max(z[f"c{ci}.lab"].shape[0] for ci in cases)
+    detb, cnt = torch.zeros(B, md, 6), torch.zeros(B, dtype=torch.int32)
+    gb, gc, gn = torch.zeros(B, Lmax, 4), torch.zeros(B, Lmax), torch.zeros(B, dtype=torch.int32)
+    for i, ci in enumerate(cases):
+        d, l = z[f"c{ci}.det"], z[f"c{ci}.lab"]
+        detb[i, :len(d)] = torch.from_numpy(d); cnt[i] = len(d)
+        gb[i, :len(l)] = torch.from_numpy(l); gc[i, :len(l)] = torch.from_numpy(z[f"c{ci}.lcls"]); gn[i] = len(l)
+    tp = HV.match_batched(detb.to(DEV), cnt.to(DEV), gb.to(DEV), gc.to(DEV), gn.to(DEV), iouv).cpu().numpy()
+    for i, ci in enumerate(cases):
+        n = int(cnt[i])
+        assert (tp[i, :n] == z[f"c{ci}.correct"]).all() and not tp[i, n:].any(), ci
+    # random batches vs the oracle (continuous boxes: no exact IoU ties)
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        B, md, Lmax = 6, 512, 40
+        detb = torch.zeros(B, md, 6); cnt = torch.from_numpy(rng.integers(0, md + 1, B).astype(np.int32))
+        gn = torch.from_numpy(rng.integers(0, Lmax + 1, B).astype(np.int32))
+        xy = rng.uniform(0, 500, (B, Lmax, 2)); wh = rng.uniform(10, 100, (B, Lmax, 2))
+        gb = torch.from_numpy(np.concatenate([xy, xy + wh], 2).astype(np.float32))
+        gc = torch.from_numpy(rng.integers(0, 4, (B, Lmax)).astype(np.float32))
+        src = rng.integers(0, Lmax, (B, md))
+        boxes = np.take_along_axis(gb.numpy(), src[..., None], 1) + rng.normal(0, 5.0, (B, md, 4)).astype(np.float32)
+        detb[..., :4] = torch.from_numpy(boxes.astype(np.float32))
+        detb[..., 4] = torch.from_numpy(rng.uniform(0.25, 1, (B, md)).astype(np.float32))
+        detb[..., 5] = torch.from_numpy(rng.integers(0, 4, (B, md)).astype(np.float32))
+        tp = HV.match_batched(detb.to(DEV), cnt.to(DEV), gb.to(DEV), gc.to(DEV), gn.to(DEV), iouv).cpu().numpy()
+        for b in range(B):
+            n, m = int(cnt[b]), int(gn[b])
+            ref = V.process_batch(detb[b, :n].numpy(), gb[b, :m].numpy(), gc[b, :m].numpy(), iouv.numpy()) if n and m else \
+                np.zeros((n, 10), bool)
+            assert (tp[b, :n] == ref).all() and not tp[b, n:].any()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # NMS: bit-exact against the oracle (and the reference's golden outputs)
 # ------------------------------------------------------------------------------------------------------------

@@ -114,6 +114,21 @@ def test_bsyolo_modules_match_reference():
         np.testing.assert_allclose(y.numpy(), z[tag + ".y"], err_msg=tag, **TOL)
 
 
+def test_val_match_matches_reference():
+    """oracle/val_ref.py against the reference's own box_iou + BaseValidator.match_predictions (val_match.npz)."""
+    from oracle import val_ref as V
+    z = _load("val_match.npz")
+    iouv = torch.linspace(0.5, 0.95, 10).numpy()
+    for ci in json.loads(str(z["cases"])):
+        det, lab, lcls = z[f"c{ci}.det"], z[f"c{ci}.lab"], z[f"c{ci}.lcls"]
+        if len(det) and len(lab):
+            np.testing.assert_allclose(V.box_iou(lab, det[:, :4]), z[f"c{ci}.iou"], rtol=1e-6, atol=1e-7)
+            got = V.match_predictions(det[:, 5], lcls, z[f"c{ci}.iou"], iouv)
+        else:
+            got = np.zeros((len(det), 10), bool)
+        assert (got == z[f"c{ci}.correct"]).all(), ci
+
+
 def test_fuse_conv_bn_known_answer():
     z = _load("modules.npz")
     c = R.Conv("m", 8, 12, 3, 1)
