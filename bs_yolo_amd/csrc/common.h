@@ -146,6 +146,20 @@ struct ElaArgs {
 size_t ela_scratch_floats(int H, int W, int C);
 int launch_ela(const ElaArgs& a, hipStream_t s);
 
+// Fused DWConv 3x3 (+SiLU) -> Conv 1x1 (+act) (conv_mfma.hip: dwpw_fused_kernel)
+struct DwPwArgs {
+    const half_t* src;
+    int lds;
+    int B, H, W, C;
+    const float *dww, *dwb;  // depthwise f32 [9][C], [C]
+    const void* wgt;         // 1x1 packed f16 [CoutPad][Kpad]
+    const float* bias;
+    half_t* dst;
+    int ldd, Cout, act;
+};
+bool dwpw_fused_supported(int C, int Cout);
+int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s);
+
 struct DwArgs {
     const half_t* src;
     int lds;

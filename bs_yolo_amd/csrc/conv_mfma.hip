@@ -1037,6 +1037,226 @@ static int launch_patch(const ConvK& k, hipStream_t s) {
     return BSY_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused DWConv 3x3 (+BN+SiLU) -> Conv 1x1 (+BN+SiLU): the two-layer units of YOLO11's class branch (head.py:49-57:
+// nn.Sequential(DWConv(x, x, 3), Conv(x, c3, 1))).  Unfused, the depthwise map makes a round trip through HBM and the
+// pair costs two launches (0.12 ms per pair at 80 x 80 x 128, B = 64).  Here, per 8 x 16 output tile and 32-channel chunk:
+//   * the 10 x 18 input patch arrives by LDS-DMA exactly as in the patch kernel above (one chunk ahead);
+//   * the VALU computes the depthwise conv + SiLU of the chunk from the patch (f32, same tap order as dwconv3x3_kernel ->
+//     bit-identical values) and parks it as the [128 px][32 ch] B-operand tile in the layout the MFMA stage reads;
+//   * the MFMAs multiply it with the 1x1 weights of the chunk (DMA ring of 2).
+// The kernel is bound by the depthwise VALU work (9 FMA + SiLU per element) -- the 1x1 conv rides along for free.
+// Depthwise weights [9][C] + bias [C] (f32) sit in LDS for the whole launch (C <= 256).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DwPwK {
+    const half_t* src;
+    int ld0, B, H, W, C;
+    unsigned span0, wspan;
+    const float* dww;   // [9][C]
+    const float* dwb;   // [C]
+    const half_t* wgt;  // packed [CoutPad][Kpad]
+    const float* bias;
+    half_t* dst;
+    int ldd, Cout, Kpad, act, tiles_x, tiles_y, ntn;
+};
+#define DWPW_MAXC 256
+template <int NT>
+__global__ __launch_bounds__(256) void dwpw_fused_kernel(const DwPwK p) {
+    constexpr int TN = 64 * NT, TM = 128;
+    constexpr int PIW = 3, NPI = 12, NPX = 10 * CP_PW;  // patch: 180 entries in 12 DMA wave-instructions
+    constexpr int PBUF = NPI * 16 * 32, WST = TN * 32, PT = TM * 32;
+    constexpr int WIW = TN / 64;
+    constexpr int OTILE = TM * (TN + 8);
+    constexpr int RING = 2 * PBUF + 2 * WST + PT;
+    constexpr int SMEM = (RING > OTILE ? RING : OTILE) + 2 * 10 * DWPW_MAXC;  // + depthwise weights / bias (f32)
+    __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+    half_t* sW = smem + 2 * PBUF;
+    half_t* sPt = sW + 2 * WST;
+    float* sdw = reinterpret_cast<float*>(smem + (RING > OTILE ? RING : OTILE));  // [9][C] then [C]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn_idx = wg % p.ntn;
+    int t = wg / p.ntn;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int n = t / p.tiles_y;
+    const int oy0 = ty * 8, ox0 = tx * CP_TW, n0 = tn_idx * TN;
+    const int C = p.C, nchunks = C >> 5;
+
+    for (int i = tid; i < 10 * C; i += 256) sdw[i] = i < 9 * C ? p.dww[i] : p.dwb[i - 9 * C];
+    const bsy_rsrc_t rs0 = make_rsrc(p.src, p.span0), rsw = make_rsrc(p.wgt, p.wspan);
+    unsigned poff[PIW];
+#pragma unroll
+    for (int i = 0; i < PIW; ++i) {
+        const int q = 16 * (wave + 4 * i) + (lane >> 2);
+        const int pr = q / CP_PW, pc = q - pr * CP_PW;
+        const int y = oy0 - 1 + pr, x = ox0 - 1 + pc;
+        const int chunk = (lane & 3) ^ ((q >> 2) & 3);
+        poff[i] = (q < NPX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                      ? 2u * ((unsigned)((n * p.H + y) * p.W + x) * (unsigned)p.ld0 + 8u * chunk) : BSY_OOB;
+    }
+    unsigned woff[WIW];
+#pragma unroll
+    for (int j = 0; j < WIW; ++j) {
+        const int r = 16 * (4 * j + wave) + (lane >> 2);
+        woff[j] = 2u * ((unsigned)(n0 + r) * (unsigned)p.Kpad + 8u * ((lane & 3) ^ ((r >> 2) & 3)));
+    }
+    auto issue = [&](int c) {
+        half_t* dp = smem + (c & 1) * PBUF;
+#pragma unroll
+        for (int i = 0; i < PIW; ++i) dma16_buf(rs0, poff[i], 64u * (unsigned)c, dp + (wave + 4 * i) * 512);
+        half_t* dw_ = sW + (c & 1) * WST;
+#pragma unroll
+        for (int j = 0; j < WIW; ++j) dma16_buf(rsw, woff[j], 64u * (unsigned)c, dw_ + (4 * j + wave) * 512);
+    };
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // depthwise stage: this thread's two items = pixels (tid >> 2) and (tid >> 2) + 64, 8-channel piece (tid & 3)
+    const int ch8 = tid & 3;
+    int dq[2], dprow[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int px = (tid >> 2) + 64 * it;
+        dprow[it] = px;
+        dq[it] = (px >> 4) * CP_PW + (px & 15);  // patch entry of tap (0, 0)
+    }
+
+    issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk c (patch + weights) landed; every wave is done with chunk c - 1 (tile, weights, patch)
+        if (c + 1 < nchunks) issue(c + 1);
+        const half_t* sP = smem + (c & 1) * PBUF;
+        {   // depthwise 3x3 + bias + SiLU of the chunk -> B-operand tile
+            const float* wk = sdw + 32 * c + 8 * ch8;
+            f32x4 wv[9][2];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                wv[k][0] = *reinterpret_cast<const f32x4*>(wk + k * C);
+                wv[k][1] = *reinterpret_cast<const f32x4*>(wk + k * C + 4);
+            }
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sdw + 9 * C + 32 * c + 8 * ch8), b1 = *reinterpret_cast<const f32x4*>(sdw + 9 * C + 32 * c + 8 * ch8 + 4);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                float a[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[j] = b0[j]; a[4 + j] = b1[j]; }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {  // same order as dwconv3x3_kernel: (top, mid, bot) of column kw
+                        const int q = dq[it] + kh * CP_PW + kw;
+                        const half8 v = *reinterpret_cast<const half8*>(sP + q * 32 + ((ch8 ^ ((q >> 2) & 3)) << 3));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a[j] = fmaf((float)v[j], wv[kh * 3 + kw][0][j], a[j]);
+                            a[4 + j] = fmaf((float)v[4 + j], wv[kh * 3 + kw][1][j], a[4 + j]);
+                        }
+                    }
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)silu_f(a[j]);
+                const int row = dprow[it];
+                *reinterpret_cast<half8*>(sPt + row * 32 + ((ch8 ^ ((row >> 2) & 3)) << 3)) = o;
+            }
+        }
+        __syncthreads();  // B-operand tile complete
+        const half_t* sWk = sW + (c & 1) * WST;
+        half8 bfr[2][2], afr[2][NT];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int row = (wm * 2 + b) * 32 + lrow;
+            const int s0 = lh ^ ((row >> 2) & 3);
+            bfr[0][b] = *reinterpret_cast<const half8*>(sPt + row * 32 + (s0 << 3));
+            bfr[1][b] = *reinterpret_cast<const half8*>(sPt + row * 32 + ((s0 ^ 2) << 3));
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int row = (wn * NT + a) * 32 + lrow;
+            const int s0 = lh ^ ((row >> 2) & 3);
+            afr[0][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + (s0 << 3));
+            afr[1][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + ((s0 ^ 2) << 3));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+
+    constexpr int LDT = TN + 8;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int prow = (wm * 2 + b) * 32 + lrow;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int cl = (wn * NT + a) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cc = cl + 8 * g + 4 * lh;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + cc);
+                half4 o;
+                f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                if (p.act) tv = silu4_f(tv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)tv[e];
+                *reinterpret_cast<half4*>(smem + prow * LDT + cc) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPRW = TN / 8, ITER = TM * CPRW / 256;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int id = tid + 256 * i;
+        const int prow = id / CPRW, cc = (id % CPRW) * 8;
+        const int oy = oy0 + (prow >> 4), ox = ox0 + (prow & 15), cgl = n0 + cc;
+        if (oy >= p.H || ox >= p.W || cgl >= p.Cout) continue;
+        *reinterpret_cast<half8*>(p.dst + ((size_t)(n * p.H + oy) * p.W + ox) * p.ldd + cgl) =
+            *reinterpret_cast<const half8*>(smem + prow * LDT + cc);
+    }
+}
+
+bool dwpw_fused_supported(int C, int Cout) { return C > 0 && !(C & 31) && C <= DWPW_MAXC && Cout > 0 && !(Cout & 7); }
+
+int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s) {
+    if (!dwpw_fused_supported(a.C, a.Cout)) BSY_FAIL(BSY_ERR_ARG, "dwpw: unsupported widths (C %d, Cout %d): C %% 32 == 0, C <= %d, Cout %% 8 == 0", a.C, a.Cout, DWPW_MAXC);
+    if (!a.src || !a.dst || !a.dww || !a.dwb || !a.wgt || !a.bias) BSY_FAIL(BSY_ERR_ARG, "dwpw: null pointer");
+    if ((a.lds & 7) || (a.ldd & 7) || a.lds < a.C || a.ldd < a.Cout ||
+        (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.dww | (uintptr_t)a.dwb | (uintptr_t)a.wgt | (uintptr_t)a.bias) & 15))
+        BSY_FAIL(BSY_ERR_ARG, "dwpw: misaligned pointer / leading dimension");
+    if ((long long)a.B * a.H * a.W * a.lds >= (1LL << 31)) BSY_FAIL(BSY_ERR_ARG, "dwpw: source view exceeds 2^31 elements (split the batch)");
+    DwPwK k;
+    k.src = a.src; k.ld0 = a.lds; k.B = a.B; k.H = a.H; k.W = a.W; k.C = a.C;
+    k.span0 = (unsigned)((((long long)a.B * a.H * a.W - 1) * a.lds + a.C) * 2);
+    k.dww = a.dww; k.dwb = a.dwb; k.wgt = (const half_t*)a.wgt; k.bias = a.bias; k.dst = a.dst; k.ldd = a.ldd; k.Cout = a.Cout;
+    k.Kpad = round_up(a.C, 32); k.act = a.act;
+    k.wspan = (unsigned)((size_t)round_up(a.Cout, 128) * k.Kpad * 2);
+    k.tiles_x = ceil_div(a.W, CP_TW); k.tiles_y = ceil_div(a.H, 8);
+    const bool wide = a.Cout > 64;
+    k.ntn = ceil_div(a.Cout, wide ? 128 : 64);
+    const long long nblk = (long long)a.B * k.tiles_x * k.tiles_y * k.ntn;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "dwpw: tile count out of range");
+    if (wide) hipLaunchKernelGGL((dwpw_fused_kernel<2>), dim3((unsigned)nblk), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((dwpw_fused_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, s, k);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
 template <int KS, int WM, int WN, int MT, int NT, int STAGES, bool ALIGNED, int BK>
 static int launch_cfg(const ConvK& k, hipStream_t s) {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;

@@ -173,6 +173,15 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok) return BSY_ERR_ARG;
             return launch_bneck_fused(a, s);
         }
+        case BSY_OP_DWPW: {
+            DwPwArgs a;
+            a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C;
+            a.dww = (const float*)(wb + op.w_off); a.dwb = (const float*)(wb + op.b_off);
+            a.wgt = (const void*)(wb + op.w2_off); a.bias = (const float*)(wb + op.b2_off);
+            a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.Cout = op.dst.C; a.act = op.act;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_dwpw_fused(a, s);
+        }
         case BSY_OP_DWCONV_G: {
             DwGenArgs a;
             a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C;
@@ -535,6 +544,16 @@ extern "C" int bsy_ela(const void* x, int ldx, int B, int H, int W, int C, int k
     a.scratch = (float*)scratch; a.dst = (half_t*)y; a.ldd = ldy;
     return launch_ela(a, (hipStream_t)stream);
 }
+
+extern "C" int bsy_dwpw_fused(const void* x, int ldx, int B, int H, int W, int C, const float* dww, const float* dwb,
+                              const void* w, const float* b, void* y, int ldy, int C2, int act, bsy_stream stream) {
+    DwPwArgs a;
+    a.src = (const half_t*)x; a.lds = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.dww = dww; a.dwb = dwb; a.wgt = w; a.bias = b;
+    a.dst = (half_t*)y; a.ldd = ldy; a.Cout = C2; a.act = act;
+    return launch_dwpw_fused(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_dwpw_fused_supported(int C, int C2) { return dwpw_fused_supported(C, C2) ? 1 : 0; }
 
 extern "C" int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y,
                              int ldy, int act, const void* res, int ldr, bsy_stream stream) {

@@ -16,11 +16,11 @@ LIB_PATH = PKG / "libbsyolo_hip.so"
 
 BSY_F16, BSY_F32, BSY_U8 = 0, 1, 2
 BSY_EXT_BASE = 0x100000
-(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA) = range(16)
+(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW) = range(17)
 
 SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_destroy",
-    "bsy_plan_run", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_conv2d", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_dwconv", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
+    "bsy_plan_run", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_conv2d", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
     "bsy_sppf_pool", "bsy_attention", "bsy_detect_decode", "bsy_nms_workspace_bytes", "bsy_nms", "bsy_scale_boxes",
     "bsy_letterbox", "bsy_process_mask", "bsy_val_match", "bsy_last_error", "bsy_version",
 ]
@@ -96,6 +96,8 @@ def _load() -> C.CDLL:
     lib.bsy_bottleneck_fused_supported.argtypes = [i32, i32]
     lib.bsy_dwconv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp]
     lib.bsy_ela_scratch_bytes.argtypes = [i32, i32, i32, i32]
+    lib.bsy_dwpw_fused.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.bsy_dwpw_fused_supported.argtypes = [i32, i32]
     lib.bsy_ela_scratch_bytes.restype = C.c_size_t
     lib.bsy_ela.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(C.c_float), vp, vp, i32, vp]
     lib.bsy_dwconv3x3.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp]

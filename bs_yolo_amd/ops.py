@@ -102,6 +102,18 @@ def bottleneck_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: to
     return out
 
 
+def dwpw_fused(x: torch.Tensor, wd: torch.Tensor, bd: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: bool = True) -> torch.Tensor:
+    """DWConv 3x3 + SiLU -> Conv 1x1 (+act) in one launch.  x (B,H,W,C) fp16; wd (C,1,3,3), bd (C); w (C2,C,1,1), b (C2)."""
+    B, H, W, Cc = x.shape
+    c2 = w.shape[0]
+    wdp = wd.detach().float().cpu().view(Cc, 9).t().contiguous().to(x.device)
+    bdp = bd.detach().float().contiguous().to(x.device)
+    wp, bp = pack_conv_weight(w, b, x.device)
+    out = torch.empty((B, H, W, c2), dtype=torch.float16, device=x.device)
+    L.check(L.lib.bsy_dwpw_fused(_p(x), Cc, B, H, W, Cc, _p(wdp), _p(bdp), _p(wp), _p(bp), _p(out), c2, c2, int(act), _stream(x)))
+    return out
+
+
 def dwconv_nhwc(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, stride: int = 1, act: bool = False) -> torch.Tensor:
     """Depthwise kh x kw conv, padding k/2 (csrc/bsyolo_ops.hip).  x (B,H,W,C) fp16; w (C,1,kh,kw) fp32; b (C)."""
     B, H, W, Cc = x.shape

@@ -72,6 +72,11 @@ def stem_supported(c0: int, c1: int, H: int, W: int) -> bool:
     return (c0, c1) in ((32, 64), (16, 32)) and W % 4 == 0 and H >= 4 and W >= 4
 
 
+def dwpw_supported(c: int, cout: int) -> bool:
+    """Widths dwpw_fused_kernel accepts (mirror of bsy_dwpw_fused_supported)."""
+    return c > 0 and c % 32 == 0 and c <= 256 and cout % 8 == 0
+
+
 def bneck_supported(c: int, ch: int) -> bool:
     """Widths csrc/bneck_fused.hip accepts (mirror of bsy_bottleneck_fused_supported)."""
     return (c, ch) == (32, 16)
@@ -84,12 +89,14 @@ class Plan:
     EXT_PROTO = 5
 
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
-                 fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None):
+                 fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
+                 fuse_dwpw: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
         self.fuse_head = (os.environ.get("BSY_FUSE_HEAD", "1") != "0") if fuse_head is None else bool(fuse_head)
+        self.fuse_dwpw = (os.environ.get("BSY_FUSE_DWPW", "1") != "0") if fuse_dwpw is None else bool(fuse_dwpw)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -97,7 +104,7 @@ class Plan:
         self.meta: Dict = {}
         self._lane = 0
         self._build()
-        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK, L.OP_DWCONV_G) for o in self.ops)
+        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK, L.OP_DWCONV_G, L.OP_DWPW) for o in self.ops)
 
     # ---- buffers -------------------------------------------------------------------------------------------
     def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
@@ -167,6 +174,20 @@ class Plan:
         self.ops.append(dict(kind=L.OP_DWCONV_G, H=src.H, W=src.W, OH=OH, OW=OW, src0=src, dst=dst, ksize=kh, pad=kw, stride=s,
                              act=int(act_c), wkey=key, heads=src.C, key_dim=0, name=name, lane=self._lane))
         self.flops += 2 * self.B * OH * OW * src.C * kh * kw
+        return dst
+
+    def dwpw(self, name: str, src: T, cout: int) -> T:
+        """nn.Sequential(DWConv(c, c, 3), Conv(c, cout, 1)) (head.py:49-57): one fused launch where conv_mfma.hip's
+        dwpw_fused_kernel takes the widths, else the two ordinary launches."""
+        if not (self.fuse_dwpw and dwpw_supported(src.C, cout) and not src.up):
+            t = self.dwconv(name + ".0", src, act=True)
+            return self.conv(name + ".1", t, cout, 1, 1)
+        kd = self._wrec(name + ".0", name=name + ".0", kind="dw", cout=src.C, cin=1, k=3)
+        kp = self._wrec(name + ".1", name=name + ".1", kind="conv", cout=cout, cin=src.C, k=1, perm=None)
+        dst = self.alloc(cout, src.H, src.W)
+        self.ops.append(dict(kind=L.OP_DWPW, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, dst=dst, ksize=3, stride=1, pad=1,
+                             act=1, wkey=kd, wkey2=kp, name=name, lane=self._lane))
+        self.flops += 2 * self.B * src.H * src.W * src.C * (9 + cout)
         return dst
 
     def copy(self, name: str, src: T, dst: T):
@@ -386,10 +407,8 @@ class Plan:
                 t = self.conv(f"{name}.cv3.{i}.0", x, c3, 3, 1)
                 t = self.conv(f"{name}.cv3.{i}.1", t, c3, 3, 1)
             else:
-                t = self.dwconv(f"{name}.cv3.{i}.0.0", x, act=True)
-                t = self.conv(f"{name}.cv3.{i}.0.1", t, c3, 1, 1)
-                t = self.dwconv(f"{name}.cv3.{i}.1.0", t, act=True)
-                t = self.conv(f"{name}.cv3.{i}.1.1", t, c3, 1, 1)
+                t = self.dwpw(f"{name}.cv3.{i}.0", x, c3)
+                t = self.dwpw(f"{name}.cv3.{i}.1", t, c3)
             if fused:
                 self._head_conv(f"{name}.cv3.{i}.2", t, nc, 2, i, a0[i], A, nc, strides[i])
             else:

@@ -75,6 +75,8 @@ enum bsy_op_kind {
     BSY_OP_MSCA_MIX = 13,  /* dst = sum_i softmax_i(sigmoid(logit_i)) * branch_i; branches box[0..2] + res, logits (f32
                             * (B,1,1,C) maps) cls[0..2] + msk[0]   (nn/Addmodules/MSCA.py:69-82)                        */
     BSY_OP_MUL = 14,       /* dst = src0 * src1 elementwise                                                             */
+    BSY_OP_DWPW = 16,      /* DWConv 3x3 (+SiLU) -> Conv 1x1 (+act) as one launch (YOLO11 class branch, head.py:49-57):
+                            * src0 (C channels) -> dst; w_off/b_off = depthwise f32 [9][C] / [C], w2_off/b2_off = 1x1    */
     BSY_OP_ELA = 15        /* ELA (nn/Addmodules/ELA.py:77-101): ksize = Conv1d taps; w_off -> f32 blob [spatial_conv C*k]
                             * [ch_att conv C*k][gn.weight C][gn.bias C]; scale, lvl_stride[0], lvl_stride[1] =
                             * sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight);
@@ -186,6 +188,13 @@ int bsy_dwconv(const void* x, int ldx, int B, int H, int W, int C, int kh, int k
 size_t bsy_ela_scratch_bytes(int B, int H, int W, int C);
 int bsy_ela(const void* x, int ldx, int B, int H, int W, int C, int k, const float* wsp, const float* wch,
             const float* gnw, const float* gnb, const float* coef, void* scratch, void* y, int ldy, bsy_stream stream);
+
+/* nn.Sequential(DWConv(c, c, 3), Conv(c, c2, 1)) (head.py:49-57) as ONE launch: depthwise 3x3 + SiLU computed per tile
+ * on the VALU, fed straight to the 1x1 conv's MFMAs.  dww f32 [9][C], dwb f32 [C] as bsy_dwconv3x3; w / b as bsy_conv2d.
+ * C % 32 == 0, C <= 256, C2 % 8 == 0; anything else is BSY_ERR_ARG.  Bit-identical to bsy_dwconv3x3 + bsy_conv2d. */
+int bsy_dwpw_fused(const void* x, int ldx, int B, int H, int W, int C, const float* dww, const float* dwb, const void* w,
+                   const float* b, void* y, int ldy, int C2, int act, bsy_stream stream);
+int bsy_dwpw_fused_supported(int C, int C2);
 
 /* DWConv (conv.py:224-229) 3x3 s1: w f32 [9][C], b f32 [C]. */
 int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* b, void* y, int ldy,

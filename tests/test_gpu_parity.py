@@ -293,6 +293,28 @@ def test_ela_matches_reference_golden(tag):
     assert np.abs(got - ref).max() < 4e-3 * max(1.0, np.abs(ref).max())  # fp16 input / output rounding only
 
 
+@pytest.mark.parametrize("shape,c,c2", [((2, 24, 40), 128, 128), ((1, 17, 21), 64, 80), ((3, 8, 16), 256, 64), ((2, 20, 20), 32, 128)])
+def test_dwpw_fused_matches_unfused_and_oracle(shape, c, c2):
+    """DWConv 3x3 + SiLU -> Conv 1x1 + SiLU (head.py:49-57) in one launch (dwpw_fused_kernel): bit-identical to
+    bsy_dwconv3x3 + bsy_conv2d and equal to the fp32 reference with the depthwise map rounded to fp16."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(41)
+    x = h16(torch.randn(B, c, H, W, generator=g))
+    wd = torch.randn(c, 1, 3, 3, generator=g) * 0.4
+    bd = torch.randn(c, generator=g) * 0.2
+    w = h16(torch.randn(c2, c, 1, 1, generator=g) * (2.0 / c) ** 0.5)
+    b = torch.randn(c2, generator=g) * 0.2
+    xd = nhwc(x).half().to(DEV)
+    fused = O.dwpw_fused(xd, wd, bd, w, b)
+    mid = O.dwconv3x3_nhwc(xd, wd, bd, True)
+    wp, bp = O.pack_conv_weight(w, b, DEV)
+    two = O.conv2d_nhwc(mid, wp, bp, c2, 1, 1, True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
+    ref = F.silu(F.conv2d(h16(F.silu(F.conv2d(x, wd, bd, 1, 1, 1, c))), w, b))
+    np.testing.assert_allclose(nchw(fused.float().cpu()).numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
+
+
 @pytest.mark.parametrize("act,use_res", [(True, False), (False, True)])
 def test_dwconv_matches_oracle(act, use_res):
     g = torch.Generator().manual_seed(5)
@@ -549,8 +571,8 @@ def test_engine_stem_fusion_is_bit_identical(scale):
     P = R.synth_params(m, 0)
     cfg = stock_cfg("yolo11", scale)
     # autotune off: the tuner may pick kernels with different (equally valid) summation orders per plan
-    fused = YoloEngine(cfg, P, fuse_stem=True, fuse_bneck=True, autotune=False)
-    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, autotune=False)
+    fused = YoloEngine(cfg, P, fuse_stem=True, fuse_bneck=True, fuse_dwpw=True, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, autotune=False)
     x = torch.rand(2, 3, 160, 96, generator=torch.Generator().manual_seed(3)).half().to(DEV)
     pf, _ = fused.plan_for(2, 160, 96, torch.float16, torch.float16)
     pp, _ = plain.plan_for(2, 160, 96, torch.float16, torch.float16)

@@ -59,7 +59,7 @@ def test_op_struct_layout():
 def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     """Dense-conv FLOPs per 640x640 image equal the reference graph (BASELINE.md section 2 / SURVEY 8d); the
     reference counts 81 dense convs for n/s because DFL is a 1x1 conv there (block.py:58-77), here it lives in decode."""
-    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False)
+    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False)
     dense = 0
     n = 0
     for o in p.ops:
@@ -109,6 +109,18 @@ def test_bottleneck_fusion_peephole():
     assert [o["name"] for o in n.ops if o["kind"] == L.OP_BNECK] == ["model.4.m.0", "model.16.m.0"]
     m = Plan(stock_cfg("yolo11", "m"), 1, 64, 64, fuse_bneck=True)  # C3k blocks, e = 1.0: not fused
     assert not any(o["kind"] == L.OP_BNECK for o in m.ops)
+
+
+def test_dwpw_fusion_peephole():
+    """YOLO11's class branch units nn.Sequential(DWConv, Conv 1x1) (head.py:49-57) become one OP_DWPW launch where the
+    depthwise width is <= 256 (levels 0 and 1 of YOLO11s; the 512-wide level keeps two launches)."""
+    a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_dwpw=False)
+    b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_dwpw=True)
+    assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
+    fused = [o["name"] for o in b.ops if o["kind"] == L.OP_DWPW]
+    assert fused == ["model.23.cv3.0.0", "model.23.cv3.0.1", "model.23.cv3.1.0", "model.23.cv3.1.1", "model.23.cv3.2.1"]
+    assert len(b.ops) == len(a.ops) - len(fused) and L.OP_DWPW == 16
+    assert any(o["kind"] == L.OP_DWCONV and o["name"] == "model.23.cv3.2.0.0" for o in b.ops)
 
 
 def test_plan_consumes_exactly_the_reference_parameters():
