@@ -1060,19 +1060,23 @@ struct DwPwK {
     int ldd, Cout, Kpad, act, tiles_x, tiles_y, ntn;
 };
 #define DWPW_MAXC 256
+// LDS: 2 patch buffers (chunk c + 1 lands while chunk c is processed), ONE weight stage (chunk c's 1x1 weights are issued
+// after the barrier that retires chunk c - 1's MFMAs and are only needed after the depthwise stage, which is longer than
+// their latency), the B-operand tile, and the depthwise weights / bias (dynamic: 10 * C floats) -> 46 KiB + 40 C bytes:
+// three workgroups per CU for C <= 128.
 template <int NT>
-__global__ __launch_bounds__(256) void dwpw_fused_kernel(const DwPwK p) {
+__global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const DwPwK p) {
     constexpr int TN = 64 * NT, TM = 128;
     constexpr int PIW = 3, NPI = 12, NPX = 10 * CP_PW;  // patch: 180 entries in 12 DMA wave-instructions
     constexpr int PBUF = NPI * 16 * 32, WST = TN * 32, PT = TM * 32;
     constexpr int WIW = TN / 64;
     constexpr int OTILE = TM * (TN + 8);
-    constexpr int RING = 2 * PBUF + 2 * WST + PT;
-    constexpr int SMEM = (RING > OTILE ? RING : OTILE) + 2 * 10 * DWPW_MAXC;  // + depthwise weights / bias (f32)
+    constexpr int RING = 2 * PBUF + WST + PT;
+    constexpr int SMEM = RING > OTILE ? RING : OTILE;
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+    extern __shared__ __attribute__((aligned(16))) float sdw[];  // [9][C] then [C]
     half_t* sW = smem + 2 * PBUF;
-    half_t* sPt = sW + 2 * WST;
-    float* sdw = reinterpret_cast<float*>(smem + (RING > OTILE ? RING : OTILE));  // [9][C] then [C]
+    half_t* sPt = sW + WST;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1106,13 +1110,14 @@ __global__ __launch_bounds__(256) void dwpw_fused_kernel(const DwPwK p) {
         const int r = 16 * (4 * j + wave) + (lane >> 2);
         woff[j] = 2u * ((unsigned)(n0 + r) * (unsigned)p.Kpad + 8u * ((lane & 3) ^ ((r >> 2) & 3)));
     }
-    auto issue = [&](int c) {
+    auto issue_patch = [&](int c) {
         half_t* dp = smem + (c & 1) * PBUF;
 #pragma unroll
         for (int i = 0; i < PIW; ++i) dma16_buf(rs0, poff[i], 64u * (unsigned)c, dp + (wave + 4 * i) * 512);
-        half_t* dw_ = sW + (c & 1) * WST;
+    };
+    auto issue_weights = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < WIW; ++j) dma16_buf(rsw, woff[j], 64u * (unsigned)c, dw_ + (4 * j + wave) * 512);
+        for (int j = 0; j < WIW; ++j) dma16_buf(rsw, woff[j], 64u * (unsigned)c, sW + (4 * j + wave) * 512);
     };
 
     f32x16 acc[NT][2];
@@ -1122,57 +1127,70 @@ __global__ __launch_bounds__(256) void dwpw_fused_kernel(const DwPwK p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // depthwise stage: this thread's two items = pixels (tid >> 2) and (tid >> 2) + 64, 8-channel piece (tid & 3)
+    // depthwise stage: this thread's two items = pixels (tid >> 2) and (tid >> 2) + 64 (4 tile rows apart), 8-channel
+    // piece (tid & 3).  LDS offsets (halves) of the item's nine taps, swizzle included, are chunk-independent.
     const int ch8 = tid & 3;
-    int dq[2], dprow[2];
+    int tapoff[9];
+    {
+        const int px = tid >> 2;
+        const int q0 = (px >> 4) * CP_PW + (px & 15);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int q = q0 + (k / 3) * CP_PW + k % 3;
+            tapoff[k] = q * 32 + ((ch8 ^ ((q >> 2) & 3)) << 3);
+        }
+    }
+    // the second item sits 4 rows = 72 entries further: 72 % 16 == 8 -> (q >> 2) & 3 flips bit 1 -> slot ^ 2 -> +-16 halves
+    int ptoff[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int px = (tid >> 2) + 64 * it;
-        dprow[it] = px;
-        dq[it] = (px >> 4) * CP_PW + (px & 15);  // patch entry of tap (0, 0)
+        const int row = (tid >> 2) + 64 * it;
+        ptoff[it] = row * 32 + ((ch8 ^ ((row >> 2) & 3)) << 3);
     }
 
-    issue(0);
+    issue_patch(0);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // chunk c (patch + weights) landed; every wave is done with chunk c - 1 (tile, weights, patch)
-        if (c + 1 < nchunks) issue(c + 1);
+        __syncthreads();  // patch c landed; every wave is done with chunk c - 1 (its weights, tile and patch)
+        if (c + 1 < nchunks) issue_patch(c + 1);
+        issue_weights(c);
         const half_t* sP = smem + (c & 1) * PBUF;
         {   // depthwise 3x3 + bias + SiLU of the chunk -> B-operand tile
             const float* wk = sdw + 32 * c + 8 * ch8;
-            f32x4 wv[9][2];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                wv[k][0] = *reinterpret_cast<const f32x4*>(wk + k * C);
-                wv[k][1] = *reinterpret_cast<const f32x4*>(wk + k * C + 4);
-            }
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(sdw + 9 * C + 32 * c + 8 * ch8), b1 = *reinterpret_cast<const f32x4*>(sdw + 9 * C + 32 * c + 8 * ch8 + 4);
+            float a[2][8];
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                float a[8];
+            for (int it = 0; it < 2; ++it)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { a[j] = b0[j]; a[4 + j] = b1[j]; }
+                for (int j = 0; j < 4; ++j) { a[it][j] = b0[j]; a[it][4 + j] = b1[j]; }
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
+            for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {  // same order as dwconv3x3_kernel: (top, mid, bot) of column kw
-                        const int q = dq[it] + kh * CP_PW + kw;
-                        const half8 v = *reinterpret_cast<const half8*>(sP + q * 32 + ((ch8 ^ ((q >> 2) & 3)) << 3));
+                for (int kh = 0; kh < 3; ++kh) {  // same order as dwconv3x3_kernel: (top, mid, bot) of column kw
+                    const int k = kh * 3 + kw;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk + k * C), w1 = *reinterpret_cast<const f32x4*>(wk + k * C + 4);
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        // item 1 = item 0 + 72 entries: (q >> 2) & 3 changes by 2 (72 / 4 = 18) -> slot ^ 2
+                        const half8 v = *reinterpret_cast<const half8*>(sP + (it ? ((tapoff[k] + 72 * 32) ^ 16) : tapoff[k]));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            a[j] = fmaf((float)v[j], wv[kh * 3 + kw][0][j], a[j]);
-                            a[4 + j] = fmaf((float)v[4 + j], wv[kh * 3 + kw][1][j], a[4 + j]);
+                            a[it][j] = fmaf((float)v[j], w0[j], a[it][j]);
+                            a[it][4 + j] = fmaf((float)v[4 + j], w1[j], a[it][4 + j]);
                         }
                     }
-                half8 o;
+                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)silu_f(a[j]);
-                const int row = dprow[it];
-                *reinterpret_cast<half8*>(sPt + row * 32 + ((ch8 ^ ((row >> 2) & 3)) << 3)) = o;
+            for (int it = 0; it < 2; ++it) {
+                half8 o;
+                const f32x4 s0 = silu4_f(f32x4{a[it][0], a[it][1], a[it][2], a[it][3]}), s1 = silu4_f(f32x4{a[it][4], a[it][5], a[it][6], a[it][7]});
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j] = (half_t)s0[j]; o[4 + j] = (half_t)s1[j]; }
+                *reinterpret_cast<half8*>(sPt + ptoff[it]) = o;
             }
         }
-        __syncthreads();  // B-operand tile complete
-        const half_t* sWk = sW + (c & 1) * WST;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's 1x1 weights (and the next patch) have landed
+        __syncthreads();  // B-operand tile complete, weights visible
         half8 bfr[2][2], afr[2][NT];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -1182,19 +1200,19 @@ __global__ __launch_bounds__(256) void dwpw_fused_kernel(const DwPwK p) {
             bfr[1][b] = *reinterpret_cast<const half8*>(sPt + row * 32 + ((s0 ^ 2) << 3));
         }
 #pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const int row = (wn * NT + a) * 32 + lrow;
+        for (int a_ = 0; a_ < NT; ++a_) {
+            const int row = (wn * NT + a_) * 32 + lrow;
             const int s0 = lh ^ ((row >> 2) & 3);
-            afr[0][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + (s0 << 3));
-            afr[1][a] = *reinterpret_cast<const half8*>(sWk + row * 32 + ((s0 ^ 2) << 3));
+            afr[0][a_] = *reinterpret_cast<const half8*>(sW + row * 32 + (s0 << 3));
+            afr[1][a_] = *reinterpret_cast<const half8*>(sW + row * 32 + ((s0 ^ 2) << 3));
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int a = 0; a < NT; ++a)
+            for (int a_ = 0; a_ < NT; ++a_)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+                    acc[a_][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a_], bfr[ks][b], acc[a_][b], 0, 0, 0);
     }
     __syncthreads();
 
@@ -1203,14 +1221,14 @@ __global__ __launch_bounds__(256) void dwpw_fused_kernel(const DwPwK p) {
     for (int b = 0; b < 2; ++b) {
         const int prow = (wm * 2 + b) * 32 + lrow;
 #pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const int cl = (wn * NT + a) * 32;
+        for (int a_ = 0; a_ < NT; ++a_) {
+            const int cl = (wn * NT + a_) * 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cc = cl + 8 * g + 4 * lh;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + cc);
                 half4 o;
-                f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                f32x4 tv = f32x4{acc[a_][b][4 * g], acc[a_][b][4 * g + 1], acc[a_][b][4 * g + 2], acc[a_][b][4 * g + 3]} + bv;
                 if (p.act) tv = silu4_f(tv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (half_t)tv[e];
@@ -1251,8 +1269,9 @@ int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s) {
     k.ntn = ceil_div(a.Cout, wide ? 128 : 64);
     const long long nblk = (long long)a.B * k.tiles_x * k.tiles_y * k.ntn;
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "dwpw: tile count out of range");
-    if (wide) hipLaunchKernelGGL((dwpw_fused_kernel<2>), dim3((unsigned)nblk), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((dwpw_fused_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, s, k);
+    const size_t dyn = (size_t)10 * a.C * sizeof(float);  // depthwise weights + bias
+    if (wide) hipLaunchKernelGGL((dwpw_fused_kernel<2>), dim3((unsigned)nblk), dim3(256), dyn, s, k);
+    else hipLaunchKernelGGL((dwpw_fused_kernel<1>), dim3((unsigned)nblk), dim3(256), dyn, s, k);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
