@@ -53,7 +53,8 @@ struct ConvK {
     void* y;
     void* raw;
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
-    int dbg;  // ablation switches for profiling (BSY_CONV_DBG): 1 = no DMA, 4 = no epilogue
+    int dbg;  // ablation switches for profiling (BSY_CONV_DBG; results are WRONG under them): 1 = no DMA, 4 = no epilogue,
+              // 64 = taps innermost in the K loop (the traffic experiment of DESIGN.md section 5)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int bsy_zero_page[16];  // zero-initialised; source of padded taps
@@ -463,18 +464,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
         if (ALIGNED) {
             const bool s1 = s_cb >= p.C0;
             const int ld = s1 ? p.ld1 : p.ld0;
-            int kh = (KS == 1) ? 0 : s_tap / KS;
-            int kw = (KS == 1) ? 0 : s_tap - kh * KS;
-            if (p.dbg & 8) { kh = 1; kw = 1; }  // experiment: every tap reads the centre pixel (no im2col re-read through L2)
+            const int kh = (KS == 1) ? 0 : s_tap / KS;
+            const int kw = (KS == 1) ? 0 : s_tap - kh * KS;
             // scalar part of the byte offset: tap displacement + channel base inside the source
             const unsigned sc = 2u * (unsigned)((kh * p.W + kw) * ld + (s1 ? s_cb - p.C0 : s_cb));
             const unsigned tbit = 1u << s_tap;
 #pragma unroll
             for (int i = 0; i < PIW; ++i) {
                 const unsigned kcb = 16u * (unsigned)((i & 1) ? kc1 : kc0);
-                unsigned o = (vmask[i] & tbit) ? 2u * (s1 ? off1[i] : off0[i]) + sc + kcb : BSY_OOB;
-                if (p.dbg & 128) o &= 0xFFFF0u;  // experiment: every read inside 1 MiB (L2-resident), wrong numerics
-                if (p.dbg & 256) o &= 0x3FF0u;   // experiment: every read inside 16 KiB (L1-resident), wrong numerics
+                const unsigned o = (vmask[i] & tbit) ? 2u * (s1 ? off1[i] : off0[i]) + sc + kcb : BSY_OOB;
                 if (s1) dma16_buf(rs1, o, 0u, sP + (wave * PIW + i) * RPI * BK);
                 else dma16_buf(rs0, o, 0u, sP + (wave * PIW + i) * RPI * BK);
             }
@@ -539,7 +537,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // K-step kt visible to every wave; every wave is done reading stage (kt-1)%STAGES
-        if (!(p.dbg & 16) && kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const half_t* sP = smem + (kt % STAGES) * STAGE;
         const half_t* sW = sP + TM * BK;
         // all fragment reads of the K-step first (distinct registers), then the MFMA burst: the LDS latency is paid
@@ -562,9 +560,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA burst (the scheduler would sink them back)
-        // experiment (dbg 16): issue the next DMA here, under the LDS read latency, instead of right after the barrier
-        if ((p.dbg & 16) && kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
-        if (p.dbg & 32) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < KSUB; ++ks)
 #pragma unroll
@@ -572,7 +567,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
 #pragma unroll
                 for (int b = 0; b < MT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
-        if (p.dbg & 32) __builtin_amdgcn_s_setprio(0);
     }
     if (p.dbg & 4) {
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.dst)[0] = 1.f;  // keep the accumulators live
