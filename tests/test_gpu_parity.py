@@ -549,6 +549,29 @@ def test_predict_pipeline_config1_end_to_end():
     eng.close()
 
 
+@pytest.mark.parametrize("scale,shape", [("n", (1, 32, 32)), ("s", (3, 96, 224)), ("s", (2, 160, 32)), ("n", (5, 64, 416))])
+def test_engine_tuned_fused_equals_plain_on_odd_shapes(scale, shape):
+    """Every fusion + the autotuner's picks (patch / persistent / big-tile kernels) against the plain plan (one launch per
+    layer, heuristic implicit-GEMM configurations) on small, narrow and wide inputs: same prediction up to the fp32
+    summation-order differences of the patch kernel and the fused DFL (scores 2e-3, boxes 0.25 px), same raw maps."""
+    m = R.Model("yolo11", scale, 80, "detect")
+    P = R.synth_params(m, 2)
+    cfg = stock_cfg("yolo11", scale)
+    full = YoloEngine(cfg, P)
+    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_head=False, fuse_dwpw=False, autotune=False)
+    B, H, W = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * W)).half().to(DEV)
+    yf, rf = full(x)
+    yp, rp = plain(x)
+    torch.cuda.synchronize()
+    d = (yf.float() - yp.float()).abs()
+    assert d[:, 4:].max() < 2e-3 and d[:, :4].max() < 0.25, (d[:, 4:].max(), d[:, :4].max())
+    for a, b in zip(rf, rp):
+        assert (a.float() - b.float()).abs().max() < 2e-2 * max(1.0, b.float().abs().max().item())
+    full.close()
+    plain.close()
+
+
 def test_engine_batch_independence_and_determinism():
     """Images are independent units: a batch equals its images run one by one; reruns are bit-identical."""
     m = R.Model("yolo11", "n", 80, "detect")
