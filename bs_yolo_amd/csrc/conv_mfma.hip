@@ -446,7 +446,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     unsigned woff[WIW];
 #pragma unroll
     for (int j = 0; j < WIW; ++j)
-        woff[j] = (unsigned)(n0 + (wave * WIW + j) * RPI + rsub) * (unsigned)p.Kpad + ((j & 1) ? kc1 : kc0) * 8;
+    {
+        // rows past the packed matrix (a 32-wide cout tile stages 64 rows; the last cout tile of a 128-row matrix would read
+        // rows 128..159): the descriptor path returns zeros for them, the flat-DMA (generic) path must not touch them --
+        // clamp to the last packed row, the values are never used
+        const int wrow = min(n0 + (wave * WIW + j) * RPI + rsub, ((p.Cout + 127) & ~127) - 1);
+        woff[j] = (unsigned)wrow * (unsigned)p.Kpad + ((j & 1) ? kc1 : kc0) * 8;
+    }
     const half_t* zero = reinterpret_cast<const half_t*>(bsy_zero_page);
     const bsy_rsrc_t rs0 = make_rsrc(p.src0, p.span0), rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.span1 : 0u),
                      rsw = make_rsrc(p.wgt, p.wspan);
@@ -1314,11 +1320,11 @@ bool conv_cfg_valid(const ConvArgs& a, int cfg) {
         return a.ksize == 1 && aligned_ && var >= 1 && (var != 3 || aligned64_) && !a.out_f32 && !a.res && !(a.Cout & 7) && a.Cout <= 1024 &&
                !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 && a.stride == 1;
     }
-    if (tile == 7 && ((a.Cout & 255) || (var != 1 && var != 2))) return false;  // 256x256: whole 256-cout tiles only
+    if (tile == 7 && ((a.Cout & 255) || var < 1)) return false;  // 256x256: whole 256-cout tiles only (variant 3: BK 64, 128 KiB of LDS)
     const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
     if (var >= 1 && !aligned) return false;
     if (var == 3 && !aligned64) return false;
-    if (tile == 4 && var != 1 && var != 2) return false;
+    if (tile == 4 && var < 1) return false;  // 8-wave 256 x 128: aligned variants only (3 = BK 64, 96 KiB of LDS)
     return true;
 }
 
@@ -1434,9 +1440,11 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         if (tile == 3) BSY_VAR(KS_, 2, 2, 2, 1);                                          \
         if (tile == 5) BSY_VAR(KS_, 1, 4, 2, 1);                                          \
         if (tile == 6) BSY_VAR(KS_, 2, 2, 1, 1);                                          \
+        if (tile == 7 && var == 3) return launch_cfg<KS_, 4, 2, 2, 4, 2, true, 64>(k, s); \
         if (tile == 7 && var == 1) return launch_cfg<KS_, 4, 2, 2, 4, 3, true, 32>(k, s); \
         if (tile == 7) return launch_cfg<KS_, 4, 2, 2, 4, 2, true, 32>(k, s);             \
         if (var == 1) return launch_cfg<KS_, 4, 2, 2, 2, 3, true, 32>(k, s);              \
+        if (var == 3) return launch_cfg<KS_, 4, 2, 2, 2, 2, true, 64>(k, s);              \
         return launch_cfg<KS_, 4, 2, 2, 2, 2, true, 32>(k, s);                            \
     } while (0)
     if (a.ksize == 1) BSY_TILE(1);

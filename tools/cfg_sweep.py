@@ -6,10 +6,12 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from bs_yolo_amd import ops as O
 
-SHAPES = [(64, 20, 20, 512, 512, 1, 1), (64, 20, 20, 768, 512, 1, 1), (64, 20, 20, 1024, 512, 1, 1), (64, 20, 20, 256, 512, 1, 1),
+SHAPES = [(64, 80, 80, 256, 256, 3, 2), (64, 40, 40, 256, 512, 3, 2), (64, 20, 20, 512, 512, 1, 1), (64, 20, 20, 768, 512, 1, 1), (64, 20, 20, 1024, 512, 1, 1), (64, 20, 20, 256, 512, 1, 1),
           (64, 40, 40, 384, 256, 1, 1), (64, 40, 40, 768, 256, 1, 1), (64, 40, 40, 256, 256, 1, 1), (64, 80, 80, 192, 256, 1, 1),
-          (64, 80, 80, 128, 128, 1, 1), (64, 40, 40, 256, 256, 3, 2), (64, 80, 80, 128, 128, 3, 2), (64, 20, 20, 128, 128, 3, 1)]
+          (64, 80, 80, 128, 128, 1, 1), (64, 160, 160, 128, 128, 3, 2), (64, 80, 80, 128, 128, 3, 2), (64, 80, 80, 512, 128, 1, 1), (64, 160, 160, 96, 128, 1, 1)]
 dev = "cuda:0"
+if len(sys.argv) > 1:  # cfg_sweep.py <index> : one shape only
+    SHAPES = [SHAPES[int(sys.argv[1])]]
 for (B, H, W, cin, cout, k, s) in SHAPES:
     x = (torch.randn(B, H, W, cin, device=dev) * 0.5).half()
     w = torch.randn(cout, cin, k, k) * (2.0 / (cin * k * k)) ** 0.5
