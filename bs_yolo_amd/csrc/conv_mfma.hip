@@ -1345,7 +1345,10 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (a.Cout > 64) add(5, 0);
         return n;
     }
-    // heuristic first, then the exhaustive (tile x variant) sweep the autotuner times
+    // heuristic first (what an un-tuned plan runs: the r01 measurements' usual winners), then the exhaustive
+    // (tile x variant) sweep the autotuner times
+    if (!a.epi && a.ksize == 3 && a.stride == 1 && a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) add(11, 2);  // patch kernel
+    if (!a.epi && !(a.Cout & 255) && aligned64 && M >= 16384) add(7, 3);  // 256 x 256, 64-deep K-steps
     add(tile, aligned64 ? 3 : 1);
     static const int tn[10] = {32, 64, 128, 64, 128, 128, 64, 256, 128, 64};
     for (int t = 0; t < 10; ++t) {
