@@ -306,6 +306,54 @@ __device__ __forceinline__ void conv_epilogue_head(const ConvK& p, f32x16 (&acc)
     }
 }
 
+// Class-score epilogue through LDS (f16 y, no raw map requested): the direct form above writes 64-byte pieces (32 lanes x
+// one f16 anchor) -- the class conv of the 80 x 80 level ran at 2.6 TB/s.  Here sigmoid(logit) is parked transposed,
+// [cout][TM + 8] f16, and leaves as 16-byte pieces of 8 consecutive anchors of one y row (falling back to single
+// elements for a piece that straddles two images or starts on an odd boundary).
+template <int TM, int TN, int MT, int NT, int NTHR>
+__device__ __forceinline__ void conv_epilogue_cls_lds(const ConvK& p, f32x16 (&acc)[NT][MT], half_t* stile, int m0, int n0,
+                                                      int wm, int wn, int lrow, int lh, int tid) {
+    constexpr int LDP = TM + 8;  // padded row of the transposed tile (halves)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int prow = (wm * MT + b) * 32 + lrow;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int cl = (wn * NT + a) * 32;
+            if (n0 + cl >= p.Cout) continue;  // wave-uniform; bias is padded to CoutPad only
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cl + 8 * g + 4 * lh;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[a][b][4 * g + e] + bv[e];
+                    stile[(c + e) * LDP + prow] = (half_t)(1.0f / (1.0f + __expf(-v)));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int hw = p.OH * p.OW;
+    half_t* y = reinterpret_cast<half_t*>(p.y);
+    constexpr int GPR = TM / 8;  // 8-anchor pieces per cout row
+    for (int id = tid; id < TN * GPR; id += NTHR) {
+        const int cr = id / GPR, g8 = (id - cr * GPR) * 8;
+        const int c = n0 + cr, m = m0 + g8;
+        if (c >= p.Cout || m >= p.M) continue;
+        const int n = m / hw, pix = m - n * hw;
+        const size_t yi = ((size_t)n * p.nrows + 4 + c) * p.A + p.a0 + pix;
+        if (pix + 8 <= hw && m + 8 <= p.M && !(yi & 7)) {
+            *reinterpret_cast<half8*>(y + yi) = *reinterpret_cast<const half8*>(stile + cr * LDP + g8);
+        } else {
+            for (int e = 0; e < 8 && m + e < p.M; ++e) {
+                const int me = m + e, ne = me / hw, pe = me - ne * hw;
+                y[((size_t)ne * p.nrows + 4 + c) * p.A + p.a0 + pe] = stile[cr * LDP + g8 + e];
+            }
+        }
+    }
+}
+
 // Coalesced epilogue (fp16 outputs, Cout % 8 == 0): the accumulator layout (lane = pixel, 4 channels per register
 // group) makes every direct store touch 32 different pixel rows; for the HBM-bound 1x1 layers that store pattern was
 // the whole kernel (3x).  Instead: bias + SiLU in registers -> fp16 tile [TM][TN] in LDS (the DMA ring is free after
@@ -378,7 +426,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     constexpr int STAGE = (TM + TNS) * BK;  // halves per LDS stage
     constexpr int NDMA = PIW + WIW;         // DMA instructions per thread per K-step (identical for all waves)
     constexpr int SWS = BK == 32 ? 2 : 1;   // read-side swizzle: chunk ^ ((row >> SWS) & (CPR - 1))
-    constexpr int OTILE = TM * (TN + 8);    // fp16 output tile staged by the coalesced epilogue
+    constexpr int OTILE = (TM > TN ? TM : TN) * ((TM > TN ? TN : TM) + 8);  // fp16 output tile staged by the coalesced epilogues:
+                                                                             // [TM][TN + 8], or transposed [TN][TM + 8] (class scores)
     constexpr int SMEM = STAGES * STAGE > OTILE ? STAGES * STAGE : OTILE;
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
 
@@ -579,7 +628,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
         return;
     }
     if (p.epi) {  // fused Detect decoder
-        conv_epilogue_head<MT, NT>(p, acc, m0, n0, wm, wn, lrow, lh);
+        if (p.epi == 2 && !p.y_f32 && !p.raw) {
+            __syncthreads();  // every wave has finished reading the last K-step: LDS becomes the transposed score tile
+            conv_epilogue_cls_lds<TM, TN, MT, NT, NTHR>(p, acc, smem, m0, n0, wm, wn, lrow, lh, tid);
+        } else {
+            conv_epilogue_head<MT, NT>(p, acc, m0, n0, wm, wn, lrow, lh);
+        }
         return;
     }
     const bool lds_epi = !p.out_f32 && !(p.Cout & 7) && !(p.ldd & 7) && !((uintptr_t)p.dst & 15) && p.dst_scale == 1 &&
