@@ -268,6 +268,33 @@ int bsy_val_match(const float* det, int row, const int32_t* counts, int B, int m
                   const float* gt_cls, const int32_t* gt_counts, int Lmax, const float* iouv, int n_iou,
                   unsigned char* out, bsy_stream stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Sliced inference.  The reference reaches it through the un-vendored `sahi` package (detect-sahi.py:1-13
+ * sahi.predict.predict; examples/YOLOv8-SAHI-Inference-Video/yolov8_sahi.py:70-75 get_sliced_prediction); the two
+ * calls below replace sahi.slicing.slice_image + the predictor's preprocess of each crop, and
+ * sahi.postprocess.combine.{GreedyNMMPostprocess, NMSPostprocess} (algorithm of sahi 0.11.x, see oracle/sahi_ref.py).
+ *
+ * bsy_slice_tiles: img (H, W, 3) u8 DEVICE, rows `pitch` bytes apart, 4-byte aligned; boxes DEVICE int32 (T, 4) =
+ *   x0, y0, x1, y1 with x1 - x0 == tw, y1 - y0 == th (get_slice_bboxes keeps border slices full-size by shifting them
+ *   inwards; an image smaller than the slice goes through bsy_letterbox instead);  out (T, 3, th, tw) f16/f32 = pixel
+ *   / 255, channels reversed when swap_rb != 0.  tw % 4 == 0.
+ * bsy_sahi_merge: det (T, max_det, row >= 6) f32 rows [x1 y1 x2 y2 score cls ...] in TILE pixels + counts (T): the
+ *   layout bsy_nms writes;  shift (T, 2) f32 DEVICE = tile origin (x0, y0);  boxes are clamped to >= 0 and to
+ *   (full_w, full_h) when those are > 0, dropped unless x1 < x2 and y1 < y2, then shifted.
+ *   match_metric 0 = IOU, 1 = IOS; a lower-scored box joins the first kept box (score order, same class unless
+ *   class_agnostic) with metric >= match_threshold; do_merge != 0 (GREEDYNMM) folds members whose metric against the
+ *   growing merged box is > match_threshold into it (box union, max score), do_merge == 0 (NMS) only drops them.
+ *   out (max_out, 6) f32 in class-ascending (unless agnostic), score-descending keep order; out_count DEVICE int32 =
+ *   min(kept, max_out).  T * max_det <= 65536.  No host synchronisation.
+ * --------------------------------------------------------------------------------------------------------- */
+int bsy_slice_tiles(const uint8_t* img, int H, int W, int pitch, const int32_t* boxes, int T, int th, int tw,
+                    int swap_rb, void* out, int out_dtype, bsy_stream stream);
+size_t bsy_sahi_merge_workspace_bytes(int T, int max_det);
+int bsy_sahi_merge(const float* det, const int32_t* counts, const float* shift, int T, int max_det, int row,
+                   int match_metric, float match_threshold, int class_agnostic, int do_merge, float full_w,
+                   float full_h, float* out, int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes,
+                   bsy_stream stream);
+
 const char* bsy_last_error(void);
 int bsy_version(void);
 
