@@ -84,6 +84,11 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    # BSY_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow with several ranks on ONE GPU (RCCL refuses two ranks on
+    # one device); never a measurement
+    backend = os.environ.get("BSY_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("BSY_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
@@ -92,7 +97,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from bs_yolo_amd import lib as L
     from bs_yolo_amd import nms as HN
@@ -123,22 +128,31 @@ def main():
                 sd[k] = torch.full_like(sd[k], math.log(0.25 / 0.75) - q)
         eng.close()
         eng = YoloEngine(cfg, sd, device=local)
+    from bs_yolo_amd.parallel import gather_detections_async
+    pending = None   # the previous step's detection all-gather, in flight on RCCL's stream
     gathered = None
 
     def step():
-        nonlocal gathered
+        nonlocal pending, gathered
         y, _ = eng(x, want_raw=False)
         det, counts = HN.nms_batched(y, 0.25, 0.7, max_det=300)
         if use_dist:
-            if gathered is None:
-                gathered = (torch.empty((world,) + det.shape, dtype=det.dtype, device=dev),
-                            torch.empty((world,) + counts.shape, dtype=counts.dtype, device=dev))
-            dist.all_gather_into_tensor(gathered[0], det)
-            dist.all_gather_into_tensor(gathered[1], counts)
+            # ONE collective per step (counts packed behind the detections), overlapped with the NEXT step's forward:
+            # this step's kernels are already enqueued when the stream is ordered after the previous gather
+            if pending is not None:
+                gathered = pending.wait()
+            pending = gather_detections_async(det, counts)
         return det, counts
+
+    def drain():
+        nonlocal pending, gathered
+        if pending is not None:
+            gathered = pending.wait()
+            pending = None
 
     for _ in range(args.warmup):
         det, counts = step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -146,6 +160,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         det, counts = step()
+    drain()  # the last step's gather completes inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

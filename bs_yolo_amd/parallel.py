@@ -1,8 +1,9 @@
 """Multi-GPU sharding of the hot path: one process per GPU, images (or SAHI tiles) are independent units.
 
 The reference has no multi-device inference path (select_device picks one device; DDP is training-only,
-engine/trainer.py:217-224), so this is new: contiguous batch split + one all-gather of the fixed-size detection
-tensor and of the per-image counts (RCCL over xGMI on GPUs, gloo on CPU for tests).  Payload per rank is
+engine/trainer.py:217-224), so this is new: contiguous batch split + ONE all-gather per batch of the fixed-size detection
+tensor with the per-image counts packed behind it (RCCL over xGMI on GPUs, gloo on CPU for tests), which callers may
+overlap with the next batch's forward (gather_detections_async).  Payload per rank is
 B_local * max_det * (6+nm) * 4 bytes (460 KB at B_local=64) -- latency-bound, no reduce anywhere.
 """
 from __future__ import annotations
@@ -24,34 +25,58 @@ def shard_bounds(n_items: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def gather_detections(det: torch.Tensor, counts: torch.Tensor, n_items: Optional[int] = None, group=None):
-    """det (B_local, max_det, row) fp32, counts (B_local,) int32 on every rank -> (det_all (n_items, max_det, row),
-    counts_all (n_items,)) on every rank, in global item order.  Ranks may hold shards that differ by one item
-    (shard_bounds); shorter shards are padded for the collective and the padding dropped afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return det, counts
+class PendingGather:
+    """Handle of one in-flight detection all-gather: `wait()` -> (det_all, counts_all) in global item order."""
+
+    def __init__(self, work, packed_all, max_det, row, keep):
+        self._work, self._all, self._max_det, self._row, self._keep = work, packed_all, max_det, row, keep
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()  # GPU: the current stream waits for the collective, the host does not block
+            self._work = None
+        a = self._all
+        det_all = a[:, :-1].unflatten(1, (self._max_det, self._row))
+        cnt_all = a[:, -1].view(torch.int32)
+        if self._keep is not None:
+            det_all, cnt_all = det_all[self._keep], cnt_all[self._keep]
+        return det_all, cnt_all
+
+
+def gather_detections_async(det: torch.Tensor, counts: torch.Tensor, n_items: Optional[int] = None, group=None) -> PendingGather:
+    """Start the all-gather of det (B_local, max_det, row) fp32 + counts (B_local,) int32 and return at once.  ONE
+    collective per call: the counts travel as an extra fp32 word behind each item's detections (two latency-bound
+    collectives per step cost twice the ring latency), and the caller can overlap it with the next batch's forward --
+    the collective runs on RCCL's own stream; `wait()` orders the current stream after it.
+    Ranks may hold shards that differ by one item (shard_bounds); shorter shards are padded for the collective and the
+    padding dropped in `wait()`."""
+    b_local, max_det, row = det.shape
+    packed = torch.cat((det.reshape(b_local, max_det * row).float(),
+                        counts.to(torch.int32).reshape(b_local, 1).view(torch.float32)), 1)
+    if not (dist.is_available() and dist.is_initialized()):
+        return PendingGather(None, packed, max_det, row, None)
     world = dist.get_world_size(group)
-    b_local = det.shape[0]
     if n_items is None:
         n_items = b_local * world
     bounds = shard_bounds(n_items, world)
     b_max = max(e - s for s, e in bounds)
     assert b_local == bounds[dist.get_rank(group)][1] - bounds[dist.get_rank(group)][0], "shard size mismatch"
     if b_local < b_max:
-        det = torch.cat((det, det.new_zeros((b_max - b_local,) + det.shape[1:])))
-        counts = torch.cat((counts, counts.new_zeros(b_max - b_local)))
-    det_all = det.new_empty((world * b_max,) + det.shape[1:])
-    cnt_all = counts.new_empty(world * b_max)
-    if det.is_cuda:
-        dist.all_gather_into_tensor(det_all, det.contiguous(), group=group)
-        dist.all_gather_into_tensor(cnt_all, counts.contiguous(), group=group)
+        packed = torch.cat((packed, packed.new_zeros((b_max - b_local, packed.shape[1]))))
+    packed_all = packed.new_empty((world * b_max, packed.shape[1]))
+    if dist.get_backend(group) == "nccl":
+        work = dist.all_gather_into_tensor(packed_all, packed, group=group, async_op=True)
     else:  # gloo
-        dl = list(det_all.chunk(world))
-        cl = list(cnt_all.chunk(world))
-        dist.all_gather(dl, det.contiguous(), group=group)
-        dist.all_gather(cl, counts.contiguous(), group=group)
-        det_all, cnt_all = torch.cat(dl), torch.cat(cl)
-    if all(e - s == b_max for s, e in bounds):
-        return det_all, cnt_all
-    keep = torch.cat([torch.arange(k * b_max, k * b_max + (e - s)) for k, (s, e) in enumerate(bounds)]).to(det.device)
-    return det_all[keep], cnt_all[keep]
+        work = dist.all_gather(list(packed_all.chunk(world)), packed, group=group, async_op=True)
+    keep = None
+    if not all(e - s == b_max for s, e in bounds):
+        keep = torch.cat([torch.arange(k * b_max, k * b_max + (e - s)) for k, (s, e) in enumerate(bounds)]).to(det.device)
+    return PendingGather(work, packed_all, max_det, row, keep)
+
+
+def gather_detections(det: torch.Tensor, counts: torch.Tensor, n_items: Optional[int] = None, group=None):
+    """det (B_local, max_det, row) fp32, counts (B_local,) int32 on every rank -> (det_all (n_items, max_det, row),
+    counts_all (n_items,)) on every rank, in global item order (blocking form of gather_detections_async)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return det, counts
+    return gather_detections_async(det, counts, n_items, group).wait()

@@ -260,7 +260,7 @@ def test_shard_bounds():
 WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from bs_yolo_amd.parallel import gather_detections, shard_bounds
+from bs_yolo_amd.parallel import gather_detections, gather_detections_async, shard_bounds
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
 n_items = int(sys.argv[3])
@@ -277,6 +277,13 @@ assert torch.equal(d[:, 0, 0], torch.arange(n_items, dtype=torch.float32)), d[:,
 assert torch.equal(c, (torch.arange(n_items) % 5).to(torch.int32))
 exp_rank = torch.cat([torch.full((b - a,), float(k)) for k, (a, b) in enumerate(shard_bounds(n_items, world))])
 assert torch.equal(d[:, 0, 4], exp_rank)
+# two gathers in flight (bench.py overlaps the gather of step k with the forward of step k+1)
+h1 = gather_detections_async(det, counts, n_items)
+h2 = gather_detections_async(det + 1, counts + 1, n_items)
+d1, c1 = h1.wait()
+d2, c2 = h2.wait()
+assert torch.equal(d1, d) and torch.equal(c1, c) and torch.equal(d2, d + 1) and torch.equal(c2, c + 1)
+assert c2.dtype == torch.int32 and d2.shape == (n_items, 4, 6)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
