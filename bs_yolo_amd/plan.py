@@ -54,7 +54,7 @@ class T:
 class WRec:
     """How to pack one op's parameters into the weight blob (weights.py)."""
     name: str          # state_dict prefix, e.g. "model.2.m.0.cv1"  (Conv: .conv.weight + .bn.*; plain: .weight/.bias)
-    kind: str          # conv | plain | dw | first | deconv
+    kind: str          # conv | conv2 (name + post stacked along cout) | plain | dw | first | deconv
     cout: int
     cin: int
     k: int
@@ -90,13 +90,14 @@ class Plan:
 
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
-                 fuse_dwpw: Optional[bool] = None):
+                 fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
         self.fuse_head = (os.environ.get("BSY_FUSE_HEAD", "1") != "0") if fuse_head is None else bool(fuse_head)
         self.fuse_dwpw = (os.environ.get("BSY_FUSE_DWPW", "1") != "0") if fuse_dwpw is None else bool(fuse_dwpw)
+        self.merge_c3k = (os.environ.get("BSY_MERGE_C3K", "1") != "0") if merge_c3k is None else bool(merge_c3k)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -120,7 +121,9 @@ class Plan:
 
     def conv(self, name: str, src: Union[T, Sequence[T]], cout: int, k: int = 1, s: int = 1, act: bool = True,
              dst: Optional[T] = None, res: Optional[T] = None, plain: bool = False, out_f32: bool = False,
-             perm: Optional[List[int]] = None) -> T:
+             perm: Optional[List[int]] = None, name2: Optional[str] = None) -> T:
+        """name2: a second Conv module of the same input and kernel whose output channels follow this one's (weights.py
+        kind "conv2": the two folded weight matrices stacked along cout) -- one launch for both, cout = the total."""
         srcs = [src] if isinstance(src, T) else list(src)
         assert 1 <= len(srcs) <= 2, "at most two concat operands per conv"
         H, W = srcs[0].H, srcs[0].W
@@ -133,7 +136,11 @@ class Plan:
         assert dst.C == cout and dst.H == OH and dst.W == OW and dst.f32 == out_f32 and not dst.up
         if res is not None:
             assert res.C == cout and res.H == OH and res.W == OW and not res.up
-        key = self._wrec(name, name=name, kind="plain" if plain else "conv", cout=cout, cin=cin, k=k, perm=perm)
+        if name2 is not None:
+            assert not plain and perm is None and cout % 2 == 0
+            key = self._wrec(name + "+" + name2, name=name, kind="conv2", cout=cout, cin=cin, k=k, post=name2)
+        else:
+            key = self._wrec(name, name=name, kind="plain" if plain else "conv", cout=cout, cin=cin, k=k, perm=perm)
         self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
                              src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
                              act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane, cout=cout))
@@ -214,8 +221,14 @@ class Plan:
         """block.py:3320-3334 + :3807-3815: cv3(cat(m(cv1 x), cv2 x)), m = n x Bottleneck(c_, c_, k=(3,3), e=1)."""
         c_ = int(dst.C * 0.5)
         cat = self.alloc(2 * c_, x.H, x.W)
-        cur = self.conv(name + ".cv1", x, c_, 1, 1)
-        self.conv(name + ".cv2", x, c_, 1, 1, dst=cat.slice(c_, c_))
+        if self.merge_c3k and n >= 2:
+            # cv1 and cv2 read the same x: ONE launch writes [cv1 x | cv2 x] into the concat buffer (twice the cout per
+            # pixel tile, one launch less); the last bottleneck then overwrites the cv1 half, which only the first one reads
+            self.conv(name + ".cv1", x, 2 * c_, 1, 1, dst=cat, name2=name + ".cv2")
+            cur = cat.slice(0, c_)
+        else:
+            cur = self.conv(name + ".cv1", x, c_, 1, 1)
+            self.conv(name + ".cv2", x, c_, 1, 1, dst=cat.slice(c_, c_))
         for i in range(n):
             out = cat.slice(0, c_) if i == n - 1 else self.alloc(c_, x.H, x.W)
             self.bottleneck(f"{name}.m.{i}", cur, out, shortcut, (3, 3), 1.0)

@@ -62,9 +62,12 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
         wt, b = _f32(sd[r.name + ".weight"]), _f32(sd[r.name + ".bias"])
         dy, dx = r.tap
         w = wt[:, :, dy, dx].t().contiguous().view(r.cout, r.cin, 1, 1)
+    elif r.kind == "conv2":  # two Conv modules on the same input, stacked along cout (plan.py conv(name2=...))
+        (w, b), (w2, b2) = fold_conv_bn(sd, r.name, eps), fold_conv_bn(sd, r.post, eps)
+        w, b = torch.cat([w, w2]), torch.cat([b, b2])
     else:
         w, b = fold_conv_bn(sd, r.name, eps)
-    if r.kind in ("conv", "plain", "first", "deconv"):
+    if r.kind in ("conv", "conv2", "plain", "first", "deconv"):
         cout, cin, k = r.cout, r.cin, r.k
         assert tuple(w.shape) == (cout, cin, k, k), (r.name, tuple(w.shape), (cout, cin, k, k))
         if r.perm is not None:
@@ -181,9 +184,11 @@ def synth_state_dict(plan: Plan, seed: int = 0, cls_gain: float = 0.1, cls_bias:
             continue
         cin = 1 if r.kind == "dw" else r.cin
         fan = cin * r.k * r.k
-        sd[r.name + ".conv.weight"] = torch.randn(r.cout, cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
-        sd[r.name + ".bn.weight"] = torch.rand(r.cout, generator=g) * 0.6 + 0.7
-        sd[r.name + ".bn.bias"] = torch.rand(r.cout, generator=g) * 0.6 - 0.3
-        sd[r.name + ".bn.running_mean"] = torch.rand(r.cout, generator=g) * 0.6 - 0.3
-        sd[r.name + ".bn.running_var"] = torch.rand(r.cout, generator=g) + 0.5
+        # kind "conv2": two modules of half the width each, drawn in the order the unmerged plan draws them
+        for nm, co in (((r.name, r.cout // 2), (r.post, r.cout // 2)) if r.kind == "conv2" else ((r.name, r.cout),)):
+            sd[nm + ".conv.weight"] = torch.randn(co, cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
+            sd[nm + ".bn.weight"] = torch.rand(co, generator=g) * 0.6 + 0.7
+            sd[nm + ".bn.bias"] = torch.rand(co, generator=g) * 0.6 - 0.3
+            sd[nm + ".bn.running_mean"] = torch.rand(co, generator=g) * 0.6 - 0.3
+            sd[nm + ".bn.running_var"] = torch.rand(co, generator=g) + 0.5
     return sd

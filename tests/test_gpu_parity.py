@@ -558,7 +558,7 @@ def test_engine_tuned_fused_equals_plain_on_odd_shapes(scale, shape):
     P = R.synth_params(m, 2)
     cfg = stock_cfg("yolo11", scale)
     full = YoloEngine(cfg, P)
-    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_head=False, fuse_dwpw=False, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_head=False, fuse_dwpw=False, merge_c3k=False, autotune=False)
     B, H, W = shape
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * W)).half().to(DEV)
     yf, rf = full(x)
@@ -589,13 +589,14 @@ def test_engine_batch_independence_and_determinism():
 
 @pytest.mark.parametrize("scale", ["n", "s"])
 def test_engine_stem_fusion_is_bit_identical(scale):
-    """The OP_STEM / OP_BNECK plan (fused launches) returns exactly what the plan of plain convs returns."""
+    """The OP_STEM / OP_BNECK / OP_DWPW plan (fused launches, merged C3k branch convs) returns exactly what the plan of plain
+    convs returns."""
     m = R.Model("yolo11", scale, 80, "detect")
     P = R.synth_params(m, 0)
     cfg = stock_cfg("yolo11", scale)
     # autotune off: the tuner may pick kernels with different (equally valid) summation orders per plan
     fused = YoloEngine(cfg, P, fuse_stem=True, fuse_bneck=True, fuse_dwpw=True, autotune=False)
-    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False, autotune=False)
     x = torch.rand(2, 3, 160, 96, generator=torch.Generator().manual_seed(3)).half().to(DEV)
     pf, _ = fused.plan_for(2, 160, 96, torch.float16, torch.float16)
     pp, _ = plain.plan_for(2, 160, 96, torch.float16, torch.float16)

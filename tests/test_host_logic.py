@@ -59,7 +59,7 @@ def test_op_struct_layout():
 def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     """Dense-conv FLOPs per 640x640 image equal the reference graph (BASELINE.md section 2 / SURVEY 8d); the
     reference counts 81 dense convs for n/s because DFL is a 1x1 conv there (block.py:58-77), here it lives in decode."""
-    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False)
+    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False)
     dense = 0
     n = 0
     for o in p.ops:
@@ -70,6 +70,27 @@ def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     assert n == nconv
     assert abs(dense / 1e9 - gflops) < 0.01 * gflops
     assert p.meta["A"] == 8400 and p.meta["strides"] == [8.0, 16.0, 32.0]
+
+
+def test_c3k_branch_merge():
+    """C3k's cv1 and cv2 (same input) become one conv of twice the width writing the concat buffer; parameters, their
+    random draws and the packed rows are those of the two separate convs."""
+    from bs_yolo_amd.weights import pack_plan_weights, synth_state_dict
+    cfg = stock_cfg("yolo11", "s")
+    a, b = Plan(cfg, 1, 64, 64, merge_c3k=False), Plan(cfg, 1, 64, 64, merge_c3k=True)
+    assert len(a.ops) - len(b.ops) == 3 and a.flops == b.flops
+    merged = [o for o in b.ops if "+" in str(o.get("wkey", ""))]
+    assert [o["name"] for o in merged] == ["model.6.m.0.cv1", "model.8.m.0.cv1", "model.22.m.0.cv1"]
+    sa, sb = synth_state_dict(a, 0), synth_state_dict(b, 0)
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+    ba, bb = pack_plan_weights(a, sa), pack_plan_weights(b, sb)
+    ra1, ra2, rb = a.wrecs["model.6.m.0.cv1"], a.wrecs["model.6.m.0.cv2"], b.wrecs["model.6.m.0.cv1+model.6.m.0.cv2"]
+    c_, kp = ra1.cout, 128  # 1x1 over 128 input channels: rows of 128 halves
+    rows = lambda blob, off, n: blob[off: off + n * kp * 2]
+    assert rb.cout == 2 * c_ and rows(bb, rb.w_off, c_) == rows(ba, ra1.w_off, c_)
+    assert rows(bb, rb.w_off + c_ * kp * 2, c_) == rows(ba, ra2.w_off, c_)
+    assert bb[rb.b_off: rb.b_off + 4 * c_] == ba[ra1.b_off: ra1.b_off + 4 * c_]
+    assert bb[rb.b_off + 4 * c_: rb.b_off + 8 * c_] == ba[ra2.b_off: ra2.b_off + 4 * c_]
 
 
 def test_stem_fusion_peephole():
@@ -138,8 +159,8 @@ def test_plan_consumes_exactly_the_reference_parameters():
                 used |= {f"{r.name}.{s}" for s in ("ch_weight", "sp_weight", "res_weight", "ch_att.2.weight",
                                                    "spatial_conv.weight", "gn.weight", "gn.bias")}
             else:
-                used |= {r.name + ".conv.weight"} | {f"{r.name}.bn.{s}" for s in
-                                                     ("weight", "bias", "running_mean", "running_var")}
+                for nm in ((r.name, r.post) if r.kind == "conv2" else (r.name,)):
+                    used |= {nm + ".conv.weight"} | {f"{nm}.bn.{s}" for s in ("weight", "bias", "running_mean", "running_var")}
         assert used == want
         # every view stays inside its buffer and respects the kernels' alignment rules
         for o in p.ops:
