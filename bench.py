@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-runs", type=int, default=2)
+    ap.add_argument("--cpu-runs", type=int, default=20, help="CPU baseline sample: runs of --cpu-batch images (~10 s in all)")
     return ap.parse_args()
 
 
@@ -67,6 +67,8 @@ def cpu_baseline(args, cfg_sd):
             y, _ = m.forward(P, x)
             PP.non_max_suppression(y, 0.25, 0.7)
         dt = time.perf_counter() - t0
+    if args.cpu_runs <= 0:
+        return None
     return {"value": round(args.cpu_batch * args.cpu_runs / dt, 3), "unit": "images/sec", "cores": cores,
             "kind": "port",
             "sample": f"{args.cpu_runs} x batch {args.cpu_batch} {NAMES[args.family]}{args.scale} {args.imgsz}x{args.imgsz} fp32 "
