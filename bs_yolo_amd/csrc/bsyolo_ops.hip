@@ -243,6 +243,212 @@ int launch_gap(const half_t* src, int lds_, int B, int H, int W, int C, half_t* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// MSCAAttention's spatial part in one launch (nn/Addmodules/MSCA.py:53-75): attn = conv0(x) (5 x 5), the four strip-conv
+// branches attn_i = conv{i}_2(conv{i}_1(attn)) (1 x k then k x 1, k = 5 / 7 / 11 / 21; `dilconv` folded into conv{i}_2 at
+// pack time) and gap(attn_i).  Everything is depthwise, so a workgroup owns (image, 8 channels) and keeps that H x W
+// slab in LDS: x, attn and the row-conv intermediate never reach HBM and the nine conv launches + four pooling launches
+// of the unfused plan (0.39 ms of BS-YOLO11s' 4.8 ms forward at 20 x 20 x 512, B = 64) become one that reads the map
+// once and writes the four branch maps.  Arithmetic is that of dwconv_win_kernel / gap_kernel step for step (bias first,
+// taps in (dy, dx) order as f32 FMAs, f16 rounding of every intermediate map, the same strided partial sums and LDS
+// tree for the mean), so the results are bit-identical to the unfused plan.  H * W <= MSCA_SP_MAXPIX (covers the 40 x 40
+// level of a 1280-pixel input; larger maps keep the separate launches).
+// ---------------------------------------------------------------------------------------------------------------------
+struct MscaSpK {
+    const half_t* src;
+    int lds, HW, H, W, C;
+    const float* w[9];  // conv0, conv0_1, conv0_2, conv1_1, conv1_2, conv2_1, conv2_2, conv3_1, conv3_2: [taps][C]
+    const float* b[9];
+    half_t* br[4];
+    int ldb[4];
+    half_t* gap[4];
+    int ldg[4];
+};
+
+// attn and the row-conv intermediate live in LDS as f32 copies of their f16-rounded values, so the 88 strip taps per
+// element cost one 8-byte LDS read + one packed FMA per channel PAIR and no conversions.  A thread owns one channel pair
+// (tid & 3) of the pixels slot, slot + 64, .. (slot = tid >> 2): the taps' weights of its pair stay in registers across
+// the pixel loop (2 K floats; with all 8 channels per thread the 21-tap strips spill), and 1600 items over 256 threads
+// leave 11 % of the lanes idle instead of 22 %.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 msca_round2(f32x2 a, half2_t& o) {  // f16 rounding of a map element, kept as f32
+    o[0] = (half_t)a[0]; o[1] = (half_t)a[1];
+    return f32x2{(float)o[0], (float)o[1]};
+}
+
+// Tap t of conv number ci (0 = conv0, 1 + 2 i / 2 + 2 i = row / column conv of branch i) sits at row MSCA_TAP0[ci] + t of
+// the LDS weight table sw[122][8] (f32; rows 113 .. 121 = the nine biases): staged once per workgroup, then every phase
+// pulls the 2 K floats of its channel pair into registers with immediate-offset LDS reads.  (Read from global memory
+// the compiler keeps one 64-bit address per tap alive for all nine convs: 380 VGPRs.)
+#define MSCA_NTAP 113
+__device__ __constant__ const int MSCA_TAP0[9] = {0, 25, 30, 35, 42, 49, 60, 71, 92};
+
+// (Measured alternatives, same results, all slower than this form's 0.23 ms at 20 x 20 x 512, B = 64: zero-bordered slabs
+// without bounds tests -- 72 KiB of LDS, two workgroups per CU instead of three: 0.25 ms; 512 threads with two pixels in
+// flight per thread: 0.29 ms; eight channels per thread on f16 slabs: 0.26 ms.  The kernel is bound by its ~50 barriers
+// and the dependent FMA chains of the reference's summation order, not by instruction count.)
+#define MSCA_SP_MAXPIX 1890  // (16 + 32 + 32) B x H*W + 8 KiB of reduction scratch + 4 KiB of weights <= 160 KiB of LDS
+
+// One strip-conv branch: st = rows(sa) (1 x K), branch = cols(st) (K x 1) -> HBM; gs[m] = this thread's share of
+// gap_kernel's partial sum number slot + 64 m (pixels q with q % 256 == slot + 64 m, ascending).
+template <int K, int T0>
+__device__ __forceinline__ void msca_branch(const MscaSpK& p, int bi, const f32x2* sa, f32x2* st, const f32x2* sw, int c2,
+                                            int n, int slot, int pr, int y0, int x0, int sy, int sx_, f32x2 (&gs)[4]) {
+    constexpr int R = K / 2;
+    const int H = p.H, W = p.W, HW = p.HW;
+    {
+        f32x2 wr[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) wr[t] = sw[(T0 + t) * 4 + pr];
+        const f32x2 br = sw[(MSCA_NTAP + 1 + 2 * bi) * 4 + pr];
+        int y = y0, x = x0;
+        for (int q = slot; q < HW; q += 64) {
+            f32x2 acc = br;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const int ix = x + dx - R;
+                const f32x2 v = (unsigned)ix < (unsigned)W ? sa[(q + dx - R) * 4 + pr] : f32x2{0.f, 0.f};
+                acc = __builtin_elementwise_fma(v, wr[dx], acc);
+            }
+            half2_t o;
+            st[q * 4 + pr] = msca_round2(acc, o);
+            x += sx_; y += sy;
+            if (x >= W) { x -= W; ++y; }
+        }
+    }
+    __syncthreads();
+    {
+        f32x2 wc[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) wc[t] = sw[(T0 + K + t) * 4 + pr];
+        const f32x2 bc = sw[(MSCA_NTAP + 2 + 2 * bi) * 4 + pr];
+        int y = y0, x = x0, m = 0;
+        for (int q = slot; q < HW; q += 64, m = (m + 1) & 3) {
+            f32x2 acc = bc;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy) {
+                const int iy = y + dy - R;
+                const f32x2 v = (unsigned)iy < (unsigned)H ? st[(q + (dy - R) * W) * 4 + pr] : f32x2{0.f, 0.f};
+                acc = __builtin_elementwise_fma(v, wc[dy], acc);
+            }
+            half2_t o;
+            const f32x2 r = msca_round2(acc, o);
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)  // (m is not a compile-time index)
+                if (mm == m) gs[mm] += r;
+            *reinterpret_cast<half2_t*>(p.br[bi] + ((size_t)n * HW + q) * p.ldb[bi] + c2) = o;
+            x += sx_; y += sy;
+            if (x >= W) { x -= W; ++y; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void msca_spatial_kernel(const MscaSpK p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char msca_smem[];
+    f32x2* sa = reinterpret_cast<f32x2*>(msca_smem);                  // attn  [HW][4 pairs]
+    f32x2* st = sa + (size_t)p.HW * 4;                                 // row-conv output
+    half2_t* sx = reinterpret_cast<half2_t*>(st + (size_t)p.HW * 4);  // x [HW][4 pairs]
+    float(*red)[8] = reinterpret_cast<float(*)[8]>(sx + (size_t)p.HW * 4);
+    f32x2* sw = reinterpret_cast<f32x2*>(red + 256);                   // weight table [122][4 pairs]
+    const int c = blockIdx.x * 8, n = blockIdx.y, tid = threadIdx.x;
+    const int pr = tid & 3, slot = tid >> 2, c2 = c + 2 * pr;
+    const int H = p.H, W = p.W, HW = p.HW, C = p.C;
+    // pixel walk of this thread: q = slot, slot + 64, ..  (one division per thread instead of one per pixel and phase)
+    const int y0 = slot / W, x0 = slot - y0 * W, sy = 64 / W, sx_ = 64 - sy * W;
+
+    for (int q = tid; q < HW; q += 256)
+        *reinterpret_cast<half8*>(sx + (size_t)q * 4) = *reinterpret_cast<const half8*>(p.src + ((size_t)n * HW + q) * p.lds + c);
+    for (int e = tid; e < (MSCA_NTAP + 9) * 2; e += 256) {  // 16-byte pieces of the weight table
+        const int row = e >> 1, h4 = (e & 1) * 4;
+        const float* g;
+        if (row >= MSCA_NTAP) {
+            g = p.b[row - MSCA_NTAP] + c + h4;
+        } else {
+            int ci = 0;
+#pragma unroll
+            for (int k = 1; k < 9; ++k) ci += row >= MSCA_TAP0[k];
+            g = p.w[ci] + (size_t)(row - MSCA_TAP0[ci]) * C + c + h4;
+        }
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(sw) + row * 8 + h4) = *reinterpret_cast<const f32x4*>(g);
+    }
+    __syncthreads();
+    {   // attn = conv0(x): 5 x 5
+        f32x2 w0[25];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) w0[t] = sw[t * 4 + pr];
+        const f32x2 b0 = sw[MSCA_NTAP * 4 + pr];
+        int y = y0, x = x0;
+        for (int q = slot; q < HW; q += 64) {
+            f32x2 acc = b0;
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) {
+                const int iy = y + dy - 2;
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) {
+                    const int ix = x + dx - 2;
+                    half2_t h = half2_t{0, 0};
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) h = sx[(q + (dy - 2) * W + dx - 2) * 4 + pr];
+                    acc = __builtin_elementwise_fma(f32x2{(float)h[0], (float)h[1]}, w0[dy * 5 + dx], acc);
+                }
+            }
+            half2_t o;
+            sa[q * 4 + pr] = msca_round2(acc, o);
+            x += sx_; y += sy;
+            if (x >= W) { x -= W; ++y; }
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+        f32x2 gs[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+        if (i == 0) msca_branch<5, 25>(p, 0, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
+        else if (i == 1) msca_branch<7, 35>(p, 1, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
+        else if (i == 2) msca_branch<11, 49>(p, 2, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
+        else msca_branch<21, 71>(p, 3, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {  // gap_kernel's 256 strided partial sums, then its tree
+            red[slot + 64 * m][2 * pr] = gs[m][0];
+            red[slot + 64 * m][2 * pr + 1] = gs[m][1];
+        }
+        __syncthreads();  // also: every thread is done reading st
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (tid < s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[tid][j] += red[tid + s2][j];
+            __syncthreads();
+        }
+        if (tid < 8) p.gap[i][(size_t)n * p.ldg[i] + c + tid] = (half_t)(red[0][tid] / (float)HW);
+        __syncthreads();
+    }
+}
+
+bool msca_spatial_supported(int H, int W) { return H > 0 && W > 0 && H * W <= MSCA_SP_MAXPIX; }
+
+int launch_msca_spatial(const MscaSpArgs& a, hipStream_t s) {
+    if (!msca_spatial_supported(a.H, a.W)) BSY_FAIL(BSY_ERR_ARG, "msca_spatial: %d x %d map does not fit LDS (H*W <= %d)", a.H, a.W, MSCA_SP_MAXPIX);
+    if (!a.src || (a.C & 7) || (a.lds & 7) || ((uintptr_t)a.src & 15) || a.B <= 0) BSY_FAIL(BSY_ERR_ARG, "msca_spatial: bad source layout");
+    MscaSpK k;
+    k.src = a.src; k.lds = a.lds; k.H = a.H; k.W = a.W; k.HW = a.H * a.W; k.C = a.C;
+    for (int i = 0; i < 9; ++i) {
+        if (!a.w[i] || !a.b[i] || ((uintptr_t)a.w[i] & 15) || ((uintptr_t)a.b[i] & 15)) BSY_FAIL(BSY_ERR_ARG, "msca_spatial: weight %d missing / misaligned", i);
+        k.w[i] = a.w[i]; k.b[i] = a.b[i];
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (!a.br[i] || !a.gap[i] || (a.ldb[i] & 7) || ((uintptr_t)a.br[i] & 15) || a.ldg[i] < a.C) BSY_FAIL(BSY_ERR_ARG, "msca_spatial: bad output %d", i);
+        k.br[i] = a.br[i]; k.ldb[i] = a.ldb[i]; k.gap[i] = a.gap[i]; k.ldg[i] = a.ldg[i];
+    }
+    const size_t smem = (size_t)k.HW * 80 + 256 * 8 * 4 + (MSCA_NTAP + 9) * 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)msca_spatial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MSCA_SP_MAXPIX * 80 + 8192 + (MSCA_NTAP + 9) * 32));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(msca_spatial_kernel, dim3(a.C / 8, a.B), dim3(256), smem, s, k);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // MSCA branch mix: weight_i[n, c] = softmax over i of sigmoid(logit_i[n, c]); out = sum_i weight_i * branch_i
 // ---------------------------------------------------------------------------------------------------------------------
 struct MixK {

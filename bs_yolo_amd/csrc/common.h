@@ -122,6 +122,18 @@ struct DwGenArgs {       // depthwise kh x kw, stride 1 / 2, "same" padding, + b
 int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s);
 int launch_copy_view(const half_t* src, int lds_, int up, int B, int H, int W, int C, half_t* dst, int ldd, hipStream_t s);
 int launch_gap(const half_t* src, int lds_, int B, int H, int W, int C, half_t* out, int ldo, hipStream_t s);
+struct MscaSpArgs {
+    const half_t* src;
+    int lds, B, H, W, C;
+    const float* w[9];  // conv0, conv0_1, conv0_2, conv1_1, conv1_2, conv2_1, conv2_2, conv3_1, conv3_2
+    const float* b[9];
+    half_t* br[4];
+    int ldb[4];
+    half_t* gap[4];
+    int ldg[4];
+};
+bool msca_spatial_supported(int H, int W);
+int launch_msca_spatial(const MscaSpArgs& a, hipStream_t s);
 struct MixArgs {
     const half_t* br[4];
     int ldb[4];

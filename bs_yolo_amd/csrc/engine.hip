@@ -203,6 +203,21 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok) return BSY_ERR_ARG;
             return launch_gap(src, op.src0.ld, op.B, op.H, op.W, op.src0.C, dst, op.dst.ld, s);
         }
+        case BSY_OP_MSCA_SPATIAL: {
+            MscaSpArgs a;
+            a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C;
+            for (int i = 0; i < 9; ++i) {
+                a.w[i] = (const float*)(wb + op.aux_off[2 * i]);
+                a.b[i] = (const float*)(wb + op.aux_off[2 * i + 1]);
+            }
+            for (int i = 0; i < 4; ++i) {
+                const bsy_view& bv = i < 3 ? op.box[i] : op.res;
+                const bsy_view& gv = i < 3 ? op.cls[i] : op.msk[0];
+                a.br[i] = R.h(bv); a.ldb[i] = bv.ld; a.gap[i] = R.h(gv); a.ldg[i] = gv.ld;
+            }
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_msca_spatial(a, s);
+        }
         case BSY_OP_MSCA_MIX: {
             MixArgs a;
             for (int i = 0; i < 4; ++i) {

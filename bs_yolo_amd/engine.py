@@ -21,7 +21,7 @@ class YoloEngine:
     def __init__(self, cfg: dict, state_dict: Mapping[str, torch.Tensor], device: int = 0, bn_eps: float = BN_EPS,
                  autotune: Optional[bool] = None, fuse_stem: Optional[bool] = None,
                  fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None, fuse_dwpw: Optional[bool] = None,
-                 merge_c3k: Optional[bool] = None):
+                 merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
@@ -38,8 +38,9 @@ class YoloEngine:
         self.fuse_head = fuse_head
         self.fuse_dwpw = fuse_dwpw
         self.merge_c3k = merge_c3k
+        self.fuse_msca = fuse_msca
         self._packed = Plan(cfg, 1, 64, 64, fuse_stem=fuse_stem, fuse_bneck=fuse_bneck, fuse_head=fuse_head, fuse_dwpw=fuse_dwpw,
-                            merge_c3k=merge_c3k)
+                            merge_c3k=merge_c3k, fuse_msca=fuse_msca)
         blob = pack_plan_weights(self._packed, state_dict, bn_eps)
         self.weight_bytes = len(blob)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
@@ -58,7 +59,7 @@ class YoloEngine:
         if H % 32 or W % 32:
             raise ValueError(f"input {H}x{W} must be a multiple of the max stride 32 (utils/checks.py:120-172)")
         plan = Plan(self.cfg, B, H, W, L.dtype_code(in_dtype), L.dtype_code(out_dtype), fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head,
-                    fuse_dwpw=self.fuse_dwpw, merge_c3k=self.merge_c3k)
+                    fuse_dwpw=self.fuse_dwpw, merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca)
         adopt_offsets(plan, self._packed)
         ops = plan.c_ops()
         sizes = (C.c_int64 * len(plan.buf_bytes))(*plan.buf_bytes)

@@ -16,7 +16,7 @@ LIB_PATH = PKG / "libbsyolo_hip.so"
 
 BSY_F16, BSY_F32, BSY_U8 = 0, 1, 2
 BSY_EXT_BASE = 0x100000
-(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW) = range(17)
+(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW, OP_MSCA_SPATIAL) = range(18)
 
 SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_destroy",
@@ -57,6 +57,7 @@ class Op(C.Structure):
         ("lane", C.c_int32), ("tuned_cfg", C.c_int32), ("join", C.c_int32),
         ("mid_c", C.c_int32),
         ("w2_off", C.c_int64), ("b2_off", C.c_int64),
+        ("aux_off", C.c_int64 * 18),
     ]
 
 

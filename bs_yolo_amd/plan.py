@@ -72,6 +72,11 @@ def stem_supported(c0: int, c1: int, H: int, W: int) -> bool:
     return (c0, c1) in ((32, 64), (16, 32)) and W % 4 == 0 and H >= 4 and W >= 4
 
 
+def msca_spatial_supported(H: int, W: int) -> bool:
+    """Maps whose (H x W x 8 channel) slabs fit LDS (mirror of csrc/bsyolo_ops.hip msca_spatial_supported)."""
+    return H > 0 and W > 0 and H * W <= 1890
+
+
 def dwpw_supported(c: int, cout: int) -> bool:
     """Widths dwpw_fused_kernel accepts (mirror of bsy_dwpw_fused_supported)."""
     return c > 0 and c % 32 == 0 and c <= 256 and cout % 8 == 0
@@ -90,7 +95,7 @@ class Plan:
 
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
-                 fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None):
+                 fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
@@ -98,6 +103,7 @@ class Plan:
         self.fuse_head = (os.environ.get("BSY_FUSE_HEAD", "1") != "0") if fuse_head is None else bool(fuse_head)
         self.fuse_dwpw = (os.environ.get("BSY_FUSE_DWPW", "1") != "0") if fuse_dwpw is None else bool(fuse_dwpw)
         self.merge_c3k = (os.environ.get("BSY_MERGE_C3K", "1") != "0") if merge_c3k is None else bool(merge_c3k)
+        self.fuse_msca = (os.environ.get("BSY_FUSE_MSCA", "1") != "0") if fuse_msca is None else bool(fuse_msca)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -291,15 +297,33 @@ class Plan:
         folded into their weights; the four SE convs run on (B, 1, 1, C) maps through the ordinary 1x1 conv kernel."""
         assert not x.up
         C, H, W = x.C, x.H, x.W
-        attn = self.dwconv_g(name + ".conv0", x, 5, 5, 1, 0, kind="dwg_plain")
+        strips = ((5, "conv0"), (7, "conv1"), (11, "conv2"), (21, "conv3"))
         branches, logits = [], []
-        for i, (k, base) in enumerate(((5, "conv0"), (7, "conv1"), (11, "conv2"), (21, "conv3"))):
-            a = self.dwconv_g(f"{name}.{base}_1", attn, 1, k, 1, 0, kind="dwg_plain")
-            a = self.dwconv_g(f"{name}.{base}_2", a, k, 1, 1, 0, kind="dwg_plain", post=(name + ".dilconv") if i < 3 else None)
-            branches.append(a)
-            g = self.alloc(C, 1, 1)
-            self.ops.append(dict(kind=L.OP_GAP, H=H, W=W, OH=1, OW=1, src0=a, dst=g, name=f"{name}.gap{i}", lane=self._lane))
-            logits.append(self.conv(f"{name}.SE{i + 1}.conv.0", g, C, 1, 1, act=False, plain=True, out_f32=True))
+        if self.fuse_msca and msca_spatial_supported(H, W):
+            # one launch for the nine depthwise convs and the four global means (csrc/bsyolo_ops.hip msca_spatial_kernel)
+            keys = [self._wrec(name + ".conv0", name=name + ".conv0", kind="dwg_plain", cout=C, cin=1, k=5, kw=5)]
+            for i, (k, base) in enumerate(strips):
+                keys.append(self._wrec(f"{name}.{base}_1", name=f"{name}.{base}_1", kind="dwg_plain", cout=C, cin=1, k=1, kw=k))
+                keys.append(self._wrec(f"{name}.{base}_2", name=f"{name}.{base}_2", kind="dwg_plain", cout=C, cin=1, k=k, kw=1,
+                                       post=(name + ".dilconv") if i < 3 else None))
+                se = f"{name}.SE{i + 1}.conv.0"  # registered here so the records keep the unfused plan's order (blob layout,
+                self._wrec(se, name=se, kind="plain", cout=C, cin=C, k=1, perm=None)  # synth_state_dict's random draws)
+            branches = [self.alloc(C, H, W) for _ in strips]
+            gaps = [self.alloc(C, 1, 1) for _ in strips]
+            self.ops.append(dict(kind=L.OP_MSCA_SPATIAL, H=H, W=W, OH=H, OW=W, src0=x, box=branches[:3], res=branches[3],
+                                 cls=gaps[:3], msk=[gaps[3]], wkeys=keys, name=name + ".spatial", lane=self._lane))
+            self.flops += 2 * self.B * H * W * C * (25 + 2 * sum(k for k, _ in strips))
+            for i, g in enumerate(gaps):
+                logits.append(self.conv(f"{name}.SE{i + 1}.conv.0", g, C, 1, 1, act=False, plain=True, out_f32=True))
+        else:
+            attn = self.dwconv_g(name + ".conv0", x, 5, 5, 1, 0, kind="dwg_plain")
+            for i, (k, base) in enumerate(strips):
+                a = self.dwconv_g(f"{name}.{base}_1", attn, 1, k, 1, 0, kind="dwg_plain")
+                a = self.dwconv_g(f"{name}.{base}_2", a, k, 1, 1, 0, kind="dwg_plain", post=(name + ".dilconv") if i < 3 else None)
+                branches.append(a)
+                g = self.alloc(C, 1, 1)
+                self.ops.append(dict(kind=L.OP_GAP, H=H, W=W, OH=1, OW=1, src0=a, dst=g, name=f"{name}.gap{i}", lane=self._lane))
+                logits.append(self.conv(f"{name}.SE{i + 1}.conv.0", g, C, 1, 1, act=False, plain=True, out_f32=True))
         mix = self.alloc(C, H, W)
         self.ops.append(dict(kind=L.OP_MSCA_MIX, H=H, W=W, OH=H, OW=W, dst=mix, box=branches[:3], res=branches[3], cls=logits[:3],
                              msk=[logits[3]], name=name + ".mix", lane=self._lane))
@@ -602,6 +626,10 @@ class Plan:
                 assert w.w_off >= 0, "pack weights before serialising"
                 o.w2_off, o.b2_off = w.w_off, w.b_off
             o.mid_c = d.get("mid_c", 0)
+            for j, k in enumerate(d.get("wkeys", [])):
+                w = self.wrecs[k]
+                assert w.w_off >= 0, "pack weights before serialising"
+                o.aux_off[2 * j], o.aux_off[2 * j + 1] = w.w_off, w.b_off
             if d["kind"] == L.OP_ELA:
                 cf = self.wrecs[d["wkey"]].coef
                 d = dict(d, scale=cf[0], lvl_stride=[cf[1], cf[2]])

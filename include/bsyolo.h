@@ -77,6 +77,10 @@ enum bsy_op_kind {
     BSY_OP_MUL = 14,       /* dst = src0 * src1 elementwise                                                             */
     BSY_OP_DWPW = 16,      /* DWConv 3x3 (+SiLU) -> Conv 1x1 (+act) as one launch (YOLO11 class branch, head.py:49-57):
                             * src0 (C channels) -> dst; w_off/b_off = depthwise f32 [9][C] / [C], w2_off/b2_off = 1x1    */
+    BSY_OP_MSCA_SPATIAL = 17, /* MSCAAttention's depthwise part in one launch (nn/Addmodules/MSCA.py:53-75): src0 -> the four
+                            * strip-conv branch maps box[0..2] + res and their global means cls[0..2] + msk[0] ((B,1,1,C) f16);
+                            * aux_off = (w, b) byte offsets of conv0, conv0_1, conv0_2, conv1_1, .. conv3_2 (f32 [taps][C] /
+                            * [C], `dilconv` folded into conv{0,1,2}_2).  H * W <= 1890                                  */
     BSY_OP_ELA = 15        /* ELA (nn/Addmodules/ELA.py:77-101): ksize = Conv1d taps; w_off -> f32 blob [spatial_conv C*k]
                             * [ch_att conv C*k][gn.weight C][gn.bias C]; scale, lvl_stride[0], lvl_stride[1] =
                             * sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight);
@@ -117,6 +121,7 @@ typedef struct bsy_op {
     int32_t join;           /* 1: every side stream is joined back into lane 0 before this op */
     int32_t mid_c;          /* STEM / BNECK: channels of the fused-away intermediate map */
     int64_t w2_off, b2_off; /* STEM / BNECK: second conv's weights / bias (byte offsets into the weight blob) */
+    int64_t aux_off[18];    /* MSCA_SPATIAL: (weights, bias) byte offsets of its nine depthwise convs */
 } bsy_op;
 
 int bsy_engine_create(int device, bsy_engine** out);

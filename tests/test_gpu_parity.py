@@ -612,6 +612,29 @@ def test_engine_stem_fusion_is_bit_identical(scale):
     plain.close()
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 160), (1, 640, 640), (3, 64, 64), (1, 1280, 1280)])
+def test_engine_msca_spatial_fusion_is_bit_identical(shape):
+    """BS-YOLO: the one-launch MSCAAttention spatial part (nine depthwise convs + four global means out of LDS) returns
+    exactly what the thirteen separate launches return -- on 3 x 5, 20 x 20, 2 x 2 and 40 x 40 attention maps."""
+    m = R.Model("bsyolo11", "n", 12, "detect")
+    P = R.synth_params(m, 3)
+    cfg = stock_cfg("bsyolo11", "n", 12)
+    fused = YoloEngine(cfg, P, fuse_msca=True, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_msca=False, autotune=False)
+    B, H, W = shape
+    pf, _ = fused.plan_for(B, H, W, torch.float16, torch.float16)
+    pp, _ = plain.plan_for(B, H, W, torch.float16, torch.float16)
+    assert sum(o["kind"] == L.OP_MSCA_SPATIAL for o in pf.ops) == 1 and len(pp.ops) - len(pf.ops) == 12
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV)
+    yf, rf = fused(x)
+    yp, rp = plain(x)
+    assert torch.equal(yf, yp)
+    for a, b in zip(rf, rp):
+        assert torch.equal(a, b)
+    fused.close()
+    plain.close()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 def test_engine_fused_decoder_matches_decode_kernel(dtype):
     """Detect._inference (head.py:113-148) fused into the last conv of every head branch (conv_epilogue_head) against the
