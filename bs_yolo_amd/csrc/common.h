@@ -213,6 +213,29 @@ int launch_nhwc2nchw(const half_t* src, int ld, int B, int C, int hw, void* out,
 int launch_raw_nchw(const float* box, int ldb, const float* cls, int ldc, int B, int h, int w, int nc, void* out,
                     int out_dtype, hipStream_t s);
 
+// acc + f32(h) * w with ONE instruction per element: v_fma_mix_f32 reads the f16 operand (low / high half of a packed
+// register) directly, so a depthwise tap costs 8 VALU issues per 8 channels instead of 8 v_cvt_f32_f16 + 4 v_pk_fma_f32
+// (and packed f32 math is the slower choice beside MFMAs).  Same value as fmaf((float)h, w, acc): the conversion is exact.
+__device__ __forceinline__ float fma_mix_lo(unsigned hpair, float w, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(w), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned hpair, float w, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(w), "v"(acc));
+    return r;
+}
+// a[0..7] += f32(v[0..7]) * (w0, w1)
+__device__ __forceinline__ void fma_mix8(float (&a)[8], const half8& v, const f32x4& w0, const f32x4& w1) {
+    union { half8 h; unsigned u[4]; } x;
+    x.h = v;
+    a[0] = fma_mix_lo(x.u[0], w0[0], a[0]); a[1] = fma_mix_hi(x.u[0], w0[1], a[1]);
+    a[2] = fma_mix_lo(x.u[1], w0[2], a[2]); a[3] = fma_mix_hi(x.u[1], w0[3], a[3]);
+    a[4] = fma_mix_lo(x.u[2], w1[0], a[4]); a[5] = fma_mix_hi(x.u[2], w1[1], a[5]);
+    a[6] = fma_mix_lo(x.u[3], w1[2], a[6]); a[7] = fma_mix_hi(x.u[3], w1[3], a[7]);
+}
+
 // SiLU in fp32: x * sigmoid(x) = x / (1 + 2^(-x*log2 e)); v_exp_f32 + v_rcp_f32 (1 ulp each) -- the result is rounded
 // to fp16 right after, so the IEEE-division expansion (~10 VALU) would buy nothing.  exp2 overflow -> inf -> rcp -> 0.
 __device__ __forceinline__ float silu_f(float x) {

@@ -1227,11 +1227,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
                     for (int it = 0; it < 2; ++it) {
                         // item 1 = item 0 + 72 entries: (q >> 2) & 3 changes by 2 (72 / 4 = 18) -> slot ^ 2
                         const half8 v = *reinterpret_cast<const half8*>(sP + (it ? ((tapoff[k] + 72 * 32) ^ 16) : tapoff[k]));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            a[it][j] = fmaf((float)v[j], w0[j], a[it][j]);
-                            a[it][4 + j] = fmaf((float)v[4 + j], w1[j], a[it][4 + j]);
-                        }
+                        fma_mix8(a[it], v, w0, w1);
                     }
                 }
 #pragma unroll
