@@ -29,6 +29,7 @@ SOURCES = {
     "letterbox.hip": ["-ffp-contract=off"],
     "masks.hip": ["-ffp-contract=off"],
     "val_match.hip": ["-ffp-contract=off"],
+    "val_ap.hip": ["-ffp-contract=off"],
     "sahi.hip": ["-ffp-contract=off"],
     "engine.hip": [],
 }

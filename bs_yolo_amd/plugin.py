@@ -146,6 +146,29 @@ def install_val_metrics(validator):
     return validator
 
 
+def install_ap_per_class(metrics_module, device="cuda:0"):
+    """metrics_module = ultralytics.utils.metrics: `ap_per_class` (:620-706, called by Metric / DetMetrics.process :940) goes
+    to the device implementation when no plots are asked for (the plotting path stays the reference's own)."""
+    from . import val as _val
+    orig = metrics_module.ap_per_class
+    if getattr(orig, "_bsy", False):
+        return orig
+
+    def ap_per_class(tp, conf, pred_cls, target_cls, plot=False, on_plot=None, save_dir=None, names={}, eps=1e-16, prefix=""):
+        n = len(conf)
+        if plot or not torch.cuda.is_available() or n == 0 or n > (1 << 20) or getattr(tp, "ndim", 2) != 2 or tp.shape[1] > 16:
+            kw = dict(plot=plot, on_plot=on_plot, names=names, eps=eps, prefix=prefix)
+            if save_dir is not None:
+                kw["save_dir"] = save_dir
+            return orig(tp, conf, pred_cls, target_cls, **kw)
+        return _val.ap_per_class(tp, conf, pred_cls, target_cls, eps=eps, device=device)
+
+    ap_per_class._bsy = True
+    ap_per_class._bsy_orig = orig
+    metrics_module.ap_per_class = ap_per_class
+    return ap_per_class
+
+
 def install_preprocess(predictor):
     """predictor = a BasePredictor instance whose model is already set up."""
     from . import letterbox as _lb

@@ -273,6 +273,19 @@ int bsy_val_match(const float* det, int row, const int32_t* counts, int B, int m
                   const float* gt_cls, const int32_t* gt_counts, int Lmax, const float* iouv, int n_iou,
                   unsigned char* out, bsy_stream stream);
 
+/* ap_per_class + compute_ap (utils/metrics.py:620-706, :588-617) without the plots and the max-F1 pick (host side).
+ * tp (N, T) uint8, conf (N) f32 in [0, 1], pred_cls (N) f32 -- the concatenated statistics DetectionValidator.get_stats
+ * (models/yolo/detect/val.py:160-170) hands to DetMetrics.process; classes / nt: DEVICE (nc) = np.unique(target_cls,
+ * return_counts=True); x101 / x1000: DEVICE np.linspace(0, 1, 101 / 1000).  Outputs (float64, DEVICE): ap (nc, T),
+ * p_curve / r_curve / prec_values (nc, 1000), n_pred (nc) int32 = detections of each class (rows of classes with
+ * n_pred == 0 stay zero; the reference appends a prec_values row only for classes with predictions).
+ * N <= 2^20, T <= 16, class ids 0 .. 4094.  Ties in conf: lower index first (np.argsort's order there is unpinned). */
+size_t bsy_ap_workspace_bytes(int N, int T);
+int bsy_ap_per_class(const uint8_t* tp, const float* conf, const float* pred_cls, int N, int T, const int32_t* classes,
+                     const int32_t* nt, int nc, const double* x101, const double* x1000, double eps, double* ap, double* p_curve,
+                     double* r_curve, double* prec_values, int32_t* n_pred, void* workspace, size_t workspace_bytes,
+                     bsy_stream stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Sliced inference.  The reference reaches it through the un-vendored `sahi` package (detect-sahi.py:1-13
  * sahi.predict.predict; examples/YOLOv8-SAHI-Inference-Video/yolov8_sahi.py:70-75 get_sliced_prediction); the two

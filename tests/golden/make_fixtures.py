@@ -418,10 +418,47 @@ def letterbox_fixtures():
     print("wrote letterbox", len(cases), "geometry cases,", len(pix), "pixel cases")
 
 
+def ap_fixtures():
+    """Known answers of the reference's ap_per_class (utils/metrics.py:620-706, with compute_ap :588-617) on synthetic
+    detection statistics: tp (N, 10) bool, conf (N) float32 (all distinct: numpy's unstable argsort leaves ties unpinned),
+    pred_cls (N), target_cls (M).  Cases cover classes without predictions / without labels and a single detection."""
+    from ultralytics.utils.metrics import ap_per_class
+    rng = np.random.default_rng(5)
+    out, cases = {}, []
+    for ci, (n, m, ncls, hit) in enumerate([(400, 120, 5, 0.7), (5000, 900, 80, 0.5), (1, 3, 2, 1.0), (60, 40, 12, 0.2), (3000, 500, 3, 0.9)]):
+        conf = rng.permutation(np.linspace(0.05, 0.999, n)).astype(np.float32)
+        pred_cls = rng.integers(0, ncls, n).astype(np.float32)
+        target_cls = rng.integers(0, ncls + 2, m).astype(np.float32)   # two classes have labels but no predictions
+        if ci == 3:
+            pred_cls[pred_cls == 4] = 30.0                              # a predicted class without labels
+        base = rng.random(n) < hit * conf                               # better-scored detections are right more often
+        tp = np.stack([base & (rng.random(n) < 1.0 - 0.08 * j) for j in range(10)], 1)
+        tp = np.logical_and.accumulate(tp, 1)                           # a hit at IoU t is a hit at every lower threshold
+        for c in np.unique(pred_cls):                                   # a label is matched at most once: <= n_l hits per class
+            n_l = int((target_cls == c).sum())
+            idx = np.nonzero(pred_cls == c)[0]
+            idx = idx[np.argsort(-conf[idx])]
+            for j in range(10):
+                hits = idx[tp[idx, j]]
+                tp[hits[n_l:], j] = False
+        r = ap_per_class(tp, conf, pred_cls, target_cls, plot=False)
+        names = ["tp", "fp", "p", "r", "f1", "ap", "unique_classes", "p_curve", "r_curve", "f1_curve", "x", "prec_values"]
+        for k, v in zip(names, r):
+            out[f"c{ci}.out.{k}"] = np.asarray(v)
+        out[f"c{ci}.tp"], out[f"c{ci}.conf"], out[f"c{ci}.pred_cls"], out[f"c{ci}.target_cls"] = tp, conf, pred_cls, target_cls
+        cases.append(ci)
+    out["cases"] = json.dumps(cases)
+    np.savez_compressed(HERE / "ap_per_class.npz", **out)
+    print("wrote ap_per_class", len(cases), "cases")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "val":  # only the validator-matching vectors
         val_match_fixtures()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ap":  # only the ap_per_class vectors
+        ap_fixtures()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bsyolo":  # only the BS-YOLO graph vectors (added after the stock set)
         graph_fixture("bsyolo11n_detect", "bsyolo11", "n", "detect", [(2, 64, 64), (1, 96, 160)], nc=12, keep_layers=True)

@@ -715,6 +715,35 @@ def test_val_match_golden_and_random():
 # ------------------------------------------------------------------------------------------------------------
 # NMS: bit-exact against the oracle (and the reference's golden outputs)
 # ------------------------------------------------------------------------------------------------------------
+def test_ap_per_class_golden_and_large():
+    """bs_yolo_amd.val.ap_per_class (csrc/val_ap.hip, float64) against the REFERENCE's own ap_per_class outputs
+    (tests/golden/ap_per_class.npz) -- every one of the 12 returned arrays within 1e-12 -- and against the oracle on
+    200 000 detections of 80 classes (class segments longer than any workgroup pass, confidence ties included)."""
+    from bs_yolo_amd import val as HV
+    from oracle import val_ref as V
+    z = np.load(GOLDEN / "ap_per_class.npz")
+    names = ["tp", "fp", "p", "r", "f1", "ap", "unique_classes", "p_curve", "r_curve", "f1_curve", "x", "prec_values"]
+    for ci in json.loads(str(z["cases"])):
+        got = HV.ap_per_class(z[f"c{ci}.tp"], z[f"c{ci}.conf"], z[f"c{ci}.pred_cls"], z[f"c{ci}.target_cls"], device=DEV)
+        for k, g in zip(names, got):
+            want = z[f"c{ci}.out.{k}"]
+            assert np.asarray(g).shape == want.shape, (ci, k, np.asarray(g).shape, want.shape)
+            np.testing.assert_allclose(np.asarray(g, dtype=np.float64), want.astype(np.float64), rtol=0, atol=1e-12, err_msg=f"case {ci} {k}")
+    rng = np.random.default_rng(6)
+    n, m, ncls = 200_000, 30_000, 80
+    conf = np.round(rng.uniform(0.001, 1.0, n), 4).astype(np.float32)      # ~20 detections share every confidence value
+    pred_cls = rng.integers(0, ncls, n).astype(np.float32)
+    target_cls = rng.integers(0, ncls, m).astype(np.float32)
+    tp = np.logical_and.accumulate(np.stack([rng.random(n) < 0.1 * conf * (1.0 - 0.07 * j) for j in range(10)], 1), 1)
+    want = V.ap_per_class(tp, conf, pred_cls, target_cls)
+    got = HV.ap_per_class(torch.from_numpy(tp).to(DEV), torch.from_numpy(conf).to(DEV), torch.from_numpy(pred_cls).to(DEV), target_cls, device=DEV)
+    for k, g, w in zip(names, got, want):
+        np.testing.assert_allclose(np.asarray(g, dtype=np.float64), np.asarray(w, dtype=np.float64), rtol=0, atol=1e-12, err_msg=k)
+    # no detections / no labels
+    e = HV.ap_per_class(np.zeros((0, 10), bool), np.zeros(0, np.float32), np.zeros(0, np.float32), np.array([1.0, 1.0, 3.0]), device=DEV)
+    assert e[5].shape == (2, 10) and not e[5].any() and e[11].shape == (0, 1000) and list(e[6]) == [1, 3]
+
+
 def _nms_compare(pred, kw):
     ref_in = pred.clone()
     ref = PP.non_max_suppression(ref_in, **kw)

@@ -238,3 +238,18 @@ def test_resize_linear_properties():
     half = LB.resize_linear_u8(img[:36, :52], (26, 18))  # exact 2x -> box mean
     s = img[:36, :52].astype(np.int32)
     assert np.array_equal(half, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2))
+
+
+def test_ap_per_class_golden():
+    """oracle.val_ref.ap_per_class against the reference's own ap_per_class outputs (tests/golden/ap_per_class.npz, written by
+    make_fixtures.py `ap`): AP per class and threshold, the 1000-point P / R / F1 / precision-at-0.5 curves, the max-F1 operating
+    point.  Tolerance 1e-12 (float64; np.trapz sums pairwise, the restatement sequentially)."""
+    from oracle import val_ref as V
+    z = np.load(GOLDEN / "ap_per_class.npz")
+    names = ["tp", "fp", "p", "r", "f1", "ap", "unique_classes", "p_curve", "r_curve", "f1_curve", "x", "prec_values"]
+    for ci in json.loads(str(z["cases"])):
+        got = V.ap_per_class(z[f"c{ci}.tp"], z[f"c{ci}.conf"], z[f"c{ci}.pred_cls"], z[f"c{ci}.target_cls"])
+        for k, g in zip(names, got):
+            want = z[f"c{ci}.out.{k}"]
+            assert np.asarray(g).shape == want.shape, (ci, k, np.asarray(g).shape, want.shape)
+            np.testing.assert_allclose(np.asarray(g, dtype=np.float64), want.astype(np.float64), rtol=0, atol=1e-12, err_msg=f"case {ci} {k}")
