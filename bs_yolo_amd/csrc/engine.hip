@@ -29,8 +29,9 @@ struct bsy_plan {
     // side streams ("lanes") for independent op chains + the events that fork / join them
     std::vector<hipStream_t> lanes;      // index 0 unused (lane 0 = caller's stream)
     std::vector<hipEvent_t> lane_done;   // per lane: recorded at its tail before a join
+    std::vector<hipEvent_t> lane_fork;   // per lane: recorded on the caller's stream where the lane forks (one event per lane:
+                                         // an event that still has a waiter pending is never re-recorded)
     float last_event_overhead_ms = 0.f;  // bsy_plan_profile: median empty event interval of the last call
-    hipEvent_t fork_ev = nullptr;
 };
 
 extern "C" int bsy_engine_create(int device, bsy_engine** out) {
@@ -91,13 +92,15 @@ extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, cons
     }
     int max_lane = 0;
     for (const auto& o : p->ops) max_lane = o.lane > max_lane ? o.lane : max_lane;
-    if (max_lane > 32) { (void)hipFree(p->workspace); delete p; BSY_FAIL(BSY_ERR_ARG, "plan_create: too many lanes"); }
+    if (max_lane > 31) { (void)hipFree(p->workspace); delete p; BSY_FAIL(BSY_ERR_ARG, "plan_create: too many lanes"); }
     p->lanes.assign(max_lane + 1, nullptr);
     p->lane_done.assign(max_lane + 1, nullptr);
-    bool ok = hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming) == hipSuccess;
+    p->lane_fork.assign(max_lane + 1, nullptr);
+    bool ok = true;
     for (int l = 1; l <= max_lane && ok; ++l)
         ok = hipStreamCreateWithFlags(&p->lanes[l], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&p->lane_fork[l], hipEventDisableTiming) == hipSuccess;
     if (!ok) { bsy_plan_destroy(p); BSY_FAIL(BSY_ERR_HIP, "plan_create: stream/event creation failed"); }
     *out = p;
     return BSY_OK;
@@ -108,7 +111,7 @@ extern "C" void bsy_plan_destroy(bsy_plan* p) {
     for (auto ev : p->events) (void)hipEventDestroy(ev);
     for (auto ev : p->lane_done) if (ev) (void)hipEventDestroy(ev);
     for (auto st : p->lanes) if (st) (void)hipStreamDestroy(st);
-    if (p->fork_ev) (void)hipEventDestroy(p->fork_ev);
+    for (auto ev : p->lane_fork) if (ev) (void)hipEventDestroy(ev);
     if (p->workspace) (void)hipFree(p->workspace);
     delete p;
 }
@@ -361,8 +364,8 @@ extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream
         if (op.lane > 0) {
             s = p->lanes[op.lane];
             if (!(active & (1u << op.lane))) {
-                HIP_TRY(hipEventRecord(p->fork_ev, main));
-                HIP_TRY(hipStreamWaitEvent(s, p->fork_ev, 0));
+                HIP_TRY(hipEventRecord(p->lane_fork[op.lane], main));
+                HIP_TRY(hipStreamWaitEvent(s, p->lane_fork[op.lane], 0));
                 active |= 1u << op.lane;
             }
         }

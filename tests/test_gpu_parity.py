@@ -612,6 +612,35 @@ def test_engine_stem_fusion_is_bit_identical(scale):
     plain.close()
 
 
+def test_engine_bsyolo_large_input_matches_oracle():
+    """BS-YOLO11n on a 1024 x 1280 input (the golden graphs stop at 96 x 160): 128 x 160 ELA rows / columns, a 32 x 40 MSCA
+    map through the one-launch spatial kernel, depthwise windows over 256 x 320 maps -- against the oracle with the engine's
+    storage precision: raw maps within 2 % of their range, decoded outputs by mean error (see below), reruns bit-identical."""
+    m = R.Model("bsyolo11", "n", 12, "detect")
+    P = R.synth_params(m, 1)
+    x = torch.rand(1, 3, 1024, 1280, generator=torch.Generator().manual_seed(77))
+    eng = YoloEngine(stock_cfg("bsyolo11", "n", 12), P, autotune=False)
+    y, raws = eng(x.half().to(DEV))
+    y2, _ = eng(x.half().to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    R.FP16_EMULATION = True
+    try:
+        with torch.inference_mode():
+            yq, rq = m.forward(P, x.half().float())
+    finally:
+        R.FP16_EMULATION = False
+    for a, b in zip(raws, rq):
+        assert (a.float().cpu() - b).abs().max() < 2e-2 * b.abs().max(), (a.float().cpu() - b).abs().max() / b.abs().max()
+    # Decoded outputs: with these synthetic weights the graph amplifies fp16 storage rounding at this size -- the CPU
+    # fp16-emulating oracle itself is 0.21 (scores) / 37 px (boxes) off the fp32 oracle on 1.8 % of the 26 880 anchors, mean
+    # 0.07 px -- so the bar is statistical: mean errors and the share of anchors that moved.
+    d = (y.float().cpu() - yq).abs()
+    moved = (d[:, :4].amax(1) > 3.0).float().mean()
+    assert d[:, 4:].mean() < 1e-3 and d[:, :4].mean() < 0.2 and moved < 0.05, (d[:, 4:].mean(), d[:, :4].mean(), moved)
+    eng.close()
+
+
 @pytest.mark.parametrize("shape", [(2, 96, 160), (1, 640, 640), (3, 64, 64), (1, 1280, 1280)])
 def test_engine_msca_spatial_fusion_is_bit_identical(shape):
     """BS-YOLO: the one-launch MSCAAttention spatial part (nine depthwise convs + four global means out of LDS) returns
