@@ -32,6 +32,7 @@ struct bsy_plan {
     std::vector<hipEvent_t> lane_fork;   // per lane: recorded on the caller's stream where the lane forks (one event per lane:
                                          // an event that still has a waiter pending is never re-recorded)
     float last_event_overhead_ms = 0.f;  // bsy_plan_profile: median empty event interval of the last call
+    size_t guard = 0;                    // bytes of guard band behind every buffer (BSY_PLAN_GUARD)
 };
 
 extern "C" int bsy_engine_create(int device, bsy_engine** out) {
@@ -72,12 +73,18 @@ extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, cons
     bsy_plan* p = new bsy_plan();
     p->eng = e;
     p->ops.assign(ops, ops + n_ops);
+    // BSY_PLAN_GUARD=<bytes> (test aid): a guard band of that many bytes, filled with 0xA5, behind every buffer;
+    // bsy_plan_check_guards reports the first band a kernel wrote into (an out-of-bounds store).
+    {
+        const char* g = getenv("BSY_PLAN_GUARD");
+        p->guard = g ? ((size_t)atoll(g) + 255) & ~(size_t)255 : 0;
+    }
     size_t off = 0;
     for (int i = 0; i < n_bufs; ++i) {
         if (buf_bytes[i] < 0) { delete p; BSY_FAIL(BSY_ERR_ARG, "plan_create: negative buffer size"); }
         p->buf_off.push_back(off);
         p->buf_size.push_back((size_t)buf_bytes[i]);
-        off += ((size_t)buf_bytes[i] + 255) & ~(size_t)255;
+        off += (((size_t)buf_bytes[i] + 255) & ~(size_t)255) + p->guard;
     }
     p->workspace_bytes = off + 256;
     if (hipMalloc((void**)&p->workspace, p->workspace_bytes) != hipSuccess) {
@@ -90,6 +97,12 @@ extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, cons
         delete p;
         BSY_FAIL(BSY_ERR_HIP, "plan_create: hipMemset failed");
     }
+    for (int i = 0; i < n_bufs && p->guard; ++i)
+        if (hipMemset(p->workspace + p->buf_off[i] + ((p->buf_size[i] + 255) & ~(size_t)255), 0xA5, p->guard) != hipSuccess) {
+            (void)hipFree(p->workspace);
+            delete p;
+            BSY_FAIL(BSY_ERR_HIP, "plan_create: guard memset failed");
+        }
     int max_lane = 0;
     for (const auto& o : p->ops) max_lane = o.lane > max_lane ? o.lane : max_lane;
     if (max_lane > 31) { (void)hipFree(p->workspace); delete p; BSY_FAIL(BSY_ERR_ARG, "plan_create: too many lanes"); }
@@ -103,6 +116,28 @@ extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, cons
              hipEventCreateWithFlags(&p->lane_fork[l], hipEventDisableTiming) == hipSuccess;
     if (!ok) { bsy_plan_destroy(p); BSY_FAIL(BSY_ERR_HIP, "plan_create: stream/event creation failed"); }
     *out = p;
+    return BSY_OK;
+}
+
+// Test aid: synchronises the device and checks the guard bands (plans created under BSY_PLAN_GUARD).  Returns BSY_OK and
+// *bad_buf = -1 when every band is intact, else the index of the first buffer whose band was written and the byte offset
+// of the first damaged byte inside the band.
+extern "C" int bsy_plan_check_guards(bsy_plan* p, int32_t* bad_buf, int64_t* bad_off) {
+    if (!p || !bad_buf) BSY_FAIL(BSY_ERR_ARG, "plan_check_guards: bad argument");
+    *bad_buf = -1;
+    if (bad_off) *bad_off = 0;
+    if (!p->guard) return BSY_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned char> host(p->guard);
+    for (size_t i = 0; i < p->buf_off.size(); ++i) {
+        HIP_TRY(hipMemcpy(host.data(), p->workspace + p->buf_off[i] + ((p->buf_size[i] + 255) & ~(size_t)255), p->guard, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < p->guard; ++k)
+            if (host[k] != 0xA5) {
+                *bad_buf = (int32_t)i;
+                if (bad_off) *bad_off = (int64_t)k;
+                return BSY_OK;
+            }
+    }
     return BSY_OK;
 }
 

@@ -140,6 +140,18 @@ class YoloEngine:
         L.check(L.lib.bsy_plan_profile(h, ext, n, C.c_void_p(stream), ms))
         return [(o["name"], o["kind"], float(t)) for o, t in zip(plan.ops, ms)], plan
 
+    def check_guards(self):
+        """Test aid (engines created with BSY_PLAN_GUARD=<bytes> set): [(plan key, buffer index, byte offset, op names that
+        write that buffer)] for every plan with a damaged guard band -- empty when no kernel stored out of bounds."""
+        bad = []
+        for key, (plan, h) in self._plans.items():
+            b, off = C.c_int32(-1), C.c_int64(0)
+            L.check(L.lib.bsy_plan_check_guards(h, C.byref(b), C.byref(off)))
+            if b.value >= 0:
+                writers = [o["name"] for o in plan.ops for k in ("dst", "res") if o.get(k) is not None and getattr(o[k], "buf", -1) == b.value and k == "dst"]
+                bad.append((key[:3], b.value, off.value, writers))
+        return bad
+
     def read_view(self, plan, h, t) -> torch.Tensor:
         """Debug/test aid: copy an activation view back as a (B, C, H, W) fp32 CPU tensor."""
         hs, ws = (t.H // 2, t.W // 2) if t.up else (t.H, t.W)

@@ -140,6 +140,10 @@ int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
 int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
 /* HOST out[n_ops]: configuration id per op (tile << 4 | variant), -1 for non-conv / untuned ops. */
 int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n_ops);
+/* Test aid: plans created with BSY_PLAN_GUARD=<bytes> in the environment keep a guard band of that many bytes (0xA5) behind
+ * every workspace buffer; this call synchronises the device and reports the first buffer whose band was written (an
+ * out-of-bounds store), *bad_buf = -1 when all are intact. */
+int bsy_plan_check_guards(bsy_plan* p, int32_t* bad_buf, int64_t* bad_off);
 /* Debug/test aid: synchronous copy of one workspace buffer to HOST memory (bytes <= the buffer's size). */
 int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes);
 /* Per-op device time (ms): runs the plan once with a HIP event recorded after every op on `stream`, syncs.  The cost of

@@ -572,6 +572,28 @@ def test_engine_tuned_fused_equals_plain_on_odd_shapes(scale, shape):
     plain.close()
 
 
+@pytest.mark.parametrize("fam,scale,nc,task,shapes", [
+    ("yolo11", "s", 80, "detect", [(2, 640, 640), (1, 1280, 1280), (3, 64, 96), (1, 32, 32)]),
+    ("yolo11", "n", 80, "segment", [(2, 320, 320), (1, 160, 96)]),
+    ("yolov8", "s", 80, "detect", [(2, 320, 640)]),
+    ("bsyolo11", "n", 12, "detect", [(1, 1024, 1024), (2, 96, 160)]),
+])
+def test_engine_no_out_of_bounds_stores(fam, scale, nc, task, shapes, monkeypatch):
+    """Every workspace buffer gets a 4 KiB guard band (BSY_PLAN_GUARD, a test aid of bsy_plan_create): after tuned and
+    un-tuned forwards on whole, ragged and tiny maps no kernel of the plan has stored outside its destination."""
+    from bs_yolo_amd.plan import Plan
+    from bs_yolo_amd.weights import synth_state_dict
+    monkeypatch.setenv("BSY_PLAN_GUARD", "4096")
+    cfg = stock_cfg(fam, scale, nc, task)
+    sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
+    for tune in (False, True):
+        eng = YoloEngine(cfg, sd, autotune=tune)
+        for B, H, W in shapes:
+            eng(torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV))
+        assert eng.check_guards() == []
+        eng.close()
+
+
 def test_engine_batch_independence_and_determinism():
     """Images are independent units: a batch equals its images run one by one; reruns are bit-identical."""
     m = R.Model("yolo11", "n", 80, "detect")
