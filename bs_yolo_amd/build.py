@@ -14,18 +14,20 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libbsyolo_hip.so"
 ARCH = "gfx950"
-# per-file extra flags: NMS / letterbox decisions must round exactly like the fp32 CPU reference (no FMA contraction)
+# per-file extra flags: NMS / letterbox decisions must round exactly like the fp32 CPU reference (no FMA contraction);
+# -fno-slp-vectorize: files whose kernels convert f16 operands and then do f32 arithmetic -- the SLP-packed form
+# (v_cvt_f32_f16 SDWA -> v_pk_*_f32) returned wrong odd elements beside MFMA kernels of other streams (csrc/common.h)
 SOURCES = {
     "err.cpp": [],
     "conv_mfma.hip": [],
     "conv_first.hip": [],
     "stem_fused.hip": [],
     "bneck_fused.hip": [],
-    "bsyolo_ops.hip": [],
-    "elementwise.hip": [],
+    "bsyolo_ops.hip": ["-fno-slp-vectorize"],
+    "elementwise.hip": ["-fno-slp-vectorize"],
     "attention.hip": [],
     "detect.hip": [],
-    "nms.hip": ["-ffp-contract=off"],
+    "nms.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "letterbox.hip": ["-ffp-contract=off"],
     "masks.hip": ["-ffp-contract=off"],
     "val_match.hip": ["-ffp-contract=off"],

@@ -67,11 +67,7 @@ __global__ __launch_bounds__(256) void dwconv_generic_kernel(const half_t* __res
             const half8 v = bo_load16(rs, off);
             const float* wp = w + (size_t)(dy * kw + dx) * wld + c;
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[j] = fmaf((float)v[j], w0[j], acc[j]);
-                acc[4 + j] = fmaf((float)v[4 + j], w1[j], acc[4 + j]);
-            }
+            fma_mix8(acc, v, w0, w1);  // v_fma_mix_f32 per element (common.h)
         }
     }
     half8 o;
@@ -129,12 +125,7 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const half_t* __restric
             const float* wp = w + (size_t)(dy * KW + dx) * wld + c;
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-            for (int p = 0; p < DWG_PX; ++p)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[p][j] = fmaf((float)win[p * S + dx][j], w0[j], acc[p][j]);
-                    acc[p][4 + j] = fmaf((float)win[p * S + dx][4 + j], w1[j], acc[p][4 + j]);
-                }
+            for (int p = 0; p < DWG_PX; ++p) fma_mix8(acc[p], win[p * S + dx], w0, w1);  // v_fma_mix_f32 per element (common.h)
         }
     }
 #pragma unroll
@@ -273,8 +264,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 msca_round2(f32x2 a, half2_t& o) {  // f16 rounding of a map element, kept as f32
-    o[0] = (half_t)a[0]; o[1] = (half_t)a[1];
-    return f32x2{(float)o[0], (float)o[1]};
+    const half_t o0 = (half_t)a[0], o1 = (half_t)a[1];  // converted back from two separate registers (no SDWA half select)
+    o[0] = o0; o[1] = o1;
+    return f32x2{(float)o0, (float)o1};
 }
 
 // Tap t of conv number ci (0 = conv0, 1 + 2 i / 2 + 2 i = row / column conv of branch i) sits at row MSCA_TAP0[ci] + t of
@@ -336,7 +328,7 @@ __device__ __forceinline__ void msca_branch(const MscaSpK& p, int bi, const f32x
             const f32x2 r = msca_round2(acc, o);
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm)  // (m is not a compile-time index)
-                if (mm == m) gs[mm] += r;
+                if (mm == m) { gs[mm][0] += r[0]; gs[mm][1] += r[1]; }
             *reinterpret_cast<half2_t*>(p.br[bi] + ((size_t)n * HW + q) * p.ldb[bi] + c2) = o;
             x += sx_; y += sy;
             if (x >= W) { x -= W; ++y; }
@@ -387,9 +379,11 @@ __global__ __launch_bounds__(256) void msca_spatial_kernel(const MscaSpK p) {
 #pragma unroll
                 for (int dx = 0; dx < 5; ++dx) {
                     const int ix = x + dx - 2;
-                    half2_t h = half2_t{0, 0};
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) h = sx[(q + (dy - 2) * W + dx - 2) * 4 + pr];
-                    acc = __builtin_elementwise_fma(f32x2{(float)h[0], (float)h[1]}, w0[dy * 5 + dx], acc);
+                    union { half2_t h; unsigned u; } hv;
+                    hv.u = 0u;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv.h = sx[(q + (dy - 2) * W + dx - 2) * 4 + pr];
+                    acc[0] = fma_mix_lo(hv.u, w0[dy * 5 + dx][0], acc[0]);  // no convert + packed FMA here (common.h)
+                    acc[1] = fma_mix_hi(hv.u, w0[dy * 5 + dx][1], acc[1]);
                 }
             }
             half2_t o;

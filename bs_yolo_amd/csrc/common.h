@@ -213,6 +213,11 @@ int launch_nhwc2nchw(const half_t* src, int ld, int B, int C, int hw, void* out,
 int launch_raw_nchw(const float* box, int ldb, const float* cls, int ldc, int B, int h, int w, int nc, void* out,
                     int out_dtype, hipStream_t s);
 
+// WHY these exist (round 1): the natural form `fmaf((float)h[j], w[j], a[j])` compiles to
+// v_cvt_f32_f16 (SDWA WORD_1 for the odd elements) feeding SLP-packed v_pk_fma_f32 -- and that sequence returned wrong
+// odd elements, sporadically, whenever MFMA kernels of another stream shared the CUs (SCDown's depthwise conv: 26 of 48
+// forwards; 0 of 48 with packing off).  Depthwise kernels therefore use v_fma_mix_f32 (no conversion, no packing) and
+// their files are built with -fno-slp-vectorize (build.py).
 // acc + f32(h) * w with ONE instruction per element: v_fma_mix_f32 reads the f16 operand (low / high half of a packed
 // register) directly, so a depthwise tap costs 8 VALU issues per 8 channels instead of 8 v_cvt_f32_f16 + 4 v_pk_fma_f32
 // (and packed f32 math is the slower choice beside MFMAs).  Same value as fmaf((float)h, w, acc): the conversion is exact.
@@ -225,6 +230,13 @@ __device__ __forceinline__ float fma_mix_hi(unsigned hpair, float w, float acc) 
     float r;
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(w), "v"(acc));
     return r;
+}
+// element J (compile-time) of a half8 register quadruple
+template <int J>
+__device__ __forceinline__ float fma_mix_e(const half8& v, float w, float acc) {
+    union { half8 h; unsigned u[4]; } x;
+    x.h = v;
+    return (J & 1) ? fma_mix_hi(x.u[J >> 1], w, acc) : fma_mix_lo(x.u[J >> 1], w, acc);
 }
 // a[0..7] += f32(v[0..7]) * (w0, w1)
 __device__ __forceinline__ void fma_mix8(float (&a)[8], const half8& v, const f32x4& w0, const f32x4& w1) {

@@ -37,6 +37,13 @@ __device__ __forceinline__ half8 dw_load16(dw_rsrc_t, unsigned) { return half8{0
 #endif
 #define DW_OOB 0xFFFFFFF0u
 
+// a[j] = fma(f32(v[j]), w[j], a[j]) for the 8 channels of a piece, one v_fma_mix_f32 each (same order per element as before:
+// top, mid, bot of column kw = 0, 1, 2)
+__device__ __forceinline__ void dw_fma8(float (&a)[8], const half8& v, const float (&w)[8]) {
+    a[0] = fma_mix_e<0>(v, w[0], a[0]); a[1] = fma_mix_e<1>(v, w[1], a[1]); a[2] = fma_mix_e<2>(v, w[2], a[2]); a[3] = fma_mix_e<3>(v, w[3], a[3]);
+    a[4] = fma_mix_e<4>(v, w[4], a[4]); a[5] = fma_mix_e<5>(v, w[5], a[5]); a[6] = fma_mix_e<6>(v, w[6], a[6]); a[7] = fma_mix_e<7>(v, w[7], a[7]);
+}
+
 template <bool ACT, bool RES>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict__ src, int lds_, int B, int H, int W,
                                                         int C, const float* __restrict__ w,
@@ -91,18 +98,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const half_t* __restrict
         load_row(y + 1, bot);
         float acc[DW_PX][8];
 #pragma unroll
-        for (int p = 0; p < DW_PX; ++p)
+        for (int p = 0; p < DW_PX; ++p) {
+            // v_fma_mix_f32 per element (common.h: the convert + packed-FMA form is not safe beside MFMA kernels)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float a = bs[j];
+            for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    a = fmaf((float)top[p + kw][j], wk[kw][j], a);
-                    a = fmaf((float)mid[p + kw][j], wk[3 + kw][j], a);
-                    a = fmaf((float)bot[p + kw][j], wk[6 + kw][j], a);
-                }
-                acc[p][j] = a;
+            for (int kw = 0; kw < 3; ++kw) {
+                dw_fma8(acc[p], top[p + kw], wk[kw]);
+                dw_fma8(acc[p], mid[p + kw], wk[3 + kw]);
+                dw_fma8(acc[p], bot[p + kw], wk[6 + kw]);
             }
+        }
 #pragma unroll
         for (int p = 0; p < DW_PX; ++p) {
             const int x = x0 + p;
