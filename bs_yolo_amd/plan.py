@@ -111,6 +111,10 @@ class Plan:
         self.meta: Dict = {}
         self._lane = 0
         self._build()
+        if os.environ.get("BSY_LANES", "1") == "0":  # test aid: every op on the caller's stream (a serial reference schedule)
+            for o in self.ops:
+                if "lane" in o:
+                    o["lane"] = 0
         assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK, L.OP_DWCONV_G, L.OP_DWPW) for o in self.ops)
 
     # ---- buffers -------------------------------------------------------------------------------------------
