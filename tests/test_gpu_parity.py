@@ -594,6 +594,31 @@ def test_engine_no_out_of_bounds_stores(fam, scale, nc, task, shapes, monkeypatc
         eng.close()
 
 
+@pytest.mark.parametrize("fam,scale,nc,shape", [("yolo11", "s", 80, (8, 640, 640)), ("bsyolo11", "n", 12, (2, 1024, 1024))])
+def test_engine_lanes_equal_serial_schedule(fam, scale, nc, shape, monkeypatch):
+    """The product schedule (Detect branches on six side streams, running beside each other) returns bit for bit what the
+    same plan returns with every op on one stream (BSY_LANES=0) -- 20 forwards.  (a depthwise kernel
+    whose f16 converts fed packed f32 FMAs failed exactly this kind of comparison.)"""
+    from bs_yolo_amd.plan import Plan
+    from bs_yolo_amd.weights import synth_state_dict
+    cfg = stock_cfg(fam, scale, nc)
+    sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
+    B, H, W = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(5)).half().to(DEV)
+    monkeypatch.setenv("BSY_LANES", "0")
+    ser = YoloEngine(cfg, sd, autotune=False)
+    y0, r0 = ser(x)
+    assert max(o.get("lane", 0) for o in ser.plan_for(B, H, W, torch.float16, torch.float16)[0].ops) == 0
+    monkeypatch.setenv("BSY_LANES", "1")
+    eng = YoloEngine(cfg, sd, autotune=False)
+    assert max(o.get("lane", 0) for o in eng.plan_for(B, H, W, torch.float16, torch.float16)[0].ops) >= 5
+    for _ in range(20):
+        y, r = eng(x)
+        assert torch.equal(y, y0) and all(torch.equal(a, b) for a, b in zip(r, r0))
+    eng.close()
+    ser.close()
+
+
 def test_engine_batch_independence_and_determinism():
     """Images are independent units: a batch equals its images run one by one; reruns are bit-identical."""
     m = R.Model("yolo11", "n", 80, "detect")
