@@ -14,20 +14,22 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libbsyolo_hip.so"
 ARCH = "gfx950"
+COMMON = ["-fno-slp-vectorize"]
 # per-file extra flags: NMS / letterbox decisions must round exactly like the fp32 CPU reference (no FMA contraction);
-# -fno-slp-vectorize: files whose kernels convert f16 operands and then do f32 arithmetic -- the SLP-packed form
-# (v_cvt_f32_f16 SDWA -> v_pk_*_f32) returned wrong odd elements beside MFMA kernels of other streams (csrc/common.h)
+# COMMON -fno-slp-vectorize: the SLP vectoriser turns adjacent scalar f32 operations into packed v_pk_*_f32 instructions;
+# fed by SDWA f16 converts that form returned wrong odd elements beside MFMA kernels of other streams (csrc/common.h,
+# DESIGN.md section 7), and it buys nothing measurable anywhere (the headline forward: 3.572 vs 3.580 ms, three runs each)
 SOURCES = {
     "err.cpp": [],
     "conv_mfma.hip": [],
     "conv_first.hip": [],
     "stem_fused.hip": [],
     "bneck_fused.hip": [],
-    "bsyolo_ops.hip": ["-fno-slp-vectorize"],
-    "elementwise.hip": ["-fno-slp-vectorize"],
+    "bsyolo_ops.hip": [],
+    "elementwise.hip": [],
     "attention.hip": [],
     "detect.hip": [],
-    "nms.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "nms.hip": ["-ffp-contract=off"],
     "letterbox.hip": ["-ffp-contract=off"],
     "masks.hip": ["-ffp-contract=off"],
     "val_match.hip": ["-ffp-contract=off"],
@@ -60,7 +62,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     for src, extra in SOURCES.items():
         obj = objdir / (src.rsplit(".", 1)[0] + ".o")
         if force or _stale(obj, [CSRC / src, *headers]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *extra, "-c",
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *COMMON, *extra, "-c",
                    str(CSRC / src), "-o", str(obj)]
             jobs.append(cmd)
     def run(cmd):

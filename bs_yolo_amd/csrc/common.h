@@ -217,7 +217,7 @@ int launch_raw_nchw(const float* box, int ldb, const float* cls, int ldc, int B,
 // v_cvt_f32_f16 (SDWA WORD_1 for the odd elements) feeding SLP-packed v_pk_fma_f32 -- and that sequence returned wrong
 // odd elements, sporadically, whenever MFMA kernels of another stream shared the CUs (SCDown's depthwise conv: 26 of 48
 // forwards; 0 of 48 with packing off).  Depthwise kernels therefore use v_fma_mix_f32 (no conversion, no packing) and
-// their files are built with -fno-slp-vectorize (build.py).
+// the whole library is built with -fno-slp-vectorize (build.py).
 // acc + f32(h) * w with ONE instruction per element: v_fma_mix_f32 reads the f16 operand (low / high half of a packed
 // register) directly, so a depthwise tap costs 8 VALU issues per 8 channels instead of 8 v_cvt_f32_f16 + 4 v_pk_fma_f32
 // (and packed f32 math is the slower choice beside MFMAs).  Same value as fmaf((float)h, w, acc): the conversion is exact.
@@ -253,17 +253,11 @@ __device__ __forceinline__ void fma_mix8(float (&a)[8], const half8& v, const f3
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
-// Four at a time: the three non-transcendental steps become packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two
-// lanes' worth per issue slot), bit-identical to silu_f per element.  SiLU is ~2.5 G evaluations per 64-image forward;
-// in the VALU-bound kernels (fused stem / bottleneck, depthwise) it is the largest single cost.
+// Four at a time, element by element (with -fno-slp-vectorize these stay scalar instructions; packed, the compiler's
+// choice under plain -O3, they were not one microsecond faster over a forward).
 __device__ __forceinline__ f32x4 silu4_f(f32x4 x) {
-    const f32x4 m = x * -1.4426950408889634f;
-    f32x4 e;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(m[i]);
-    const f32x4 d = e + 1.0f;
     f32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(d[i]);
-    return x * r;
+    for (int i = 0; i < 4; ++i) r[i] = silu_f(x[i]);
+    return r;
 }

@@ -6,13 +6,14 @@ export every symbol of the header -- there is no CPU / PyTorch fallback behind i
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import torch  # noqa: F401  -- FIRST: the process must hold ONE HIP runtime (torch's libamdhip64); loading ours before
 #                               torch would bring in a second copy that sees no device
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libbsyolo_hip.so"
+LIB_PATH = Path(os.environ["BSY_LIB"]) if os.environ.get("BSY_LIB") else PKG / "libbsyolo_hip.so"  # BSY_LIB: A/B builds (tools/)
 
 BSY_F16, BSY_F32, BSY_U8 = 0, 1, 2
 BSY_EXT_BASE = 0x100000

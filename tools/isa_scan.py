@@ -10,14 +10,14 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-from bs_yolo_amd.build import ARCH, CSRC, SOURCES, _hipcc  # noqa: E402
+from bs_yolo_amd.build import ARCH, COMMON, CSRC, SOURCES, _hipcc  # noqa: E402
 
 bad = []
 for src, extra in SOURCES.items():
     if not src.endswith(".hip"):
         continue
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-x", "hip", *extra, "-S", "--cuda-device-only",
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-x", "hip", *COMMON, *extra, "-S", "--cuda-device-only",
                f"-I{ROOT / 'include'}", "-o", f.name, str(CSRC / src)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
