@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
                 for (int g = 0; g < CH / 8; ++g) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + 8 * g + 4 * lh);
                     union { half4 h; unsigned u[2]; } o;
-                    f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bv;
+                    f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
                     if (p.act) t = silu4_f(t);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(sb2 + 8 * g + 4 * lh);
                 const half4 rv = *reinterpret_cast<const half4*>(rbase + 8 * g);
                 half4 o;
-                f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bv;
+                f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
                 if (p.act) t = silu4_f(t);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)t[q] + (float)rv[q]);

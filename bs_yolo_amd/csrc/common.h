@@ -253,6 +253,14 @@ __device__ __forceinline__ void fma_mix8(float (&a)[8], const half8& v, const f3
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
+// a + b element by element: a vector-typed `a + b` is a pair of v_pk_add_f32, this is four v_add_f32 (the kernels that run
+// beside other streams' MFMA kernels carry no packed f32 arithmetic at all; see the note on fma_mix_lo above)
+__device__ __forceinline__ f32x4 add4_f(f32x4 a, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = a[i] + b[i];
+    return r;
+}
 // Four at a time, element by element (with -fno-slp-vectorize these stay scalar instructions; packed, the compiler's
 // choice under plain -O3, they were not one microsecond faster over a forward).
 __device__ __forceinline__ f32x4 silu4_f(f32x4 x) {

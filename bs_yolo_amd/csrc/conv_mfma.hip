@@ -374,7 +374,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvK& p, f32x16 (&acc)[
                 const int c = cl + 8 * g + 4 * lh;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
                 half4 o;
-                f32x4 t = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                f32x4 t = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]}, bv);
                 if (p.act) t = silu4_f(t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (half_t)t[e];
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
                         const int c = cl + 8 * g + 4 * lh;
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + n0 + c);
                         half4 o;
-                        f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                        f32x4 tv = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]}, bv);
                         if (p.act) tv = silu4_f(tv);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
                 const int c = cl + 8 * g + 4 * lh;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
                 half4 o;
-                f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]} + bv;
+                f32x4 tv = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]}, bv);
                 if (p.act) tv = silu4_f(tv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (half_t)tv[e];
@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
                 const int cc = cl + 8 * g + 4 * lh;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + cc);
                 half4 o;
-                f32x4 tv = f32x4{acc[a_][b][4 * g], acc[a_][b][4 * g + 1], acc[a_][b][4 * g + 2], acc[a_][b][4 * g + 3]} + bv;
+                f32x4 tv = add4_f(f32x4{acc[a_][b][4 * g], acc[a_][b][4 * g + 1], acc[a_][b][4 * g + 2], acc[a_][b][4 * g + 3]}, bv);
                 if (p.act) tv = silu4_f(tv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (half_t)tv[e];

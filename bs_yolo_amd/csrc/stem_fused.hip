@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
                 for (int g = 0; g < NCH; ++g) {  // couts 8g + 4lh .. +3  (C0 = 16: g < 2 only)
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb0 + 8 * g + 4 * lh);
                     union { half4 h; unsigned u[2]; } o;
-                    f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bv;
+                    f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
                     if (p.act) t = silu4_f(t);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
                 const int c = nh1 * 32 + 8 * g + 4 * lh;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + c);
                 half4 o;
-                f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bv;
+                f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
                 if (p.act) t = silu4_f(t);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)t[q];
