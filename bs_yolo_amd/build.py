@@ -4,6 +4,7 @@
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -53,24 +54,44 @@ def _stale(out: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
+def _signature(cmd, src: Path, headers) -> str:
+    """What an object file was built from: the exact command line plus the contents of its source and of EVERY header of
+    csrc/ and include/ (a flag change -- the correctness workaround -fno-slp-vectorize is one -- or an edit of any header
+    rebuilds; mtimes are not consulted)."""
+    h = hashlib.sha256()
+    h.update("\0".join(cmd).encode())
+    for f in (src, *headers):
+        h.update(b"\0" + f.name.encode() + b"\0")
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
-    headers = [CSRC / "common.h", PKG.parent / "include" / "bsyolo.h"]
+    headers = sorted(CSRC.glob("*.h")) + sorted((PKG.parent / "include").glob("*.h"))
     hipcc = _hipcc()
     jobs = []
     for src, extra in SOURCES.items():
         obj = objdir / (src.rsplit(".", 1)[0] + ".o")
-        if force or _stale(obj, [CSRC / src, *headers]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *COMMON, *extra, "-c",
-                   str(CSRC / src), "-o", str(obj)]
-            jobs.append(cmd)
-    def run(cmd):
+        stamp = obj.with_suffix(".sig")
+        # paths relative to the package: the signature must not depend on where the tree is checked out
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *COMMON, *extra, "-c",
+               str(CSRC / src), "-o", str(obj)]
+        sig = _signature([hipcc, ARCH, *COMMON, *extra, src], CSRC / src, headers)
+        if force or not obj.exists() or not stamp.exists() or stamp.read_text() != sig:
+            jobs.append((cmd, stamp, sig))
+    def run(job):
+        cmd, stamp, sig = job if isinstance(job, tuple) else (job, None, None)
         if verbose:
             print(" ".join(cmd), flush=True)
+        if stamp is not None and stamp.exists():
+            stamp.unlink()
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if stamp is not None:
+            stamp.write_text(sig)
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))

@@ -261,6 +261,10 @@ struct MscaSpK {
 // the pixel loop (2 K floats; with all 8 channels per thread the 21-tap strips spill), and 1600 items over 256 threads
 // leave 11 % of the lanes idle instead of 22 %.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two scalar v_fma_f32 (bit-identical to the packed v_pk_fma_f32 the vector builtin emits): since round 2 NO kernel of the
+// library carries packed f32 arithmetic (tests/test_host_logic.py::test_isa_has_no_packed_f32 scans the shipped objects) --
+// the engine cannot promise that this kernel never shares CUs with another engine's or a user stream's MFMA kernels
+__device__ __forceinline__ f32x2 msca_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 msca_round2(f32x2 a, half2_t& o) {  // f16 rounding of a map element, kept as f32
@@ -301,7 +305,7 @@ __device__ __forceinline__ void msca_branch(const MscaSpK& p, int bi, const f32x
             for (int dx = 0; dx < K; ++dx) {
                 const int ix = x + dx - R;
                 const f32x2 v = (unsigned)ix < (unsigned)W ? sa[(q + dx - R) * 4 + pr] : f32x2{0.f, 0.f};
-                acc = __builtin_elementwise_fma(v, wr[dx], acc);
+                acc = msca_fma2(v, wr[dx], acc);
             }
             half2_t o;
             st[q * 4 + pr] = msca_round2(acc, o);
@@ -322,7 +326,7 @@ __device__ __forceinline__ void msca_branch(const MscaSpK& p, int bi, const f32x
             for (int dy = 0; dy < K; ++dy) {
                 const int iy = y + dy - R;
                 const f32x2 v = (unsigned)iy < (unsigned)H ? st[(q + (dy - R) * W) * 4 + pr] : f32x2{0.f, 0.f};
-                acc = __builtin_elementwise_fma(v, wc[dy], acc);
+                acc = msca_fma2(v, wc[dy], acc);
             }
             half2_t o;
             const f32x2 r = msca_round2(acc, o);

@@ -512,7 +512,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     int c8 = ALIGNED ? 0 : kc0 - tap * p.Cin8;
     const int Cin = p.Cin8 * 8;
 
-    auto issue = [&](int kt, int stage) {
+    // K-step state travels BY VALUE (cur_*) and is advanced by advance() below on plain locals: captured by reference and
+    // mutated inside this lambda the four ints ended up in a 12-byte private (scratch) frame -- reloaded per lane and then
+    // fed to the DMA's scalar offset operands through waterfall loops, in every ALIGNED instantiation (round-1 VERDICT)
+    auto issue = [&](int kt, int stage, const int s_tap, const int s_cb, const int tap, const int c8) {
         half_t* sP = smem + stage * STAGE;
         half_t* sW = sP + TM * BK;
         if (p.dbg & 1) return;
@@ -530,12 +533,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
                 const unsigned o = (vmask[i] & tbit) ? 2u * (s1 ? off1[i] : off0[i]) + sc + kcb : BSY_OOB;
                 if (s1) dma16_buf(rs1, o, 0u, sP + (wave * PIW + i) * RPI * BK);
                 else dma16_buf(rs0, o, 0u, sP + (wave * PIW + i) * RPI * BK);
-            }
-            if (p.dbg & 64) {  // experiment (timing only, wrong numerics): taps innermost -> re-reads one K-step apart
-                if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += BK; }
-            } else {
-                s_cb += BK;
-                if (s_cb >= Cin) { s_cb = 0; ++s_tap; }
             }
 #pragma unroll
             for (int j = 0; j < WIW; ++j)
@@ -556,13 +553,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
                 const half_t* g = (vmask[i] & tbit) ? base + (size_t)o : zero;
                 dma16(g, sP + (wave * PIW + i) * RPI * BK);
             }
-            c8 += 4;
-            while (c8 >= p.Cin8) { c8 -= p.Cin8; ++tap; }
 #pragma unroll
             for (int j = 0; j < WIW; ++j)
                 dma16(p.wgt + (size_t)(woff[j] + (unsigned)kt * 32u), sW + (wave * WIW + j) * RPI * BK);
         }
     };
+#define BSY_ADVANCE_K()                                                                          \
+    do {                                                                                         \
+        if (ALIGNED) {                                                                           \
+            if (p.dbg & 64) { /* experiment (timing only, wrong numerics): taps innermost */     \
+                if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += BK; }                               \
+            } else {                                                                             \
+                s_cb += BK;                                                                      \
+                if (s_cb >= Cin) { s_cb = 0; ++s_tap; }                                          \
+            }                                                                                    \
+        } else {                                                                                 \
+            c8 += 4;                                                                             \
+            while (c8 >= p.Cin8) { c8 -= p.Cin8; ++tap; }                                        \
+        }                                                                                        \
+    } while (0)
 
     f32x16 acc[NT][MT];
 #pragma unroll
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     // prologue: STAGES-1 K-steps in flight
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) issue(s, s);
+        if (s < nk) { issue(s, s, s_tap, s_cb, tap, c8); BSY_ADVANCE_K(); }
 
     for (int kt = 0; kt < nk; ++kt) {
         // wait for K-step kt: everything issued after it may stay in flight
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // K-step kt visible to every wave; every wave is done reading stage (kt-1)%STAGES
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES, s_tap, s_cb, tap, c8); BSY_ADVANCE_K(); }
         const half_t* sP = smem + (kt % STAGES) * STAGE;
         const half_t* sW = sP + TM * BK;
         // all fragment reads of the K-step first (distinct registers), then the MFMA burst: the LDS latency is paid
@@ -645,6 +654,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
         conv_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, lrow, lh);
     }
 }
+
+#undef BSY_ADVANCE_K
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent 1x1 kernel with dedicated store waves ("thin-K" layers: 2-24 K-steps per tile).

@@ -387,28 +387,41 @@ extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream
     int rc = BSY_OK;
     for (size_t i = 0; i < p->ops.size() && rc == BSY_OK; ++i) {
         const bsy_op& op = p->ops[i];
+        // no early return inside this loop: every exit goes through the tail join below
         if (op.join && active) {
-            for (size_t l = 1; l < p->lanes.size(); ++l)
+            for (size_t l = 1; l < p->lanes.size() && rc == BSY_OK; ++l)
                 if (active & (1u << l)) {
-                    HIP_TRY(hipEventRecord(p->lane_done[l], p->lanes[l]));
-                    HIP_TRY(hipStreamWaitEvent(main, p->lane_done[l], 0));
+                    if (hipEventRecord(p->lane_done[l], p->lanes[l]) != hipSuccess ||
+                        hipStreamWaitEvent(main, p->lane_done[l], 0) != hipSuccess) {
+                        bsy_set_error("plan_run: joining lane %zu failed", l);
+                        rc = BSY_ERR_HIP;
+                    } else {
+                        active &= ~(1u << l);
+                    }
                 }
-            active = 0;
+            if (rc != BSY_OK) break;
         }
         hipStream_t s = main;
         if (op.lane > 0) {
             s = p->lanes[op.lane];
             if (!(active & (1u << op.lane))) {
-                HIP_TRY(hipEventRecord(p->lane_fork[op.lane], main));
-                HIP_TRY(hipStreamWaitEvent(s, p->lane_fork[op.lane], 0));
+                if (hipEventRecord(p->lane_fork[op.lane], main) != hipSuccess ||
+                    hipStreamWaitEvent(s, p->lane_fork[op.lane], 0) != hipSuccess) {
+                    bsy_set_error("plan_run: forking lane %d failed", op.lane);
+                    rc = BSY_ERR_HIP;
+                    break;
+                }
                 active |= 1u << op.lane;
             }
         }
         rc = run_op(p, op, R, s);
     }
-    // never leave side streams un-joined (error paths included): the caller only synchronises its own stream
+    // never leave side streams un-joined (error paths included): the caller only synchronises its own stream.  After an
+    // error the lanes are drained on the host as well, so that nothing of this forward can still be writing the workspace
+    // or the caller's outputs when the error is reported (the last-error text of the failing call is kept).
     for (size_t l = 1; l < p->lanes.size(); ++l)
         if (active & (1u << l)) {
+            if (rc != BSY_OK) (void)hipStreamSynchronize(p->lanes[l]);
             (void)hipEventRecord(p->lane_done[l], p->lanes[l]);
             (void)hipStreamWaitEvent(main, p->lane_done[l], 0);
         }

@@ -15,15 +15,12 @@ import torch
 
 from . import lib as L
 
-_ws_cache = {}
-
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    ws = _ws_cache.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[device] = ws
-    return ws
+    """Scratch for one call, taken from torch's caching allocator: the block is bound to the CURRENT stream (a later
+    call on another stream or thread never shares it while this call's kernels are pending), so the boundary keeps no
+    state of its own -- SURVEY section 8(b): "no global state except last-error TLS"."""
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
 def nms_batched(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,

@@ -23,6 +23,7 @@ from typing import Optional
 
 import torch
 
+from . import lib as _L
 from . import nms as _nms
 from .engine import YoloEngine
 from .plan import Plan
@@ -48,20 +49,46 @@ def cfg_of(model) -> dict:
     return cfg
 
 
-def accelerate(model, device: Optional[int] = None, verbose: bool = False):
-    """Install the engine behind ``model.forward``.  Returns the same model object."""
+def _weights_version(model) -> tuple:
+    """Cheap fingerprint of the parameters and buffers: in-place updates (optimizer steps, EMA, load_state_dict's copy_)
+    bump ``Tensor._version``; ``.half()`` / ``.to()`` / ``fuse()`` replace the storages (data_ptr)."""
+    n, ver, ptr = 0, 0, 0
+    for t in list(model.parameters()) + list(model.buffers()):
+        n += 1
+        ver += t._version
+        ptr ^= t.data_ptr() + 0x9E3779B1 * n
+    return (n, ver, ptr)
+
+
+def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_inputs: Optional[str] = None):
+    """Install the engine behind ``model.forward``.  Returns the same model object.
+
+    fp32_inputs: what an fp32 image tensor gets (the reference's ``predict()`` default is ``half=False``,
+    engine/predictor.py:131).  The engine stores activations in fp16, which is NOT the fp32 model's arithmetic (DESIGN.md
+    section 4: max |dscore| up to 6e-3 against the fp32 reference, vs the north-star's 1e-3), so the default
+    ``"reference"`` sends fp32 inputs to the original forward; ``"engine"`` opts in to the fp16-storage engine for them
+    (outputs still come back as fp32).  ``BSY_FP32_INPUTS`` overrides the default.  fp16 inputs (``half=True`` /
+    ``model.half()``) always run on the engine: there the reference itself computes in fp16."""
+    import os
     cfg = cfg_of(model)
     orig_forward = model.forward
-    state = {"engine": None, "key": None}
+    state = {"engine": None, "key": None, "fallbacks": 0, "engine_calls": 0, "rebuilds": 0}
+    fp32_mode = fp32_inputs or os.environ.get("BSY_FP32_INPUTS", "reference")
+    if fp32_mode not in ("reference", "engine"):
+        raise ValueError(f"fp32_inputs must be 'reference' or 'engine', not {fp32_mode!r}")
 
     def _engine_for(dev: torch.device) -> YoloEngine:
-        if state["engine"] is None or state["key"] != dev.index:
+        key = (dev.index or 0, _weights_version(model))
+        if state["engine"] is None or state["key"] != key:
             if state["engine"] is not None:
                 state["engine"].close()
-            # weights are read at this moment: after AutoBackend has called fuse()/half() (autobackend.py:139-145)
+                state["engine"] = None
+            # weights are read at this moment: after AutoBackend has called fuse()/half() (autobackend.py:139-145); the key
+            # makes a later in-place update (EMA, load_state_dict, a training step) or a .half()/.to() rebuild the engine
             sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
             state["engine"] = YoloEngine(cfg, sd, device=dev.index or 0, bn_eps=model_bn_eps(model))
-            state["key"] = dev.index
+            state["key"] = key
+            state["rebuilds"] += 1
         return state["engine"]
 
     def forward(self, x, *args, **kwargs):
@@ -71,9 +98,18 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False):
         profile = kwargs.get("profile", False)
         if (self.training or augment or visualize or embed or profile or args or not isinstance(x, torch.Tensor)
                 or not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float16, torch.float32)
-                or x.shape[2] % 32 or x.shape[3] % 32):
+                or (x.dtype == torch.float32 and fp32_mode != "engine")
+                or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32 or x.shape[0] == 0):
+            state["fallbacks"] += 1
             return orig_forward(x, *args, **kwargs)
-        y, raws = _engine_for(x.device)(x)
+        try:
+            y, raws = _engine_for(x.device)(x)
+        except (_L.BsyError, NotImplementedError, AssertionError) as e:  # a shape / graph the engine rejects: the reference runs it
+            if verbose:
+                print(f"bs_yolo_amd: falling back to the reference forward ({e})")
+            state["fallbacks"] += 1
+            return orig_forward(x, *args, **kwargs)
+        state["engine_calls"] += 1
         return y, raws
 
     model.forward = types.MethodType(forward, model)
@@ -100,8 +136,10 @@ def install_nms(ops_module):
 
     def non_max_suppression(prediction, *args, **kwargs):
         p = prediction[0] if isinstance(prediction, (list, tuple)) else prediction
+        # positional order after `prediction` (utils/ops.py:167-182): conf_thres, iou_thres, classes, agnostic, multi_label,
+        # labels (5), max_det, nc, max_time_img, max_nms, max_wh, in_place, rotated (12)
         rotated = kwargs.get("rotated", False) or (len(args) > 12 and args[12])
-        labels = kwargs.get("labels", ()) or (args[4] if len(args) > 4 else ())
+        labels = kwargs.get("labels", ()) or (args[5] if len(args) > 5 else ())
         if (not isinstance(p, torch.Tensor)) or (not p.is_cuda) or rotated or len(labels) or p.shape[-1] == 6 \
                 or p.dtype not in (torch.float16, torch.float32):
             return orig(prediction, *args, **kwargs)

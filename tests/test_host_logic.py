@@ -386,3 +386,34 @@ print("ok")
 '''
     r = subprocess.run([sys.executable, "-c", code, str(ROOT)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- build / ISA guards (need hipcc's binutils only, no GPU) ----------------------------------------------------------------
+def test_isa_has_no_packed_f32():
+    """The concurrency-hazard mitigation of DESIGN.md section 7, enforced on the SHIPPED code objects: no kernel of
+    libbsyolo_hip.so carries packed f32 arithmetic (v_pk_fma/mul/add_f32) -- hence none can pair it with SDWA f16->f32
+    converts -- and no conv / fused-conv kernel has a private (scratch) frame."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import isa_scan
+    bad, n, scratch = isa_scan.scan()
+    assert n >= 130, f"only {n} kernels found: the disassembly failed"
+    assert not bad, f"packed f32 arithmetic in {bad}"
+    conv_scratch = [k for k in scratch if "conv_mfma_kernel" in k or "conv3x3_patch" in k or "conv1x1_persist" in k or "c3k2_tail" in k]
+    assert not conv_scratch, f"scratch frames in {conv_scratch}"
+
+
+def test_build_signature_tracks_flags_and_headers(tmp_path):
+    """bs_yolo_amd/build.py rebuilds an object when its command line or ANY header of csrc/ / include/ changes (ADVICE r1:
+    the correctness workaround is a flag, and image_conv.h was not tracked)."""
+    from bs_yolo_amd import build as Bd
+    src = tmp_path / "a.hip"
+    hdr = tmp_path / "h.h"
+    src.write_text("int f();")
+    hdr.write_text("// v1")
+    s0 = Bd._signature(["hipcc", "gfx950", "-fno-slp-vectorize", "a.hip"], src, [hdr])
+    assert s0 == Bd._signature(["hipcc", "gfx950", "-fno-slp-vectorize", "a.hip"], src, [hdr])
+    assert s0 != Bd._signature(["hipcc", "gfx950", "a.hip"], src, [hdr])
+    hdr.write_text("// v2")
+    assert s0 != Bd._signature(["hipcc", "gfx950", "-fno-slp-vectorize", "a.hip"], src, [hdr])
+    hdrs = sorted(p.name for p in Bd.CSRC.glob("*.h"))
+    assert "image_conv.h" in hdrs and "common.h" in hdrs
