@@ -2,13 +2,17 @@
 """Headline benchmark: images/sec of the YOLO11s 640x640 fp16 detection hot path (forward + NMS) on MI355X.
 
     python bench.py                                   # 1 GPU, defaults
+    python bench.py --gpus N                          # N GPUs: starts the N ranks itself (a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W        # N GPUs, one rank per GPU (RCCL)
+        bench.py --gpus N --steps K --warmup W        # the same, launched by the caller: one rank per GPU (RCCL)
+    python bench.py --imgsz 1280                      # the 1280 x 1280 line of the north-star
+    python bench.py --gpus 8 --scaling strong --scale m --imgsz 1280 --batch 256   # BASELINE config 3: 256 images split 32 / GPU
 
 One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
 engine forward (all HIP kernels) -> batched HIP NMS (conf 0.25, iou 0.7, max_det 300) -> (N > 1) RCCL all-gather of
-the fixed-size detections over xGMI.  Images are independent units: each rank owns its own batch of 64 (weak scaling,
-no data-path collective besides the detection all-gather).
+the fixed-size detections over xGMI.  Images are independent units: by default each rank owns its own batch of 64 (weak
+scaling); `--scaling strong` keeps the GLOBAL batch at --batch and gives every rank a contiguous share of it.  No
+data-path collective besides the detection all-gather.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are taken).
 """
@@ -24,25 +28,25 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", default="s")
     ap.add_argument("--family", default="yolo11", choices=["yolo11", "yolov8", "bsyolo11"],
                     help="graph: stock YOLO11 (the headline config), YOLOv8, or the fork's own BS-YOLO graph (nc = 12)")
     ap.add_argument("--imgsz", type=int, default=640)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling) or in all (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch images per GPU; strong: --batch images in all, split contiguously over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-runs", type=int, default=20, help="CPU baseline sample: runs of --cpu-batch images (~10 s in all)")
+    ap.add_argument("--cpu-runs-1t", type=int, default=3, help="the same at ONE thread (the reference's default, ultralytics/__init__.py:7-8)")
     return ap.parse_args()
 
 
@@ -50,40 +54,66 @@ NAMES = {"yolo11": "YOLO11", "yolov8": "YOLOv8", "bsyolo11": "BS-YOLO11"}
 
 
 def cpu_baseline(args, cfg_sd):
-    """The oracle (torch-CPU fp32 restatement of the reference path, oracle/) timed on this host: forward + NMS."""
+    """The oracle (torch-CPU fp32 restatement of the reference path, oracle/) timed on this host: forward + NMS, at this
+    job's core share AND at one thread (`import ultralytics` pins OMP_NUM_THREADS=1 by default)."""
+    import torch
     from oracle import postproc_ref as PP
     from oracle import yolo_ref as R
     m = R.Model(args.family, args.scale, 12 if args.family == "bsyolo11" else 80, "detect")
     P = {k: v.float() for k, v in cfg_sd.items()}
     P[f"model.{len(m.layers) - 1}.dfl.conv.weight"] = torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)
     x = torch.rand(args.cpu_batch, 3, args.imgsz, args.imgsz, generator=torch.Generator().manual_seed(0))
-    # the GPU box shares its host: use this job's CPU share (16 threads per GPU), not every visible core
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    with torch.inference_mode():
-        y, _ = m.forward(P, x)  # warm-up
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_runs):
-            y, _ = m.forward(P, x)
-            PP.non_max_suppression(y, 0.25, 0.7)
-        dt = time.perf_counter() - t0
+
+    def timed(threads, runs):
+        torch.set_num_threads(threads)
+        with torch.inference_mode():
+            y, _ = m.forward(P, x)  # warm-up
+            t0 = time.perf_counter()
+            for _ in range(runs):
+                y, _ = m.forward(P, x)
+                PP.non_max_suppression(y, 0.25, 0.7)
+            return time.perf_counter() - t0
+
     if args.cpu_runs <= 0:
         return None
-    return {"value": round(args.cpu_batch * args.cpu_runs / dt, 3), "unit": "images/sec", "cores": cores,
-            "kind": "port",
-            "sample": f"{args.cpu_runs} x batch {args.cpu_batch} {NAMES[args.family]}{args.scale} {args.imgsz}x{args.imgsz} fp32 "
-                      f"forward + NMS, torch CPU {cores} threads, after 1 warm-up ({dt:.1f} s)"}
+    # the GPU box shares its host: use this job's CPU share (16 threads per GPU), not every visible core
+    cores = min(16, os.cpu_count() or 1)
+    what = f"batch {args.cpu_batch} {NAMES[args.family]}{args.scale} {args.imgsz}x{args.imgsz} fp32 forward + NMS, torch CPU"
+    dt = timed(cores, args.cpu_runs)
+    out = {"value": round(args.cpu_batch * args.cpu_runs / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"{args.cpu_runs} x {what} {cores} threads, after 1 warm-up ({dt:.1f} s)"}
+    if args.cpu_runs_1t > 0:
+        dt1 = timed(1, args.cpu_runs_1t)
+        out["single_thread"] = {"value": round(args.cpu_batch * args.cpu_runs_1t / dt1, 3), "unit": "images/sec", "cores": 1,
+                                "sample": f"{args.cpu_runs_1t} x {what} 1 thread, after 1 warm-up ({dt1:.1f} s)"}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `torch.distributed.run` and relay its
+    output and exit code.  Decided before this process has imported torch or touched the GPU (never an exec of a process
+    that initialised HIP)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     # BSY_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow with several ranks on ONE GPU (RCCL refuses two ranks on
@@ -111,14 +141,22 @@ def main():
     cfg = stock_cfg(args.family, args.scale, 12 if args.family == "bsyolo11" else 80, "detect")
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
     eng = YoloEngine(cfg, sd, device=local)
-    B, S = args.batch, args.imgsz
+    S = args.imgsz
+    if args.scaling == "strong":  # the global batch is fixed: this rank's contiguous share of it (parallel.shard_bounds)
+        from bs_yolo_amd.parallel import shard_bounds
+        lo, hi = shard_bounds(args.batch, world)[rank]
+        B, global_batch = hi - lo, args.batch
+        if B == 0:
+            sys.exit(f"--scaling strong: batch {args.batch} leaves rank {rank} of {world} without images")
+    else:
+        B, global_batch = args.batch, world * args.batch
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(B, 3, S, S, generator=g).half().to(dev)
     if not (args.family == "yolo11" and args.scale == "s"):
         # The class head of synth_state_dict is calibrated for the headline graph (1.5 % of the anchors above conf 0.25).
         # Other graphs: rescale and shift it from the raw class logits of one probe forward (8 images) so that the same
         # share passes (1-2 %) -- else NMS sees either nothing or max_det-saturated images.
-        _, raws = eng(x[:8], want_raw=True)
+        _, raws = eng(x[:min(8, B)], want_raw=True)
         bias0 = float(next(v for k, v in sd.items() if ".cv3." in k and k.endswith(".2.bias")).flatten()[0])
         lc = torch.cat([r[:, 64:].float().flatten(2) for r in raws], 2) - bias0          # centred logits (8, nc, A)
         gain = 1.0 / max(float(lc.std()), 1e-6)
@@ -173,55 +211,76 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
+    value = global_batch * args.steps / dt
 
     if rank == 0:
-        # ---- roofline of the dominant kernel family (the plan's OP_CONV launches, csrc/conv_mfma.hip): HIP events around
-        #      every op on the stream ----
+        # ---- roofline of the dominant kernel family: EVERY launch that does dense-conv MFMA work -- the plan's OP_CONV ops
+        #      (conv_mfma_kernel / conv3x3_patch_kernel / conv1x1_persist_kernel) and the fused conv kernels (stem, Bottleneck,
+        #      C3k2 tail, DWConv+1x1, ...).  Round 1 priced the OP_CONV launches alone; since convs keep moving into fused
+        #      kernels that subset is no longer a stable family, so both are reported.  HIP events around every op on the
+        #      launch stream, three serial passes after the timed region.
         prof = None
         for _ in range(3):
             prof, plan = eng.profile(x)
-        conv_ms = sum(t for (_, kind, t) in prof if kind == L.OP_CONV)
-        n_conv = sum(1 for (_, kind, _) in prof if kind == L.OP_CONV)
-        conv_flops = conv_bytes = 0
-        for o in plan.ops:
-            if o["kind"] == L.OP_CONV:
-                cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
-                conv_flops += 2 * B * o["OH"] * o["OW"] * o.get("cout", o["dst"].C) * cin * o["ksize"] ** 2
-                # algorithmic bytes: every operand read once, result written once
-                conv_bytes += B * o["H"] * o["W"] * o["src0"].C * 2 // (4 if o["src0"].up else 1)
-                if o.get("src1"):
-                    conv_bytes += B * o["H"] * o["W"] * o["src1"].C * 2 // (4 if o["src1"].up else 1)
-                mode = o.get("out_f32", 0)  # 0 f16 map, 1 f32 map, 2 / 3 fused decoder: class rows / 4 box rows of y (f16)
-                out_b = B * o["OH"] * o["OW"] * ({2: o.get("cout", 0), 3: 4}.get(mode, o["dst"].C)) * (4 if mode == 1 else 2)
-                conv_bytes += out_b * (2 if o.get("res") else 1)
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        fam = [(o, t) for o, (_, _, t) in zip(plan.ops, prof) if o.get("mfma_flops")]
+        fam_ms = sum(t for _, t in fam)
+        fam_flops = sum(o["mfma_flops"] for o, _ in fam)
+        n_fam = len(fam)
+        conv_ms = sum(t for o, t in fam if o["kind"] == L.OP_CONV)
+        conv_flops = sum(o["mfma_flops"] for o, _ in fam if o["kind"] == L.OP_CONV)
+        n_conv = sum(1 for o, _ in fam if o["kind"] == L.OP_CONV)
+        # algorithmic bytes of the family: every operand read once, every result written once (fused ops: their external
+        # inputs and outputs only)
+        fam_bytes = 0
+        for o, _ in fam:
+            for key in ("src0", "src1", "res"):
+                t = o.get(key)
+                if t is None:
+                    continue
+                if o["kind"] in (L.OP_CONV_FIRST, L.OP_STEM) and key == "src0":
+                    fam_bytes += B * 3 * o["H"] * o["W"] * 2
+                else:
+                    fam_bytes += B * o["H"] * o["W"] * t.C * (4 if t.f32 else 2) // (4 if t.up else 1)
+            mode = o.get("out_f32", 0)  # 0 f16 map, 1 f32 map, 2 / 3 fused decoder: class rows / 4 box rows of y (f16)
+            fam_bytes += B * o["OH"] * o["OW"] * ({2: o.get("cout", 0), 3: 4}.get(mode, o["dst"].C)) * (4 if mode == 1 else 2)
+        achieved = fam_flops / (fam_ms * 1e-3) / 1e12
         # HBM traffic of the same kernel family cannot be sampled from inside the process: it is the PMC measurement
         # committed under profiles/ (tools/pmc_bench_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # passes, gfx950 correction), per launch like `achieved`; only valid for the default workload
-        traffic = None
-        tfile = ROOT / "profiles" / "r01_traffic.json"
-        if tfile.exists() and args.family == "yolo11" and args.scale == "s" and S == 640 and B == 64:
-            traffic = round(json.load(open(tfile))["conv_mfma_hbm_bytes_per_launch_avg"])
+        traffic, tsrc = None, None
+        for name in ("r02_traffic.json", "r01_traffic.json"):
+            tfile = ROOT / "profiles" / name
+            if tfile.exists() and args.family == "yolo11" and args.scale == "s" and S == 640 and B == 64:
+                traffic = round(json.load(open(tfile))["conv_mfma_hbm_bytes_per_launch_avg"])
+                tsrc = name
+                break
         fwd_ms = sum(t for (_, _, t) in prof)
         out = {
-            "metric": f"images/sec {NAMES[args.family]}{args.scale} {S}x{S} bs={B} (forward + NMS)", "value": round(value, 1), "unit": "images/sec",
+            "metric": f"images/sec {NAMES[args.family]}{args.scale} {S}x{S} bs={B if args.scaling == 'weak' else global_batch} (forward + NMS)",
+            "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{NAMES[args.family]}{args.scale} detect {S}x{S} fp16, batch {B} per GPU, seeded random weights, "
-                                   f"engine forward + HIP NMS (conf 0.25, iou 0.7, max_det 300)"
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{NAMES[args.family]}{args.scale} detect {S}x{S} fp16, "
+                                   + (f"batch {B} per GPU" if args.scaling == "weak" else f"global batch {global_batch} split over {world} GPU(s)")
+                                   + ", seeded random weights, engine forward + HIP NMS (conf 0.25, iou 0.7, max_det 300)"
                                    + (" + RCCL all-gather of detections" if world > 1 else ""),
-                       "global_batch": world * B, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",
+                       "global_batch": global_batch, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 1),
                        "model_gflop_per_image": round(plan.flops / B / 1e9, 2),
-                       "whole_path_tflops": round(plan.flops * world / (ms_step * 1e-3) / 1e12, 1)},
+                       "whole_path_tflops": round(plan.flops / B * global_batch / (ms_step * 1e-3) / 1e12, 1)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_traffic.json)",
-                         "algorithmic_bytes_per_launch_avg": round(conv_bytes / n_conv),
-                         "kernel": "conv family of csrc/conv_mfma.hip: conv_mfma_kernel + conv1x1_persist_kernel + conv3x3_patch_kernel (all OP_CONV launches)", "launches_per_step": n_conv,
-                         "flops_per_launch_avg": round(conv_flops / n_conv), "avg_launch_ms": round(conv_ms / n_conv, 5),
-                         "conv_ms_per_step": round(conv_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4)},
+                         "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tsrc})" if tsrc else None,
+                         "algorithmic_bytes_per_launch_avg": round(fam_bytes / n_fam),
+                         "kernel": "dense-conv family: every MFMA conv launch of one forward (conv_mfma_kernel, conv3x3_patch_kernel, "
+                                   "conv1x1_persist_kernel and the fused stem / Bottleneck / C3k2-tail / DWConv+1x1 kernels)",
+                         "launches_per_step": n_fam,
+                         "flops_per_launch_avg": round(fam_flops / n_fam), "avg_launch_ms": round(fam_ms / n_fam, 5),
+                         "family_ms_per_step": round(fam_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4),
+                         "op_conv_only": {"launches_per_step": n_conv, "ms_per_step": round(conv_ms, 4),
+                                          "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 1),
+                                          "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
+                                          "note": "the round-1 definition (plan ops of kind OP_CONV only), for continuity"}},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, sd)

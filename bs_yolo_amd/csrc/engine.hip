@@ -16,6 +16,10 @@ struct bsy_engine {
     int device = 0;
     void* weights = nullptr;
     size_t weight_bytes = 0;
+    // ONE activation arena shared by every plan created with bsy_plan_create_arena (sized for the largest of them; a plan
+    // addresses it through host-assigned offsets).  Grows, never shrinks; plans resolve the base at run time.
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
 };
 
 struct bsy_plan {
@@ -23,8 +27,10 @@ struct bsy_plan {
     std::vector<bsy_op> ops;
     std::vector<size_t> buf_off;
     std::vector<size_t> buf_size;
-    char* workspace = nullptr;
+    char* workspace = nullptr;     // plan-owned workspace (bsy_plan_create) ...
     size_t workspace_bytes = 0;
+    bool use_arena = false;        // ... or the engine's shared arena (bsy_plan_create_arena): base = eng->arena
+    char* base() const { return use_arena ? eng->arena : workspace; }
     std::vector<hipEvent_t> events;
     // side streams ("lanes") for independent op chains + the events that fork / join them
     std::vector<hipStream_t> lanes;      // index 0 unused (lane 0 = caller's stream)
@@ -49,6 +55,7 @@ extern "C" int bsy_engine_create(int device, bsy_engine** out) {
 extern "C" void bsy_engine_destroy(bsy_engine* e) {
     if (!e) return;
     if (e->weights) (void)hipFree(e->weights);
+    if (e->arena) (void)hipFree(e->arena);
     delete e;
 }
 
@@ -62,6 +69,24 @@ extern "C" int bsy_engine_load_weights(bsy_engine* e, const void* host_blob, siz
     if (hipMalloc(&e->weights, bytes + 256) != hipSuccess) BSY_FAIL(BSY_ERR_ALLOC, "load_weights: hipMalloc(%zu) failed", bytes);
     HIP_TRY(hipMemcpy(e->weights, host_blob, bytes, hipMemcpyHostToDevice));
     e->weight_bytes = bytes;
+    return BSY_OK;
+}
+
+extern "C" void bsy_plan_destroy(bsy_plan* p);
+
+static int plan_make_lanes(bsy_plan* p) {
+    int max_lane = 0;
+    for (const auto& o : p->ops) max_lane = o.lane > max_lane ? o.lane : max_lane;
+    if (max_lane > 31) BSY_FAIL(BSY_ERR_ARG, "plan_create: too many lanes");
+    p->lanes.assign(max_lane + 1, nullptr);
+    p->lane_done.assign(max_lane + 1, nullptr);
+    p->lane_fork.assign(max_lane + 1, nullptr);
+    bool ok = true;
+    for (int l = 1; l <= max_lane && ok; ++l)
+        ok = hipStreamCreateWithFlags(&p->lanes[l], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&p->lane_fork[l], hipEventDisableTiming) == hipSuccess;
+    if (!ok) BSY_FAIL(BSY_ERR_HIP, "plan_create: stream/event creation failed");
     return BSY_OK;
 }
 
@@ -103,21 +128,52 @@ extern "C" int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, cons
             delete p;
             BSY_FAIL(BSY_ERR_HIP, "plan_create: guard memset failed");
         }
-    int max_lane = 0;
-    for (const auto& o : p->ops) max_lane = o.lane > max_lane ? o.lane : max_lane;
-    if (max_lane > 31) { (void)hipFree(p->workspace); delete p; BSY_FAIL(BSY_ERR_ARG, "plan_create: too many lanes"); }
-    p->lanes.assign(max_lane + 1, nullptr);
-    p->lane_done.assign(max_lane + 1, nullptr);
-    p->lane_fork.assign(max_lane + 1, nullptr);
-    bool ok = true;
-    for (int l = 1; l <= max_lane && ok; ++l)
-        ok = hipStreamCreateWithFlags(&p->lanes[l], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&p->lane_done[l], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&p->lane_fork[l], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { bsy_plan_destroy(p); BSY_FAIL(BSY_ERR_HIP, "plan_create: stream/event creation failed"); }
+    const int rc = plan_make_lanes(p);
+    if (rc != BSY_OK) { bsy_plan_destroy(p); return rc; }
     *out = p;
     return BSY_OK;
 }
+
+// The activation buffers of this plan live at HOST-assigned byte offsets (multiples of 256; they may overlap where
+// bs_yolo_amd/plan.py found the buffers' lifetimes disjoint) inside the engine's shared arena of at least `arena_bytes`.
+// The arena is (re)allocated here when it is too small -- after a device synchronisation, so no earlier plan can still be
+// running in the old one.  Plans of one engine share the arena: run them on one stream at a time (the reference serialises
+// predict() the same way, engine/predictor.py:113,229).
+extern "C" int bsy_plan_create_arena(bsy_engine* e, const bsy_op* ops, int n_ops, const int64_t* buf_bytes, const int64_t* buf_off,
+                                     int n_bufs, int64_t arena_bytes, bsy_plan** out) {
+    if (!e || !ops || n_ops <= 0 || !out || n_bufs < 0 || (n_bufs && (!buf_bytes || !buf_off)) || arena_bytes < 0)
+        BSY_FAIL(BSY_ERR_ARG, "plan_create_arena: bad argument");
+    if (!e->weights) BSY_FAIL(BSY_ERR_STATE, "plan_create_arena: load weights first");
+    for (int i = 0; i < n_bufs; ++i)
+        if (buf_bytes[i] < 0 || buf_off[i] < 0 || (buf_off[i] & 255) || buf_off[i] + buf_bytes[i] > arena_bytes)
+            BSY_FAIL(BSY_ERR_ARG, "plan_create_arena: buffer %d (offset %lld, %lld bytes) outside the arena of %lld bytes", i,
+                     (long long)buf_off[i], (long long)buf_bytes[i], (long long)arena_bytes);
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t need = (size_t)arena_bytes + 256;
+    if (need > e->arena_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (e->arena) { HIP_TRY(hipFree(e->arena)); e->arena = nullptr; e->arena_bytes = 0; }
+        if (hipMalloc((void**)&e->arena, need) != hipSuccess) BSY_FAIL(BSY_ERR_ALLOC, "plan_create_arena: hipMalloc(%zu) failed", need);
+        e->arena_bytes = need;
+        // zero once so that padding channels nobody writes start finite (later tenants of a region leave ordinary f16 / f32
+        // activations behind; no kernel consumes padding channels)
+        HIP_TRY(hipMemset(e->arena, 0, need));
+    }
+    bsy_plan* p = new bsy_plan();
+    p->eng = e;
+    p->use_arena = true;
+    p->ops.assign(ops, ops + n_ops);
+    for (int i = 0; i < n_bufs; ++i) {
+        p->buf_off.push_back((size_t)buf_off[i]);
+        p->buf_size.push_back((size_t)buf_bytes[i]);
+    }
+    const int rc = plan_make_lanes(p);
+    if (rc != BSY_OK) { bsy_plan_destroy(p); return rc; }
+    *out = p;
+    return BSY_OK;
+}
+
+extern "C" size_t bsy_engine_arena_bytes(const bsy_engine* e) { return e ? e->arena_bytes : 0; }
 
 // Test aid: synchronises the device and checks the guard bands (plans created under BSY_PLAN_GUARD).  Returns BSY_OK and
 // *bad_buf = -1 when every band is intact, else the index of the first buffer whose band was written and the byte offset
@@ -126,7 +182,7 @@ extern "C" int bsy_plan_check_guards(bsy_plan* p, int32_t* bad_buf, int64_t* bad
     if (!p || !bad_buf) BSY_FAIL(BSY_ERR_ARG, "plan_check_guards: bad argument");
     *bad_buf = -1;
     if (bad_off) *bad_off = 0;
-    if (!p->guard) return BSY_OK;
+    if (!p->guard || p->use_arena) return BSY_OK;  // arena plans carry no guard bands (buffers alias by design)
     HIP_TRY(hipDeviceSynchronize());
     std::vector<unsigned char> host(p->guard);
     for (size_t i = 0; i < p->buf_off.size(); ++i) {
@@ -166,7 +222,7 @@ struct Resolver {
             return (char*)ext[s];
         }
         if ((size_t)v.buf >= p->buf_off.size()) { ok = false; bsy_set_error("plan_run: buffer %d out of range", v.buf); return nullptr; }
-        return p->workspace + p->buf_off[v.buf];
+        return p->base() + p->buf_off[v.buf];
     }
     half_t* h(const bsy_view& v) { char* b = base(v); return b ? (half_t*)b + v.coff : nullptr; }
     float* f(const bsy_view& v) { char* b = base(v); return b ? (float*)b + v.coff : nullptr; }
@@ -441,9 +497,8 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
     int rc = BSY_OK;
     for (size_t i = 0; i < p->ops.size() && rc == BSY_OK; ++i) {
         bsy_op& op = p->ops[i];
-        if (op.kind != BSY_OP_CONV) { rc = run_op(p, op, R, s); continue; }
+        if (op.kind != BSY_OP_CONV || op.tuned_cfg > 0) { rc = run_op(p, op, R, s); continue; }  // preset (bsy_plan_set_tuning): kept
         ConvArgs a;
-        op.tuned_cfg = 0;
         rc = run_op(p, op, R, s, &a);
         if (rc != BSY_OK) break;
         int cand[BSY_CONV_MAX_CFG];
@@ -481,11 +536,22 @@ extern "C" int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n) {
     return BSY_OK;
 }
 
+// HOST array cfg[n_ops]: >= 0 presets that configuration for op i (a later bsy_plan_autotune leaves the op alone), -1 keeps
+// the op as it is, -2 clears it (heuristic / to be tuned).  A preset that is not valid for the op's shape is ignored at launch.
+extern "C" int bsy_plan_set_tuning(bsy_plan* p, const int32_t* cfg, int n) {
+    if (!p || !cfg || n != (int)p->ops.size()) BSY_FAIL(BSY_ERR_ARG, "plan_set_tuning: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (p->ops[i].kind != BSY_OP_CONV || cfg[i] == -1) continue;
+        p->ops[i].tuned_cfg = cfg[i] >= 0 ? cfg[i] + 1 : 0;
+    }
+    return BSY_OK;
+}
+
 extern "C" int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes) {
     if (!p || !host_dst || buf < 0 || (size_t)buf >= p->buf_off.size()) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: bad argument");
     if (bytes > p->buf_size[buf]) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: %zu > buffer size %zu", bytes, p->buf_size[buf]);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host_dst, p->workspace + p->buf_off[buf], bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_dst, p->base() + p->buf_off[buf], bytes, hipMemcpyDeviceToHost));
     return BSY_OK;
 }
 

@@ -1,4 +1,4 @@
-"""Engine wrapper: owns a bsy_engine (weights in HBM) and one bsy_plan per input shape.
+"""Engine wrapper: owns a bsy_engine (weights in HBM, ONE activation arena) and an LRU set of bsy_plans, one per input shape.
 
 `YoloEngine.__call__(im)` has the calling convention AutoBackend expects from an in-memory model
 (nn/autobackend.py:524: ``self.model(im, augment=, visualize=, embed=)`` -> ``(y, x_list)``, head.py:74), with
@@ -8,6 +8,10 @@ the current stream; all compute goes through libbsyolo_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import json
+import math
+import os
+from collections import OrderedDict
 from typing import Dict, List, Mapping, Optional, Tuple
 
 import torch
@@ -21,16 +25,40 @@ class YoloEngine:
     def __init__(self, cfg: dict, state_dict: Mapping[str, torch.Tensor], device: int = 0, bn_eps: float = BN_EPS,
                  autotune: Optional[bool] = None, fuse_stem: Optional[bool] = None,
                  fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None, fuse_dwpw: Optional[bool] = None,
-                 merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None):
+                 merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None, fuse_tail: Optional[bool] = None,
+                 max_plans: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self._h = C.c_void_p()
         L.check(L.lib.bsy_engine_create(device, C.byref(self._h)))
-        self._plans: Dict[Tuple, Tuple] = {}
+        # plans: least-recently-used first.  val runs with rect=True (engine/model.py:635; per-batch shapes,
+        # data/base.py:261-284) and predict's `auto` letterbox also varies (H, W): a plan is cheap to rebuild (host-side
+        # flattening + a handful of streams / events), its activations live in the engine's shared arena and its tuning in
+        # `_tune_cache`, so old shapes are simply dropped
+        self._plans: "OrderedDict[Tuple, Tuple]" = OrderedDict()
+        self.max_plans = int(os.environ.get("BSY_MAX_PLANS", "8")) if max_plans is None else int(max_plans)
         self._tuned = set()
-        import os
+        self._elems: Dict[Tuple[int, int], int] = {}
+        # autotune results keyed by conv shape (Plan.conv_signature), shared by every plan of this engine and, with
+        # BSY_TUNE_CACHE=<file>, across processes.  `tune_stats` counts what bsy_plan_autotune had to time.
+        self._tune_cache: Dict[tuple, int] = {}
+        # second level: the same layer (channels, kernel, stride, epilogue) at a similar size (pixel count within a factor of
+        # two) reuses the winner without timing -- rect batches differ from each other by a few rows or columns
+        self._tune_family: Dict[tuple, int] = {}
+        self.tune_stats = {"timed_ops": 0, "cached_ops": 0, "family_ops": 0, "autotune_calls": 0}
+        self._tune_file = os.environ.get("BSY_TUNE_CACHE")
+        if self._tune_file and os.path.exists(self._tune_file):
+            try:
+                self._tune_cache = {tuple(k): int(v) for k, v in json.load(open(self._tune_file))}
+                for k, v in self._tune_cache.items():
+                    self._tune_family.setdefault(self._family(k), v)
+            except (OSError, ValueError):
+                self._tune_cache = {}
+        # liveness-based buffer reuse (Plan.assign_offsets).  Off under BSY_ARENA_REUSE=0 (tests that read intermediate
+        # layers back) and under BSY_PLAN_GUARD (guard bands behind every buffer: the plan then owns a private workspace)
+        self.reuse = os.environ.get("BSY_ARENA_REUSE", "1") != "0" and not os.environ.get("BSY_PLAN_GUARD")
         self.autotune = (os.environ.get("BSY_AUTOTUNE", "1") != "0") if autotune is None else bool(autotune)
         # pack once with a throw-away plan (op list structure does not depend on the input size)
         self.fuse_stem = fuse_stem  # None: BSY_FUSE_STEM env (default on); False keeps layers 0 and 1 as two launches
@@ -39,8 +67,8 @@ class YoloEngine:
         self.fuse_dwpw = fuse_dwpw
         self.merge_c3k = merge_c3k
         self.fuse_msca = fuse_msca
-        self._packed = Plan(cfg, 1, 64, 64, fuse_stem=fuse_stem, fuse_bneck=fuse_bneck, fuse_head=fuse_head, fuse_dwpw=fuse_dwpw,
-                            merge_c3k=merge_c3k, fuse_msca=fuse_msca)
+        self.fuse_tail = fuse_tail
+        self._packed = Plan(cfg, 1, 64, 64, **self._fuse_kw())
         blob = pack_plan_weights(self._packed, state_dict, bn_eps)
         self.weight_bytes = len(blob)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
@@ -50,24 +78,97 @@ class YoloEngine:
         self.stride = torch.tensor(self.meta["strides"])
         self.names = {i: f"{i}" for i in range(self.nc)}
 
+    def _fuse_kw(self):
+        return dict(fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head, fuse_dwpw=self.fuse_dwpw,
+                    merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail)
+
     # -- plans --------------------------------------------------------------------------------------------------
     def plan_for(self, B: int, H: int, W: int, in_dtype: torch.dtype, out_dtype: torch.dtype):
         key = (B, H, W, in_dtype, out_dtype)
         hit = self._plans.get(key)
         if hit is not None:
+            self._plans.move_to_end(key)
             return hit
         if H % 32 or W % 32:
             raise ValueError(f"input {H}x{W} must be a multiple of the max stride 32 (utils/checks.py:120-172)")
-        plan = Plan(self.cfg, B, H, W, L.dtype_code(in_dtype), L.dtype_code(out_dtype), fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head,
-                    fuse_dwpw=self.fuse_dwpw, merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca)
+        plan = Plan(self.cfg, B, H, W, L.dtype_code(in_dtype), L.dtype_code(out_dtype), **self._fuse_kw())
         adopt_offsets(plan, self._packed)
         ops = plan.c_ops()
         sizes = (C.c_int64 * len(plan.buf_bytes))(*plan.buf_bytes)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            L.check(L.lib.bsy_plan_create(self._h, ops, len(plan.ops), sizes, len(plan.buf_bytes), C.byref(h)))
+            if os.environ.get("BSY_PLAN_GUARD"):  # test aid: private workspace with guard bands, no aliasing
+                L.check(L.lib.bsy_plan_create(self._h, ops, len(plan.ops), sizes, len(plan.buf_bytes), C.byref(h)))
+                plan.arena_bytes = sum((b + 255) & ~255 for b in plan.buf_bytes)
+            else:
+                offs, arena = plan.assign_offsets(self.reuse)
+                plan.arena_bytes = arena
+                L.check(L.lib.bsy_plan_create_arena(self._h, ops, len(plan.ops), sizes, (C.c_int64 * len(offs))(*offs),
+                                                    len(offs), arena, C.byref(h)))
+        # conv shapes an earlier plan (or an earlier process, BSY_TUNE_CACHE) already tuned: preset, not re-timed
+        plan.conv_sigs = [plan.conv_signature(o) for o in plan.ops]
+        for sg in plan.conv_sigs:
+            if sg is not None and sg not in self._tune_cache and self._family(sg) in self._tune_family:
+                self._tune_cache[sg] = self._tune_family[self._family(sg)]
+                self.tune_stats["family_ops"] += 1
+        preset = (C.c_int32 * len(plan.ops))(*[self._tune_cache.get(sg, -1) if sg is not None else -1 for sg in plan.conv_sigs])
+        L.check(L.lib.bsy_plan_set_tuning(h, preset, len(plan.ops)))
+        while len(self._plans) >= max(self.max_plans, 1):  # evict the least recently used shape
+            _, (_, old) = self._plans.popitem(last=False)
+            L.lib.bsy_plan_destroy(old)
         self._plans[key] = (plan, h)
         return plan, h
+
+    @property
+    def arena_bytes(self) -> int:
+        """Bytes of the activation arena all plans of this engine share (the largest plan so far)."""
+        return int(L.lib.bsy_engine_arena_bytes(self._h))
+
+    @staticmethod
+    def _family(sg: tuple) -> tuple:
+        B, H, W = sg[:3]
+        return sg[3:] + (int(round(math.log2(max(B * H * W, 1)))),)
+
+    def _autotune(self, plan, h, ext, n, stream):
+        """First forward of a shape: time the candidate configurations of the conv ops whose shape has not been tuned yet
+        (bsy_plan_autotune skips preset ops) and remember the winners by conv shape."""
+        todo = sum(1 for sg in plan.conv_sigs if sg is not None and sg not in self._tune_cache)
+        self.tune_stats["autotune_calls"] += 1
+        self.tune_stats["timed_ops"] += todo
+        self.tune_stats["cached_ops"] += sum(1 for sg in plan.conv_sigs if sg is not None) - todo
+        L.check(L.lib.bsy_plan_autotune(h, ext, n, C.c_void_p(stream)))
+        if todo:
+            out = (C.c_int32 * len(plan.ops))()
+            L.check(L.lib.bsy_plan_get_tuning(h, out, len(plan.ops)))
+            for sg, c in zip(plan.conv_sigs, out):
+                if sg is not None and c >= 0:
+                    self._tune_cache.setdefault(sg, int(c))
+                    self._tune_family.setdefault(self._family(sg), int(c))
+            if self._tune_file:
+                try:
+                    tmp = self._tune_file + f".{os.getpid()}.tmp"
+                    json.dump([[list(k), v] for k, v in self._tune_cache.items()], open(tmp, "w"))
+                    os.replace(tmp, self._tune_file)
+                except OSError:
+                    pass
+
+    def _max_view_elems(self, H: int, W: int) -> int:
+        """Largest (pixels x row stride) of any activation view of ONE image at this size: the kernels keep element offsets in
+        32 bits, so a batch is split when B times this reaches 2^31 (C2f concat buffers are larger than the first
+        conv's output, which the round-1 estimate used)."""
+        key = (H, W)
+        hit = self._elems.get(key)
+        if hit is None:
+            p1 = Plan(self.cfg, 1, H, W, **self._fuse_kw())
+            hit = 1
+            for o in p1.ops:
+                for k in ("src0", "src1", "dst", "res"):
+                    t = o.get(k)
+                    if t is not None and t.buf < L.BSY_EXT_BASE:
+                        hs, ws = (t.H // 2, t.W // 2) if t.up else (t.H, t.W)
+                        hit = max(hit, hs * ws * t.ld)
+            self._elems[key] = hit
+        return hit
 
     def _ext(self, im, y, raws, proto=None):
         ptrs = [im.data_ptr(), y.data_ptr()] + [r.data_ptr() if r is not None else None for r in raws]
@@ -85,7 +186,7 @@ class YoloEngine:
             raise ValueError("expected 3 input channels")
         # the kernels keep element offsets in 32 bits: split batches whose largest activation would exceed 2^31
         # elements (e.g. 256 x 1280x1280) into equal chunks -- images are independent
-        big = max(self._packed.wrecs[next(iter(self._packed.wrecs))].cout, 8) * (H // 2) * (W // 2)
+        big = self._max_view_elems(H, W)
         if B > 1 and B * big >= (1 << 31) - (1 << 24):
             n_chunks = -(-B * big // ((1 << 31) - (1 << 24)))
             step = -(-B // n_chunks)
@@ -110,7 +211,7 @@ class YoloEngine:
         if self.autotune and (B, H, W, im.dtype) not in self._tuned:
             # first call for this shape: pick the fastest kernel configuration per conv op (runs the plan once)
             self._tuned.add((B, H, W, im.dtype))
-            L.check(L.lib.bsy_plan_autotune(h, ext, n, C.c_void_p(stream)))
+            self._autotune(plan, h, ext, n, stream)
         L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
         if m["nm"]:  # Segment.forward (head.py:197): (cat(y, mc), (raw, mc, proto)); y already carries the mc rows
             return y, (raws, y[:, 4 + m["nc"]:], proto)

@@ -20,7 +20,7 @@ BSY_EXT_BASE = 0x100000
 (OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW, OP_MSCA_SPATIAL) = range(18)
 
 SYMBOLS = [
-    "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_destroy",
+    "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_create_arena", "bsy_engine_arena_bytes", "bsy_plan_set_tuning", "bsy_plan_destroy",
     "bsy_plan_run", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_check_guards", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_conv2d", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
     "bsy_sppf_pool", "bsy_attention", "bsy_detect_decode", "bsy_nms_workspace_bytes", "bsy_nms", "bsy_scale_boxes",
     "bsy_letterbox", "bsy_process_mask", "bsy_val_match", "bsy_slice_tiles", "bsy_sahi_merge_workspace_bytes",
@@ -82,6 +82,10 @@ def _load() -> C.CDLL:
     lib.bsy_engine_destroy.restype = None
     lib.bsy_engine_load_weights.argtypes = [vp, vp, C.c_size_t]
     lib.bsy_plan_create.argtypes = [vp, C.POINTER(Op), i32, C.POINTER(i64), i32, C.POINTER(vp)]
+    lib.bsy_plan_create_arena.argtypes = [vp, C.POINTER(Op), i32, C.POINTER(i64), C.POINTER(i64), i32, i64, C.POINTER(vp)]
+    lib.bsy_engine_arena_bytes.argtypes = [vp]
+    lib.bsy_engine_arena_bytes.restype = C.c_size_t
+    lib.bsy_plan_set_tuning.argtypes = [vp, C.POINTER(C.c_int32), i32]
     lib.bsy_plan_destroy.argtypes = [vp]
     lib.bsy_plan_destroy.restype = None
     lib.bsy_plan_run.argtypes = [vp, C.POINTER(vp), i32, vp]

@@ -95,7 +95,8 @@ class Plan:
 
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
-                 fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None):
+                 fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None,
+                 fuse_tail: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
@@ -104,6 +105,7 @@ class Plan:
         self.fuse_dwpw = (os.environ.get("BSY_FUSE_DWPW", "1") != "0") if fuse_dwpw is None else bool(fuse_dwpw)
         self.merge_c3k = (os.environ.get("BSY_MERGE_C3K", "1") != "0") if merge_c3k is None else bool(merge_c3k)
         self.fuse_msca = (os.environ.get("BSY_FUSE_MSCA", "1") != "0") if fuse_msca is None else bool(fuse_msca)
+        self.fuse_tail = (os.environ.get("BSY_FUSE_TAIL", "1") != "0") if fuse_tail is None else bool(fuse_tail)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -153,7 +155,8 @@ class Plan:
             key = self._wrec(name, name=name, kind="plain" if plain else "conv", cout=cout, cin=cin, k=k, perm=perm)
         self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
                              src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
-                             act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane, cout=cout))
+                             act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane, cout=cout,
+                             mfma_flops=2 * self.B * OH * OW * cout * cin * k * k))
         self.flops += 2 * self.B * OH * OW * cout * cin * k * k
         return dst
 
@@ -164,7 +167,8 @@ class Plan:
         key = self._wrec(name, name=name, kind="first", cout=cout, cin=3, k=k)
         self.ops.append(dict(kind=L.OP_CONV_FIRST, H=self.H, W=self.W, OH=OH, OW=OW,
                              src0=T(L.BSY_EXT_BASE + self.EXT_IMG, 0, 0, 3, self.H, self.W), dst=dst, ksize=k, stride=s,
-                             pad=p, act=1, wkey=key, in_dtype=self.in_dtype, name=name))
+                             pad=p, act=1, wkey=key, in_dtype=self.in_dtype, name=name,
+                             mfma_flops=2 * self.B * OH * OW * cout * 3 * k * k))
         self.flops += 2 * self.B * OH * OW * cout * 3 * k * k
         return dst
 
@@ -203,7 +207,8 @@ class Plan:
         kp = self._wrec(name + ".1", name=name + ".1", kind="conv", cout=cout, cin=src.C, k=1, perm=None)
         dst = self.alloc(cout, src.H, src.W)
         self.ops.append(dict(kind=L.OP_DWPW, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, dst=dst, ksize=3, stride=1, pad=1,
-                             act=1, wkey=kd, wkey2=kp, name=name, lane=self._lane))
+                             act=1, wkey=kd, wkey2=kp, name=name, lane=self._lane,
+                             mfma_flops=2 * self.B * src.H * src.W * src.C * cout))  # the dense 1x1 part (the depthwise is VALU work)
         self.flops += 2 * self.B * src.H * src.W * src.C * (9 + cout)
         return dst
 
@@ -221,7 +226,8 @@ class Plan:
             k1 = self._wrec(name + ".cv1", name=name + ".cv1", kind="conv", cout=c_, cin=x.C, k=3, perm=None)
             k2 = self._wrec(name + ".cv2", name=name + ".cv2", kind="conv", cout=dst.C, cin=c_, k=3, perm=None)
             self.ops.append(dict(kind=L.OP_BNECK, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=x, dst=dst, ksize=3, stride=1,
-                                 pad=1, act=1, wkey=k1, wkey2=k2, mid_c=c_, name=name, lane=self._lane))
+                                 pad=1, act=1, wkey=k1, wkey2=k2, mid_c=c_, name=name, lane=self._lane,
+                                 mfma_flops=2 * self.B * x.H * x.W * 9 * 2 * c_ * x.C))
             self.flops += 2 * self.B * x.H * x.W * 9 * 2 * c_ * x.C
             return
         t = self.conv(name + ".cv1", x, c_, k[0], 1)
@@ -400,7 +406,8 @@ class Plan:
                     self.wrecs[key] = WRec(name=name + ".upsample", kind="deconv", cout=c_, cin=c_, k=1, tap=(dy, dx))
                 self.ops.append(dict(kind=L.OP_CONV, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=t, src1=None,
                                      dst=T(up.buf, up.ld, 0, c_, x.H, x.W), res=None, ksize=1, stride=1, pad=0, act=0,
-                                     out_f32=0, wkey=key, dst_scale=2, dst_dy=dy, dst_dx=dx, name=key))
+                                     out_f32=0, wkey=key, dst_scale=2, dst_dy=dy, dst_dx=dx, name=key,
+                                     mfma_flops=2 * self.B * x.H * x.W * c_ * c_))
                 self.flops += 2 * self.B * x.H * x.W * c_ * c_
         t = self.conv(name + ".cv2", up, c_, 3, 1)
         p = self.conv(name + ".cv3", t, nm, 1, 1)
@@ -418,7 +425,8 @@ class Plan:
         self.ops.append(dict(kind=L.OP_CONV, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, src1=None, dst=y, res=None,
                              ksize=1, stride=1, pad=0, act=0, out_f32=mode, wkey=key, dst_scale=1, name=name, cout=cout,
                              lane=self._lane, nl=cout, nc=nc, nm=0, A=A, box=[raw], cls=[], msk=[], level=level,
-                             lvl_h=[src.H, a0], lvl_w=[src.W], lvl_stride=[stride], out_dtype=self.out_dtype))
+                             lvl_h=[src.H, a0], lvl_w=[src.W], lvl_stride=[stride], out_dtype=self.out_dtype,
+                             mfma_flops=2 * self.B * src.H * src.W * cout * src.C))
         self.flops += 2 * self.B * src.H * src.W * cout * src.C
 
     def detect(self, name: str, xs: List[T], nc: int, legacy: bool, nm: int = 0, npr: int = 0):
@@ -603,8 +611,97 @@ class Plan:
         self.buf_bytes[mid.buf] = 16  # never written
         self.ops[0:2] = [dict(kind=L.OP_STEM, H=self.H, W=self.W, OH=b["OH"], OW=b["OW"], src0=a["src0"], dst=b["dst"],
                               ksize=3, stride=2, pad=1, act=1, wkey=a["wkey"], wkey2=b["wkey"], mid_c=mid.C,
-                              in_dtype=self.in_dtype, name=a["name"] + "+" + b["name"].split(".")[-1], lane=0)]
+                              in_dtype=self.in_dtype, name=a["name"] + "+" + b["name"].split(".")[-1], lane=0,
+                              mfma_flops=a["mfma_flops"] + b["mfma_flops"])]
         self.layer_out[0] = None
+
+    # ---- workspace layout -----------------------------------------------------------------------------------------
+    _VIEW_KEYS = ("src0", "src1", "dst", "res")
+    _LIST_KEYS = ("box", "cls", "msk")
+
+    def op_buffers(self, o: dict) -> List[int]:
+        """Indices of the workspace buffers an op reads or writes (external slots excluded)."""
+        out = []
+        for k in self._VIEW_KEYS:
+            t = o.get(k)
+            if t is not None and t.buf < L.BSY_EXT_BASE:
+                out.append(t.buf)
+        for k in self._LIST_KEYS:
+            for t in o.get(k, []) or []:
+                if t is not None and t.buf < L.BSY_EXT_BASE:
+                    out.append(t.buf)
+        return out
+
+    def buffer_lifetimes(self) -> List[Optional[Tuple[int, int]]]:
+        """Per buffer: (first, last) index of the ops that touch it, or None for a buffer no op uses.  Ops on side lanes run
+        concurrently with everything between their fork and the next join (csrc/engine.hip bsy_plan_run), so every buffer a
+        lane op touches is kept alive over that whole region: the serial op order says nothing about when a lane runs."""
+        n = len(self.ops)
+        life: List[Optional[List[int]]] = [None] * len(self.buf_bytes)
+        for i, o in enumerate(self.ops):
+            for b in self.op_buffers(o):
+                if life[b] is None:
+                    life[b] = [i, i]
+                else:
+                    life[b][1] = i
+        i = 0
+        while i < n:
+            if self.ops[i].get("lane", 0) > 0:
+                start = i
+                end = n - 1  # the tail join of bsy_plan_run
+                for j in range(i + 1, n):
+                    if self.ops[j].get("join", 0):
+                        end = j
+                        break
+                for j in range(start, end + 1):
+                    if self.ops[j].get("lane", 0) > 0:
+                        for b in self.op_buffers(self.ops[j]):
+                            life[b][0] = min(life[b][0], start)
+                            life[b][1] = max(life[b][1], end)
+                i = end + 1
+            else:
+                i += 1
+        return [tuple(x) if x is not None else None for x in life]
+
+    def assign_offsets(self, reuse: bool = True) -> Tuple[List[int], int]:
+        """Byte offset of every buffer inside one arena and the arena size.  reuse: buffers whose lifetimes are disjoint may
+        share addresses (greedy by size: each buffer, largest first, takes the lowest offset free of every already placed
+        buffer it is live together with) -- YOLO11s at batch 64, 640 x 640: 3.8 GB of buffers in a 1.3 GB arena."""
+        sizes = [(b + 255) & ~255 for b in self.buf_bytes]
+        offs = [0] * len(sizes)
+        if not reuse:
+            off = 0
+            for i, sz in enumerate(sizes):
+                offs[i] = off
+                off += sz
+            return offs, off
+        life = self.buffer_lifetimes()
+        placed: List[int] = []
+        top = 0
+        for i in sorted(range(len(sizes)), key=lambda k: (-sizes[k], k)):
+            if life[i] is None or sizes[i] == 0:
+                continue
+            busy = sorted((offs[j], offs[j] + sizes[j]) for j in placed
+                          if not (life[j][1] < life[i][0] or life[i][1] < life[j][0]))
+            at = 0
+            for lo, hi in busy:
+                if at + sizes[i] <= lo:
+                    break
+                at = max(at, hi)
+            offs[i] = at
+            placed.append(i)
+            top = max(top, at + sizes[i])
+        return offs, top
+
+    def conv_signature(self, o: dict) -> Optional[tuple]:
+        """What decides which kernel configuration is fastest for a conv op (and which are valid): the key of the engine's
+        autotune cache.  None for ops the autotuner does not touch."""
+        if o["kind"] != L.OP_CONV:
+            return None
+        s0, s1, d, r = o["src0"], o.get("src1"), o["dst"], o.get("res")
+        return (self.B, o["H"], o["W"], s0.C, s0.ld, int(s0.up), s1.C if s1 else 0, s1.ld if s1 else 0, int(s1.up) if s1 else 0,
+                o.get("cout", d.C), d.ld, o["ksize"], o["stride"], int(r is not None), r.ld if r is not None else 0,
+                o.get("out_f32", 0), o.get("dst_scale", 1), o.get("act", 0))
 
     # ---- serialisation ------------------------------------------------------------------------------------------
     def c_ops(self):

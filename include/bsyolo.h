@@ -132,12 +132,23 @@ int bsy_engine_load_weights(bsy_engine* e, const void* host_blob, size_t bytes);
 
 /* ops: HOST array; buf_bytes: HOST array of workspace buffer sizes.  The plan owns its workspace. */
 int bsy_plan_create(bsy_engine* e, const bsy_op* ops, int n_ops, const int64_t* buf_bytes, int n_bufs, bsy_plan** out);
+/* The same with the buffers at HOST-assigned byte offsets buf_off[] (multiples of 256, may overlap) inside ONE activation
+ * arena owned by the ENGINE and shared by all of its plans: bs_yolo_amd/plan.py assigns the offsets from buffer liveness, so a
+ * forward needs the peak of its live activations instead of their sum, and 40 input shapes (val rect batches,
+ * data/base.py:261-284; predict's `auto` letterbox) need the arena of the largest one instead of 40 workspaces.  The arena
+ * grows (after a device synchronisation) when a plan needs more.  Plans of one engine must not run concurrently. */
+int bsy_plan_create_arena(bsy_engine* e, const bsy_op* ops, int n_ops, const int64_t* buf_bytes, const int64_t* buf_off, int n_bufs,
+                          int64_t arena_bytes, bsy_plan** out);
+size_t bsy_engine_arena_bytes(const bsy_engine* e);
 void bsy_plan_destroy(bsy_plan* p);
 /* ext: HOST array of n_ext device pointers bound to the external slots (input image, y, raw maps ...). */
 int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
 /* Times every valid kernel configuration of every conv op once (HIP events on `stream`, synchronises) and records the
  * fastest per op; later bsy_plan_run calls use it.  Results are bit-identical across configurations. */
 int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
+/* HOST array cfg[n_ops]: cfg[i] >= 0 presets conv op i to that configuration (bsy_plan_autotune then skips it: results of an
+ * earlier plan with the same conv shape are reused), -1 leaves the op as it is, -2 clears it. */
+int bsy_plan_set_tuning(bsy_plan* p, const int32_t* cfg, int n_ops);
 /* HOST out[n_ops]: configuration id per op (tile << 4 | variant), -1 for non-conv / untuned ops. */
 int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n_ops);
 /* Test aid: plans created with BSY_PLAN_GUARD=<bytes> in the environment keep a guard band of that many bytes (0xA5) behind

@@ -679,7 +679,9 @@ class Model:
         """Count as the reference does (Parameters only: BN running stats are buffers)."""
         return sum(int(np.prod(s)) for n, s in self.param_specs() if "running_" not in n)
 
-    def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor):
+    def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, return_layers: bool = False):
+        """nn/tasks.py:138-165.  return_layers: also return the list of every top-level layer's output (what the fixtures'
+        `layer0_i` entries hold for the reference itself)."""
         y: List = []
         for f, m in self.layers:
             if f != -1:
@@ -691,7 +693,7 @@ class Model:
             else:
                 x = m(P, x)
             y.append(x)
-        return x
+        return (x, y) if return_layers else x
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,265 @@
+"""The drop-in boundary, exercised the way the reference reaches it: `plugin.accelerate`
+on a stand-in for a reference model, and every `install_*` hook on stand-ins for the reference's modules / instances.
+
+`/root/reference` does not exist on the GPU box, so the stand-ins are built here: an ``nn.Module`` tree whose
+``state_dict()`` carries the reference's parameter names (the graph is `graphs.stock_cfg`, the reference's own yaml
+schema), with the CPU oracle as its "original" forward, and plain objects carrying the attributes the hooks read
+(nn/autobackend.py:136-147,524; models/yolo/detect/predict.py:25; detect/val.py:93-103,209-228; engine/predictor.py:116-134).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from bs_yolo_amd import plugin
+    from bs_yolo_amd.engine import YoloEngine
+    from bs_yolo_amd.graphs import stock_cfg
+
+from oracle import letterbox_ref as LB
+from oracle import postproc_ref as PP
+from oracle import val_ref as VR
+from oracle import yolo_ref as R
+
+DEV = "cuda:0"
+
+
+class StandIn(torch.nn.Module):
+    """What `accelerate` needs of a reference DetectionModel: `.yaml` (nn/tasks.py:313), `state_dict()` under the
+    reference's names, `.training`, `.half()/.to()`, and a forward with the reference's signature (tasks.py:112-136)."""
+
+    def __init__(self, family="yolo11", scale="n", nc=80, task="detect", seed=0):
+        super().__init__()
+        self.yaml = stock_cfg(family, scale, nc, task)
+        self.ref = R.Model(family, scale, nc, task)
+        for name, t in R.synth_params(self.ref, seed).items():
+            mod = self
+            *path, leaf = name.split(".")
+            for p in path:
+                if not hasattr(mod, p):
+                    mod.add_module(p, torch.nn.Module())
+                mod = getattr(mod, p)
+            if leaf in ("running_mean", "running_var", "num_batches_tracked"):
+                mod.register_buffer(leaf, t.clone())
+            else:
+                mod.register_parameter(leaf, torch.nn.Parameter(t.clone(), requires_grad=False))
+        self.calls = 0
+        self.eval()
+
+    def forward(self, x, *args, **kwargs):  # the "reference" forward: CPU oracle on the module's current parameters
+        self.calls += 1
+        P = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
+        with torch.inference_mode():
+            y, aux = self.ref.forward(P, x.detach().float().cpu())
+        return y.to(x.device, x.dtype), [a.to(x.device, x.dtype) for a in aux]
+
+
+def _x(B=2, H=64, W=96, seed=0):
+    return torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(seed))
+
+
+def test_accelerate_runs_the_engine_and_matches_it():
+    m = StandIn().to(DEV)
+    plugin.accelerate(m, fp32_inputs="engine")
+    x = _x().half().to(DEV)
+    y, raws = m(x)
+    assert m.calls == 0 and m._bsy_state["engine_calls"] == 1
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    eng = YoloEngine(m.yaml, sd)
+    y2, raws2 = eng(x)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and all(torch.equal(a, b) for a, b in zip(raws, raws2))
+    # tuple structure and dtypes AutoBackend relies on (autobackend.py:524-525, head.py:74)
+    assert y.dtype == x.dtype and tuple(y.shape) == (2, 84, 8 * 12 + 4 * 6 + 2 * 3) and len(raws) == 3
+    # fp32 in -> fp32 out under the opt-in
+    y32, _ = m(_x().to(DEV))
+    assert y32.dtype == torch.float32 and m.calls == 0
+    eng.close()
+    plugin.restore(m)
+    assert not hasattr(m, "_bsy_state")
+    m(x)
+    assert m.calls == 1
+
+
+def test_accelerate_falls_back_where_the_engine_does_not_apply():
+    m = StandIn().to(DEV)
+    plugin.accelerate(m)
+    xh = _x().half().to(DEV)
+    n = 0
+    for kw in (dict(augment=True), dict(visualize=True), dict(embed=[1]), dict(profile=True)):  # tasks.py:134-164
+        m(xh, **kw)
+        n += 1
+        assert m.calls == n, kw
+    m(_x(H=72).half().to(DEV)); n += 1          # not a multiple of the max stride
+    m(_x().half()); n += 1                      # CPU tensor
+    m(_x().to(DEV)); n += 1                     # fp32 caller, default policy: the reference's fp32 arithmetic
+    m.train(); m(xh); n += 1; m.eval()          # training mode (head.py:71-72)
+    assert m.calls == n and m._bsy_state["engine_calls"] == 0 and m._bsy_state["fallbacks"] == n
+    m(xh)
+    assert m.calls == n and m._bsy_state["engine_calls"] == 1
+    plugin.restore(m)
+
+
+def test_accelerate_follows_weight_updates_half_and_to():
+    m = StandIn(seed=1).to(DEV)
+    plugin.accelerate(m)
+    x = _x(seed=3).half().to(DEV)
+    y0, _ = m(x)
+    m(x)
+    assert m._bsy_state["rebuilds"] == 1
+    m.half()                                    # AutoBackend's fp16 path (autobackend.py:143-145; nn/tasks.py:254 _apply)
+    y1, _ = m(x)
+    assert m._bsy_state["rebuilds"] == 2
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    eng = YoloEngine(m.yaml, sd)
+    assert torch.equal(y1, eng(x)[0])
+    eng.close()
+    # an in-place update (optimizer step / EMA / load_state_dict copy_) must not be served from stale weights
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("cv3.0.2.bias"):
+                p.add_(1.0)
+    y2, _ = m(x)
+    assert m._bsy_state["rebuilds"] == 3 and not torch.equal(y2, y1)
+    assert float((y2[:, 4:, :96] - y1[:, 4:, :96]).float().min()) > 0  # the P3 class scores rose
+    m.float().to("cpu").to(DEV)
+    m(x)
+    assert m._bsy_state["rebuilds"] == 4
+    plugin.restore(m)
+
+
+def test_accelerate_rejects_unsupported_graphs():
+    m = StandIn()
+    m.yaml = dict(m.yaml, head=[[-1, 1, "Pose", [80, [17, 3]]]])
+    with pytest.raises((NotImplementedError, AssertionError)):
+        plugin.accelerate(m)
+
+
+# ---- NMS hook (models/yolo/detect/predict.py:25, detect/val.py:95) -------------------------------------------------------
+def _pred(B=3, nc=80, A=600, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.zeros(B, 4 + nc, A)
+    p[:, :2] = torch.rand(B, 2, A, generator=g) * 600 + 20
+    p[:, 2:4] = torch.rand(B, 2, A, generator=g) * 120 + 8
+    p[:, 4:] = torch.rand(B, nc, A, generator=g) ** 6
+    return p
+
+
+def test_install_nms_dispatch():
+    calls = []
+
+    def ref_nms(prediction, *a, **k):
+        calls.append((a, k))
+        p = prediction[0] if isinstance(prediction, (list, tuple)) else prediction
+        return PP.non_max_suppression(p.float().cpu(), *a[:5], **{kk: v for kk, v in k.items() if kk in ("conf_thres", "iou_thres", "classes", "agnostic", "multi_label", "max_det")})
+
+    ops = types.SimpleNamespace(non_max_suppression=ref_nms)
+    f = plugin.install_nms(ops)
+    assert ops.non_max_suppression is f and plugin.install_nms(ops) is f  # idempotent
+    pred = _pred()
+    want = PP.non_max_suppression(pred.clone(), 0.25, 0.7)
+    # keyword call as the predictor makes it (predict.py:25-33), tuple input as the validator passes it (ops.py:219)
+    got = ops.non_max_suppression((pred.clone().to(DEV), None), 0.25, 0.7, agnostic=False, max_det=300, classes=None)
+    assert not calls and all(torch.equal(a.cpu(), b) for a, b in zip(got, want))
+    # every argument positional, labels (index 5) empty: round 1 read `multi_label` (index 4) as labels and raised
+    got = ops.non_max_suppression(pred.clone().to(DEV), 0.25, 0.7, None, False, True, (), 300)
+    want_ml = PP.non_max_suppression(pred.clone(), 0.25, 0.7, None, False, True)
+    assert not calls and all(torch.equal(a.cpu(), b) for a, b in zip(got, want_ml))
+    # what stays on the reference: CPU tensors, autolabels (positional and keyword), rotated, end2end-shaped input
+    ops.non_max_suppression(pred.clone(), 0.25, 0.7)
+    ops.non_max_suppression(pred.clone().to(DEV), 0.25, 0.7, None, False, False, [torch.zeros(0, 5)] * 3)
+    ops.non_max_suppression(pred.clone().to(DEV), 0.25, 0.7, labels=[torch.zeros(0, 5)] * 3)
+    ops.non_max_suppression(pred.clone().to(DEV), 0.25, 0.7, rotated=True)
+    assert len(calls) == 4
+
+
+def test_install_masks_dispatch():
+    calls = []
+
+    def ref_pm(protos, masks_in, bboxes, shape, upsample=False):
+        calls.append(1)
+        return PP.process_mask(protos.float().cpu(), masks_in.float().cpu(), bboxes.float().cpu(), shape, upsample)
+
+    ops = types.SimpleNamespace(process_mask=ref_pm)
+    plugin.install_masks(ops)
+    g = torch.Generator().manual_seed(0)
+    protos, mc = torch.randn(32, 40, 40, generator=g), torch.randn(5, 32, generator=g)
+    xy = torch.rand(5, 2, generator=g) * 80
+    boxes = torch.cat([xy, xy + torch.rand(5, 2, generator=g) * 70 + 4], 1)
+    want = PP.process_mask(protos, mc, boxes, (160, 160), True)
+    got = ops.process_mask(protos.to(DEV), mc.to(DEV), boxes.to(DEV), (160, 160), upsample=True)
+    assert not calls and got.is_cuda and torch.equal(got.cpu().bool(), want.bool())
+    ops.process_mask(protos, mc, boxes, (160, 160), True)
+    assert len(calls) == 1
+
+
+def test_install_val_metrics_and_ap_per_class():
+    iouv = torch.linspace(0.5, 0.95, 10)
+
+    class Validator:  # models/yolo/detect/val.py:209-228
+        def __init__(self):
+            self.iouv = iouv.to(DEV)
+            self.calls = 0
+
+        def _process_batch(self, detections, gt_bboxes, gt_cls):
+            self.calls += 1
+            return torch.from_numpy(VR.process_batch(detections.cpu().numpy(), gt_bboxes.cpu().numpy(), gt_cls.cpu().numpy()))
+
+    v = plugin.install_val_metrics(Validator())
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(12, 2, generator=g) * 400
+    gt = torch.cat([gt, gt + torch.rand(12, 2, generator=g) * 100 + 10], 1)
+    gcls = torch.randint(0, 4, (12,), generator=g).float()
+    det = torch.cat([gt[torch.randint(0, 12, (40,), generator=g)] + torch.randn(40, 4, generator=g) * 6,
+                     torch.rand(40, 1, generator=g), torch.randint(0, 4, (40, 1), generator=g).float()], 1)
+    want = VR.process_batch(det.numpy(), gt.numpy(), gcls.numpy())
+    got = v._process_batch(det.to(DEV), gt.to(DEV), gcls.to(DEV))
+    assert v.calls == 0 and np.array_equal(got.cpu().numpy(), want)
+    v._process_batch(det, gt, gcls)  # CPU detections: the reference's numpy path
+    assert v.calls == 1
+
+    calls = []
+
+    def ref_ap(tp, conf, pred_cls, target_cls, plot=False, on_plot=None, save_dir=None, names={}, eps=1e-16, prefix=""):
+        calls.append(plot)
+        return VR.ap_per_class(tp, conf, pred_cls, target_cls, eps)
+
+    metrics = types.SimpleNamespace(ap_per_class=ref_ap)
+    plugin.install_ap_per_class(metrics, device=DEV)
+    rng = np.random.default_rng(0)
+    n = 500
+    tp = rng.random((n, 10)) < np.linspace(0.7, 0.2, 10)
+    conf, pc, tc = rng.random(n), rng.integers(0, 5, n).astype(float), rng.integers(0, 5, 200).astype(float)
+    want = VR.ap_per_class(tp, conf, pc, tc)
+    got = metrics.ap_per_class(tp, conf, pc, tc, names={i: str(i) for i in range(5)})
+    assert not calls
+    for a, b in zip(got, want):
+        assert np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=0, atol=1e-12)
+    metrics.ap_per_class(tp, conf, pc, tc, plot=True)  # plotting stays the reference's
+    assert calls == [True]
+
+
+def test_install_preprocess_dispatch():
+    class Predictor:  # engine/predictor.py:116-134
+        def __init__(self):
+            self.device = torch.device(DEV)
+            self.imgsz = (64, 96)
+            self.model = types.SimpleNamespace(fp16=True, pt=True, stride=32)
+            self.calls = 0
+
+        def preprocess(self, im):
+            self.calls += 1
+            return im
+
+    p = plugin.install_preprocess(Predictor())
+    rng = np.random.default_rng(1)
+    ims = [rng.integers(0, 256, (50, 70, 3), dtype=np.uint8), rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)]
+    out = p.preprocess(ims)
+    want = LB.preprocess(ims, (64, 96), half=True, pt=True, stride=32)
+    assert p.calls == 0 and out.is_cuda and out.dtype == torch.float16
+    assert torch.equal(out.cpu(), want.half())
+    t = torch.zeros(1, 3, 64, 96)
+    assert p.preprocess(t) is t and p.calls == 1  # tensor sources skip the letterbox (predictor.py:123-134)

@@ -1021,3 +1021,104 @@ def test_letterbox_golden_pixels():
         torch.cuda.synchronize()
         exp = torch.from_numpy(np.ascontiguousarray(z[f"lb{k}"][..., ::-1].transpose(2, 0, 1))).float() / 255
         assert torch.equal(out[0].cpu(), exp)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# per-layer parity: every top-level layer output of the engine against the REFERENCE's own layer
+# outputs (fixtures layer0_i, generated by tests/golden/make_fixtures.py from the imported reference) and against the
+# oracle run with the engine's storage precision.  An end-to-end bound cannot localise a bad kernel; this one does.
+# ------------------------------------------------------------------------------------------------------------
+LAYER_TOL_EMU = 2e-3   # vs the fp16-storage oracle, as a share of the layer's range (max |ref|): kernel error only
+LAYER_TOL_REF = 4e-3   # vs the reference's fp32 outputs: adds the fp16 storage error accumulated up to that layer
+
+
+@pytest.mark.parametrize("tag", ["yolo11n_detect", "bsyolo11n_detect"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_engine_every_layer_matches_reference(tag, fused, monkeypatch):
+    monkeypatch.setenv("BSY_ARENA_REUSE", "0")  # keep every layer's buffer alive until the end of the forward
+    z = np.load(GOLDEN / f"graph_{tag}.npz")
+    meta = json.loads(str(z["meta"]))
+    m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
+    P = R.synth_params(m, meta["seed"])
+    kw = {} if fused else dict(fuse_stem=False, fuse_bneck=False, fuse_head=False, fuse_dwpw=False, merge_c3k=False, fuse_msca=False,
+                               fuse_tail=False)
+    eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), P, **kw)
+    x = torch.from_numpy(z["x0"])
+    eng(x.half().to(DEV))
+    torch.cuda.synchronize()
+    plan, h = eng.plan_for(x.shape[0], x.shape[2], x.shape[3], torch.float16, torch.float16)
+    R.FP16_EMULATION = True
+    try:
+        with torch.inference_mode():
+            _, emu = m.forward(P, x.half().float(), return_layers=True)
+    finally:
+        R.FP16_EMULATION = False
+    rows, checked = [], 0
+    for i, t in enumerate(plan.layer_out):
+        if t is None:  # fused away (layer 0 inside the stem launch) or the head
+            continue
+        got = (torch.cat([eng.read_view(plan, h, v) for v in t], 1) if isinstance(t, list) else eng.read_view(plan, h, t)).numpy()
+        ref, q = z[f"layer0_{i}"], emu[i].numpy()
+        assert got.shape == ref.shape == q.shape, (i, got.shape, ref.shape)
+        scale = np.abs(ref).max()
+        rows.append((i, np.abs(got - q).max() / scale, np.abs(got - ref).max() / scale))
+        checked += 1
+    eng.close()
+    assert checked >= len(plan.layer_out) - 3
+    bad = [r for r in rows if r[1] > LAYER_TOL_EMU or r[2] > LAYER_TOL_REF]
+    assert not bad, "layer, err vs fp16-emulating oracle, err vs reference (shares of the layer's range): " + \
+        ", ".join(f"{i}: {a:.2e} / {b:.2e}" for i, a, b in rows)
+
+
+def test_engine_memory_and_tuning_stay_bounded_over_rect_shapes():
+    """val runs rect=True by default (engine/model.py:635: per-batch shapes, data/base.py:261-284) and predict's `auto`
+    letterbox varies (H, W) too.  40 distinct shapes through ONE engine: the activation arena stays at the size of the
+    largest plan (round 1 kept a private 3.8 GB workspace per shape), old plans are evicted, no conv shape is timed twice,
+    and results do not depend on which plans came before."""
+    cfg = stock_cfg("yolo11", "n")
+    m = R.Model("yolo11", "n", 80, "detect")
+    P = R.synth_params(m, 0)
+    eng = YoloEngine(cfg, P, max_plans=4)
+    shapes = [(4, 32 * h, 32 * w) for h in range(6, 14) for w in range(8, 13)]  # 192..416 x 256..384
+    assert len(set(shapes)) == 40
+    free0, _ = torch.cuda.mem_get_info()
+    g = torch.Generator().manual_seed(0)
+    first = {}
+    largest = 0
+    for (B, H, W) in shapes:
+        x = torch.rand(B, 3, H, W, generator=g).half().to(DEV)
+        y, _ = eng(x)
+        first[(B, H, W)] = (x, y.clone())
+        plan, _ = eng.plan_for(B, H, W, torch.float16, torch.float16)
+        largest = max(largest, plan.arena_bytes)
+    torch.cuda.synchronize()
+    assert len(eng._plans) == 4
+    assert eng.arena_bytes <= largest + 4096, (eng.arena_bytes, largest)
+    # device memory actually taken by the library (hipMalloc, not torch's allocator): arena + weights + slack
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    held = sum(x.numel() * 2 + y.numel() * 2 for x, y in first.values())
+    assert free0 - free1 < 1.5 * largest + held + (64 << 20), (free0 - free1, largest, held)
+    st = dict(eng.tune_stats)
+    assert st["autotune_calls"] == 40
+    # revisit every shape (36 of them were evicted): nothing is timed again, outputs are bit-identical to the first visit
+    for (B, H, W), (x, y0) in first.items():
+        y, _ = eng(x)
+        assert torch.equal(y, y0), (B, H, W)
+    assert eng.tune_stats["timed_ops"] == st["timed_ops"]
+    # the family cache (same layer, pixel count within 2x) answers most rect shapes without timing
+    assert st["family_ops"] > 10 * st["timed_ops"] / 40, st
+    eng.close()
+
+
+def test_engine_splits_batches_by_the_largest_view():
+    """the automatic batch split must size by the largest activation view (YOLOv8 C2f concat buffers), not by the
+    first conv's output."""
+    cfg = stock_cfg("yolov8", "n", 80, "detect")
+    m = R.Model("yolov8", "n", 80, "detect")
+    eng = YoloEngine(cfg, R.synth_params(m, 0), autotune=False)
+    per_img = eng._max_view_elems(640, 640)
+    p1 = eng.plan_for(1, 640, 640, torch.float16, torch.float16)[0]
+    widest = max((t.H * t.W * t.ld) for o in p1.ops for t in [o.get("dst")] if t is not None and t.buf < 0x100000)
+    assert per_img >= widest
+    eng.close()

@@ -417,3 +417,16 @@ def test_build_signature_tracks_flags_and_headers(tmp_path):
     assert s0 != Bd._signature(["hipcc", "gfx950", "-fno-slp-vectorize", "a.hip"], src, [hdr])
     hdrs = sorted(p.name for p in Bd.CSRC.glob("*.h"))
     assert "image_conv.h" in hdrs and "common.h" in hdrs
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (it exited asking for
+    torch.distributed.run).  Without a GPU every rank stops at bench.py's own "needs a ROCm GPU" check -- which proves that
+    the child launcher ran bench.py under WORLD_SIZE = 2 (the parent never gets that far: it only relays)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box this would start a real 2-rank run")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a ROCm GPU") >= 2, r.stderr[-2000:]
