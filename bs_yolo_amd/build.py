@@ -36,6 +36,7 @@ SOURCES = {
     "val_match.hip": ["-ffp-contract=off"],
     "val_ap.hip": ["-ffp-contract=off"],
     "sahi.hip": ["-ffp-contract=off"],
+    "ref32.hip": ["-ffp-contract=off"],
     "engine.hip": [],
 }
 

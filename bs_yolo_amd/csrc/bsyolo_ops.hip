@@ -268,7 +268,12 @@ __device__ __forceinline__ f32x2 msca_fma2(f32x2 a, f32x2 b, f32x2 c) { return f
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 msca_round2(f32x2 a, half2_t& o) {  // f16 rounding of a map element, kept as f32
-    const half_t o0 = (half_t)a[0], o1 = (half_t)a[1];  // converted back from two separate registers (no SDWA half select)
+    // The f32 sums pass through an empty asm before the conversion: with scalar FMAs the compiler otherwise folds the last
+    // FMA of a chain and the conversion into v_fma_mixlo/hi_f16, which rounds the exact sum ONCE -- the separate launches this
+    // kernel must equal bit for bit round twice (f32, then f16), and 3e-4 of the elements differed by one f16 ulp.
+    float a0 = a[0], a1 = a[1];
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    const half_t o0 = (half_t)a0, o1 = (half_t)a1;  // converted back from two separate registers (no SDWA half select)
     o[0] = o0; o[1] = o1;
     return f32x2{(float)o0, (float)o1};
 }
@@ -646,6 +651,18 @@ __global__ __launch_bounds__(256) void ela_apply_kernel(const half_t* __restrict
 
 size_t ela_scratch_floats(int H, int W, int C) { return (size_t)(2 * (H + W) + 2) * C; }
 
+// means in the scratch -> gates in the scratch (f32 only: shared by the fp16 path and the fp32 correctness mode, ref32.hip)
+int launch_ela_gate(const ElaArgs& a, hipStream_t s) {
+    const int gsz = a.C >= 16 ? 16 : a.C;
+    const int Lmax = a.H > a.W ? a.H : a.W;
+    const size_t lds = ((size_t)Lmax * gsz + 512) * sizeof(float);
+    if (lds > 64 * 1024) BSY_FAIL(BSY_ERR_ARG, "ela: map side %d too long for the gate kernel", Lmax);
+    hipLaunchKernelGGL(ela_gate_kernel, dim3(a.C / gsz, a.B, 2), dim3(256), lds, s, a.scratch, ela_scratch_floats(a.H, a.W, a.C), a.H, a.W,
+                       a.C, a.k, gsz, a.wsp, a.wch, a.gnw, a.gnb);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
 int launch_ela(const ElaArgs& a, hipStream_t s) {
     if (!a.src || !a.dst || !a.scratch || !a.wsp || !a.wch || !a.gnw || !a.gnb) BSY_FAIL(BSY_ERR_ARG, "ela: null pointer");
     if ((a.C & 15) || (a.lds & 7) || (a.ldd & 7) || (((uintptr_t)a.src | (uintptr_t)a.dst) & 15) || a.k < 1 || !(a.k & 1) || a.k > 15 ||
@@ -659,8 +676,10 @@ int launch_ela(const ElaArgs& a, hipStream_t s) {
     if (lds > 64 * 1024) BSY_FAIL(BSY_ERR_ARG, "ela: map side %d too long for the gate kernel", Lmax);
     if (a.C / 8 > 256) BSY_FAIL(BSY_ERR_ARG, "ela: more than 2048 channels");
     hipLaunchKernelGGL(ela_stats_kernel, dim3(Lmax, a.B, 2), dim3(256), 0, s, a.src, a.lds, a.H, a.W, a.C, a.scratch, per_img);
-    hipLaunchKernelGGL(ela_gate_kernel, dim3(groups, a.B, 2), dim3(256), lds, s, a.scratch, per_img, a.H, a.W, a.C, a.k, gsz, a.wsp,
-                       a.wch, a.gnw, a.gnb);
+    {
+        const int rc = launch_ela_gate(a, s);
+        if (rc != BSY_OK) return rc;
+    }
     const long long total = (long long)a.B * a.H * a.W * (a.C / 8);
     hipLaunchKernelGGL(ela_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, a.H, a.W, a.C,
                        a.scratch, per_img, a.ch_coef, a.sp_coef, a.res_coef, a.dst, a.ldd);

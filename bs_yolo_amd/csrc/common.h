@@ -157,6 +157,52 @@ struct ElaArgs {
 };
 size_t ela_scratch_floats(int H, int W, int C);
 int launch_ela(const ElaArgs& a, hipStream_t s);
+int launch_ela_gate(const ElaArgs& a, hipStream_t s);
+
+// ---- fp32 correctness mode (ref32.hip): plans with bsy_op.prec == 1; NHWC f32 views --------------------------------------------
+struct Conv32Args {
+    const void* src0;    // f32 view, or (first) the BCHW image in src_dtype
+    const void* src1;
+    int src_dtype, first;
+    int ld0, ld1, C0, C1, up0, up1;
+    int B, H, W, OH, OW, ks, stride, pad;
+    const float* w;      // f32 [k*k*Cin][Cout], k = (kh, kw, cin)
+    const float* bias;   // f32 [Cout]
+    float* dst;
+    int ldd, Cout;
+    const float* res;
+    int ldr, act, dst_scale, dst_dy, dst_dx;
+};
+int launch_conv32(const Conv32Args& a, hipStream_t s);
+struct Dw32Args {
+    const float* src;
+    int lds, B, H, W, C, OH, OW, kh, kw, stride;
+    const float* w;      // f32 [kh*kw][wld]
+    int wld;
+    const float* b;
+    float* dst;
+    int ldd, act_c;
+    const float* res;
+    int ldr;
+};
+int launch_dw32(const Dw32Args& a, hipStream_t s);
+struct Mix32Args {
+    const float* br[4];
+    int ldb[4];
+    const float* lg[4];
+    int ldl[4];
+    int B, HW, C;
+    float* dst;
+    int ldd;
+};
+int launch_mix32(const Mix32Args& a, hipStream_t s);
+int launch_sppf32(float* buf, int ld, int B, int H, int W, int C, hipStream_t s);
+int launch_attn32(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s);
+int launch_nhwc2nchw32(const float* src, int ld, int B, int C, int hw, void* out, int out_dtype, hipStream_t s);
+int launch_copy32(const float* src, int lds_, int up, int B, int H, int W, int C, float* dst, int ldd, hipStream_t s);
+int launch_gap32(const float* src, int lds_, int B, int H, int W, int C, float* out, int ldo, hipStream_t s);
+int launch_mul32(const float* x, int ldx, const float* y, int ldy, long long npix, int C, float* dst, int ldd, hipStream_t s);
+int launch_ela32(const ElaArgs& a, const float* src, float* dst, hipStream_t s);  // a.src / a.dst unused
 
 // Fused DWConv 3x3 (+SiLU) -> Conv 1x1 (+act) (conv_mfma.hip: dwpw_fused_kernel)
 struct DwPwArgs {

@@ -228,8 +228,125 @@ struct Resolver {
     float* f(const bsy_view& v) { char* b = base(v); return b ? (float*)b + v.coff : nullptr; }
 };
 
+// fp32 correctness mode (bsy_op.prec == 1): same op records, f32 views, kernels of ref32.hip.  DECODE and RAW_NCHW consume f32
+// logit maps in both modes and fall through to the common path.
+int run_op_f32(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, bool& handled) {
+    const char* wb = (const char*)p->eng->weights;
+    handled = true;
+    switch (op.kind) {
+        case BSY_OP_CONV_FIRST:
+        case BSY_OP_CONV: {
+            Conv32Args a;
+            memset(&a, 0, sizeof(a));
+            a.first = op.kind == BSY_OP_CONV_FIRST;
+            a.src0 = a.first ? (const void*)R.base(op.src0) : (const void*)R.f(op.src0);
+            a.src_dtype = op.in_dtype;
+            a.src1 = R.f(op.src1);
+            a.ld0 = op.src0.ld; a.ld1 = op.src1.buf >= 0 ? op.src1.ld : 0;
+            a.C0 = op.src0.C; a.C1 = op.src1.buf >= 0 ? op.src1.C : 0;
+            a.up0 = op.up0; a.up1 = op.up1;
+            a.B = op.B; a.H = op.H; a.W = op.W; a.OH = op.OH; a.OW = op.OW; a.ks = op.ksize; a.stride = op.stride; a.pad = op.pad;
+            a.w = (const float*)(wb + op.w_off); a.bias = (const float*)(wb + op.b_off);
+            a.dst = R.f(op.dst); a.ldd = op.dst.ld; a.Cout = op.dst.C;
+            a.res = R.f(op.res); a.ldr = op.res.buf >= 0 ? op.res.ld : 0;
+            a.act = op.act; a.dst_scale = op.dst_scale > 0 ? op.dst_scale : 1; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
+            if (op.out_f32 >= 2) BSY_FAIL(BSY_ERR_ARG, "fp32 mode: fused Detect decoder ops are not part of fp32 plans");
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_conv32(a, s);
+        }
+        case BSY_OP_DWCONV:
+        case BSY_OP_DWCONV_G: {
+            Dw32Args a;
+            memset(&a, 0, sizeof(a));
+            const bool g = op.kind == BSY_OP_DWCONV_G;
+            a.src = R.f(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C; a.OH = op.OH; a.OW = op.OW;
+            a.kh = g ? op.ksize : 3; a.kw = g ? op.pad : 3; a.stride = g ? op.stride : 1;
+            a.wld = g ? op.heads : op.src0.C;
+            a.w = (const float*)(wb + op.w_off) + (g ? op.key_dim : 0); a.b = (const float*)(wb + op.b_off) + (g ? op.key_dim : 0);
+            a.dst = R.f(op.dst); a.ldd = op.dst.ld; a.act_c = g ? op.act : (op.act ? op.src0.C : 0);
+            a.res = g ? nullptr : R.f(op.res); a.ldr = (!g && op.res.buf >= 0) ? op.res.ld : 0;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_dw32(a, s);
+        }
+        case BSY_OP_SPPF_POOL: {
+            float* b = R.f(op.src0);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_sppf32(b, op.src0.ld, op.B, op.H, op.W, op.src0.C, s);
+        }
+        case BSY_OP_ATTN: {
+            const float* q = R.f(op.src0);
+            float* o = R.f(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_attn32(q, op.src0.ld, op.B, op.H * op.W, op.heads, op.key_dim, op.head_dim, op.scale, o, op.dst.ld, s);
+        }
+        case BSY_OP_NHWC2NCHW: {
+            if (op.dst.buf >= BSY_EXT_BASE && (op.dst.buf - BSY_EXT_BASE >= R.n_ext || !R.ext[op.dst.buf - BSY_EXT_BASE])) return BSY_OK;
+            const float* src = R.f(op.src0);
+            void* out = R.base(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_nhwc2nchw32(src, op.src0.ld, op.B, op.src0.C, op.H * op.W, out, op.out_dtype, s);
+        }
+        case BSY_OP_COPY: {
+            const float* src = R.f(op.src0);
+            float* dst = R.f(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_copy32(src, op.src0.ld, op.up0, op.B, op.H, op.W, op.src0.C, dst, op.dst.ld, s);
+        }
+        case BSY_OP_GAP: {
+            const float* src = R.f(op.src0);
+            float* dst = R.f(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_gap32(src, op.src0.ld, op.B, op.H, op.W, op.src0.C, dst, op.dst.ld, s);
+        }
+        case BSY_OP_MSCA_MIX: {
+            Mix32Args a;
+            for (int i = 0; i < 4; ++i) {
+                const bsy_view& bv = i < 3 ? op.box[i] : op.res;
+                const bsy_view& lv = i < 3 ? op.cls[i] : op.msk[0];
+                a.br[i] = R.f(bv); a.ldb[i] = bv.ld; a.lg[i] = R.f(lv); a.ldl[i] = lv.ld;
+            }
+            a.B = op.B; a.HW = op.H * op.W; a.C = op.dst.C; a.dst = R.f(op.dst); a.ldd = op.dst.ld;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_mix32(a, s);
+        }
+        case BSY_OP_MUL: {
+            const float* x = R.f(op.src0);
+            const float* y = R.f(op.src1);
+            float* dst = R.f(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_mul32(x, op.src0.ld, y, op.src1.ld, (long long)op.B * op.H * op.W, op.dst.C, dst, op.dst.ld, s);
+        }
+        case BSY_OP_ELA: {
+            ElaArgs a;
+            memset(&a, 0, sizeof(a));
+            a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C; a.k = op.ksize;
+            const float* blob = (const float*)(wb + op.w_off);
+            a.wsp = blob; a.wch = blob + (size_t)a.C * a.k; a.gnw = a.wch + (size_t)a.C * a.k; a.gnb = a.gnw + a.C;
+            a.ch_coef = op.scale; a.sp_coef = op.lvl_stride[0]; a.res_coef = op.lvl_stride[1];
+            a.scratch = R.f(op.res); a.ldd = op.dst.ld;
+            const float* src = R.f(op.src0);
+            float* dst = R.f(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_ela32(a, src, dst, s);
+        }
+        case BSY_OP_DECODE:
+        case BSY_OP_RAW_NCHW:
+            handled = false;
+            return BSY_OK;
+        default:
+            BSY_FAIL(BSY_ERR_ARG, "fp32 mode: op kind %d has no fp32 implementation (fused kinds are fp16-only)", op.kind);
+    }
+}
+
 int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, ConvArgs* cargs = nullptr) {
     const char* wb = (const char*)p->eng->weights;
+    if (op.prec == 1) {
+        bool handled = false;
+        const int rc = run_op_f32(p, op, R, s, handled);
+        if (rc != BSY_OK || handled) return rc;
+    } else if (op.prec != 0) {
+        BSY_FAIL(BSY_ERR_ARG, "plan_run: unknown precision mode %d", op.prec);
+    }
     switch (op.kind) {
         case BSY_OP_CONV_FIRST: {
             ConvFirstArgs a;
@@ -497,7 +614,7 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
     int rc = BSY_OK;
     for (size_t i = 0; i < p->ops.size() && rc == BSY_OK; ++i) {
         bsy_op& op = p->ops[i];
-        if (op.kind != BSY_OP_CONV || op.tuned_cfg > 0) { rc = run_op(p, op, R, s); continue; }  // preset (bsy_plan_set_tuning): kept
+        if (op.kind != BSY_OP_CONV || op.tuned_cfg > 0 || op.prec != 0) { rc = run_op(p, op, R, s); continue; }  // preset (bsy_plan_set_tuning): kept
         ConvArgs a;
         rc = run_op(p, op, R, s, &a);
         if (rc != BSY_OK) break;

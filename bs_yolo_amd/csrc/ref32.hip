@@ -1,0 +1,340 @@
+// fp32 correctness mode of the engine ("precision = fp32" plans): the same op list as the fp16 product path, executed with
+// fp32 activation storage and fp32 arithmetic by deliberately simple kernels (one thread per output element or small group,
+// sequential fmaf over K).  It exists for callers that hand the engine fp32 images -- the reference's predict() default is
+// half=False (engine/predictor.py:131) -- and expect the fp32 model's numbers: the fp16-storage path differs from the fp32
+// reference by up to 6e-3 in a score, this one by ~1e-5, inside the north-star's 1e-3.  Slow by
+// design (a few TFLOP/s); never on the benchmarked path.  Layout: NHWC f32, views (pointer incl. channel offset, ld).
+// Each kernel restates the reference arithmetic it replaces: Conv.forward_fuse conv.py:149-151, DWConv :224-229,
+// SPPF block.py:3145-3149, Attention :4279-4286, MSCAAttention nn/Addmodules/MSCA.py:53-88, ELA ELA.py:77-101.
+#include "common.h"
+
+namespace {
+__device__ __forceinline__ float silu32(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid32(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- dense conv, k x k, stride 1 / 2, up to two concatenated sources (each optionally read through nearest x2) ----------
+template <bool FIRST>
+__global__ __launch_bounds__(256) void conv32_kernel(const Conv32Args a) {
+    constexpr int PX = 4;  // output pixels per thread: one weight load feeds four FMAs
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int o = (int)(idx % a.Cout);
+    const long long m0 = idx / a.Cout * PX;
+    const long long M = (long long)a.B * a.OH * a.OW;
+    if (m0 >= M) return;
+    const int Cin = a.C0 + a.C1;
+    float acc[PX];
+    int n[PX], oh[PX], ow[PX];
+    bool ok[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const long long m = m0 + j;
+        ok[j] = m < M;
+        const long long mm = ok[j] ? m : m0;
+        n[j] = (int)(mm / (a.OH * a.OW));
+        const int rem = (int)(mm - (long long)n[j] * a.OH * a.OW);
+        oh[j] = rem / a.OW;
+        ow[j] = rem - oh[j] * a.OW;
+        acc[j] = a.bias[o];
+    }
+    for (int kh = 0; kh < a.ks; ++kh)
+        for (int kw = 0; kw < a.ks; ++kw) {
+            const float* wrow = a.w + (size_t)((kh * a.ks + kw) * Cin) * a.Cout + o;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const int iy = oh[j] * a.stride - a.pad + kh, ix = ow[j] * a.stride - a.pad + kw;
+                if (!ok[j] || (unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
+                if (FIRST) {  // BCHW image, f16 or f32
+                    for (int c = 0; c < a.C0; ++c) {
+                        const size_t ii = ((size_t)(n[j] * a.C0 + c) * a.H + iy) * a.W + ix;
+                        const float xv = a.src_dtype == BSY_F16 ? (float)reinterpret_cast<const half_t*>(a.src0)[ii]
+                                                                : reinterpret_cast<const float*>(a.src0)[ii];
+                        acc[j] = fmaf(xv, wrow[(size_t)c * a.Cout], acc[j]);
+                    }
+                } else {
+                    const float* x0 = reinterpret_cast<const float*>(a.src0) +
+                                      ((size_t)(n[j] * (a.H >> a.up0) + (iy >> a.up0)) * (a.W >> a.up0) + (ix >> a.up0)) * a.ld0;
+                    for (int c = 0; c < a.C0; ++c) acc[j] = fmaf(x0[c], wrow[(size_t)c * a.Cout], acc[j]);
+                    if (a.C1) {
+                        const float* x1 = reinterpret_cast<const float*>(a.src1) +
+                                          ((size_t)(n[j] * (a.H >> a.up1) + (iy >> a.up1)) * (a.W >> a.up1) + (ix >> a.up1)) * a.ld1;
+                        const float* w1 = wrow + (size_t)a.C0 * a.Cout;
+                        for (int c = 0; c < a.C1; ++c) acc[j] = fmaf(x1[c], w1[(size_t)c * a.Cout], acc[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        if (!ok[j]) continue;
+        float v = a.act ? silu32(acc[j]) : acc[j];
+        const size_t pix = (size_t)(n[j] * a.OH + oh[j]) * a.OW + ow[j];
+        if (a.res) v += a.res[pix * a.ldr + o];  // shortcut: after the activation (Bottleneck / PSABlock)
+        size_t dp = pix;
+        if (a.dst_scale != 1)
+            dp = ((size_t)n[j] * (a.OH * a.dst_scale) + (oh[j] * a.dst_scale + a.dst_dy)) * (size_t)(a.OW * a.dst_scale) +
+                 (ow[j] * a.dst_scale + a.dst_dx);
+        a.dst[dp * a.ldd + o] = v;
+    }
+}
+
+// ---- depthwise kh x kw, stride 1 / 2, "same" padding; SiLU on channels < act_c; optional residual ----------------------
+__global__ __launch_bounds__(256) void dw32_kernel(const Dw32Args a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.B * a.OH * a.OW * a.C;
+    if (idx >= total) return;
+    const int c = (int)(idx % a.C);
+    long long t = idx / a.C;
+    const int ow = (int)(t % a.OW);
+    t /= a.OW;
+    const int oh = (int)(t % a.OH);
+    const int n = (int)(t / a.OH);
+    float acc = a.b[c];
+    const int ph = a.kh / 2, pw = a.kw / 2;
+    for (int i = 0; i < a.kh; ++i)
+        for (int j = 0; j < a.kw; ++j) {
+            const int iy = oh * a.stride - ph + i, ix = ow * a.stride - pw + j;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                acc = fmaf(a.src[((size_t)(n * a.H + iy) * a.W + ix) * a.lds + c], a.w[(size_t)(i * a.kw + j) * a.wld + c], acc);
+        }
+    float v = c < a.act_c ? silu32(acc) : acc;
+    const size_t pix = (size_t)(n * a.OH + oh) * a.OW + ow;
+    if (a.res) v += a.res[pix * a.ldr + c];
+    a.dst[pix * a.ldd + c] = v;
+}
+
+// ---- SPPF: three chained MaxPool2d(5, 1, 2) of channels [0, C) into [C, 2C), [2C, 3C), [3C, 4C) of the same rows ----------
+__global__ __launch_bounds__(256) void sppf32_kernel(float* buf, int ld, int B, int H, int W, int C) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * H * W * C) return;
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    float m[3] = {-INFINITY, -INFINITY, -INFINITY};  // chained 5x5 pools with -inf padding = windows of 5, 9, 13 clipped to the map
+    for (int dy = -6; dy <= 6; ++dy)
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int iy = y + dy, ix = x + dx;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+            const float v = buf[((size_t)(n * H + iy) * W + ix) * ld + c];
+            const int r = max(abs(dy), abs(dx));
+            if (r <= 2) m[0] = fmaxf(m[0], v);
+            if (r <= 4) m[1] = fmaxf(m[1], v);
+            m[2] = fmaxf(m[2], v);
+        }
+    float* o = buf + ((size_t)(n * H + y) * W + x) * ld + c;
+    o[C] = m[0];
+    o[2 * C] = m[1];
+    o[3 * C] = m[2];
+}
+
+// ---- attention: out[i] = sum_j softmax_j(scale * q_i . k_j) v_j per (image, head); qkv = [q | k | v] by heads ----------------
+#define ATT32_MAXD 128
+__global__ __launch_bounds__(64) void attn32_kernel(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale,
+                                                   float* out, int ldo) {
+    const int i = blockIdx.x * 64 + threadIdx.x, head = blockIdx.y, b = blockIdx.z;
+    if (i >= N) return;
+    const float* base = qkv + (size_t)b * N * ld;
+    const float* q = base + (size_t)i * ld + head * kd;
+    const int koff = heads * kd + head * kd, voff = 2 * heads * kd + head * hd;
+    float acc[ATT32_MAXD];
+    for (int d = 0; d < hd; ++d) acc[d] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const float* kj = base + (size_t)j * ld + koff;
+        float s = 0.f;
+        for (int c = 0; c < kd; ++c) s = fmaf(q[c], kj[c], s);
+        s *= scale;
+        const float nm = fmaxf(mx, s);
+        const float corr = expf(mx - nm), pj = expf(s - nm);
+        den = den * corr + pj;
+        const float* vj = base + (size_t)j * ld + voff;
+        for (int d = 0; d < hd; ++d) acc[d] = acc[d] * corr + pj * vj[d];
+        mx = nm;
+    }
+    float* o = out + ((size_t)b * N + i) * ldo + head * hd;
+    for (int d = 0; d < hd; ++d) o[d] = acc[d] / den;
+}
+
+__global__ __launch_bounds__(256) void nhwc2nchw32_kernel(const float* src, int ld, int B, int C, int HW, void* out, int out_dtype) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * C * HW) return;
+    const int p = (int)(idx % HW);
+    long long t = idx / HW;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    const float v = src[((size_t)n * HW + p) * ld + c];
+    if (out_dtype == BSY_F32) reinterpret_cast<float*>(out)[idx] = v;
+    else reinterpret_cast<half_t*>(out)[idx] = (half_t)v;
+}
+
+__global__ __launch_bounds__(256) void copy32_kernel(const float* src, int lds_, int up, int B, int H, int W, int C, float* dst, int ldd) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * H * W * C) return;
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    dst[((size_t)(n * H + y) * W + x) * ldd + c] = src[((size_t)(n * (H >> up) + (y >> up)) * (W >> up) + (x >> up)) * lds_ + c];
+}
+
+// one workgroup per (image, channel): mean over H*W (MSCAAttention's AdaptiveAvgPool2d(1))
+__global__ __launch_bounds__(256) void gap32_kernel(const float* src, int lds_, int HW, float* out, int ldo) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    float a = 0.f;
+    for (int p = tid; p < HW; p += 256) a += src[((size_t)n * HW + p) * lds_ + c];
+    red[tid] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) out[(size_t)n * ldo + c] = red[0] / (float)HW;
+}
+
+__global__ __launch_bounds__(256) void mix32_kernel(const Mix32Args a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.B * a.HW * a.C) return;
+    const int c = (int)(idx % a.C);
+    const long long pix = idx / a.C;
+    const int n = (int)(pix / a.HW);
+    float w[4], den = 0.f;
+    for (int i = 0; i < 4; ++i) {  // softmax over the four branches of sigmoid(SE logit) (MSCA.py:69-82)
+        w[i] = expf(sigmoid32(a.lg[i][(size_t)n * a.ldl[i] + c]));
+        den += w[i];
+    }
+    float acc = 0.f;
+    for (int i = 0; i < 4; ++i) acc = fmaf(w[i] / den, a.br[i][(size_t)pix * a.ldb[i] + c], acc);
+    a.dst[(size_t)pix * a.ldd + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void mul32_kernel(const float* x, int ldx, const float* y, int ldy, long long npix, int C, float* dst, int ldd) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npix * C) return;
+    const int c = (int)(idx % C);
+    const long long pix = idx / C;
+    dst[(size_t)pix * ldd + c] = x[(size_t)pix * ldx + c] * y[(size_t)pix * ldy + c];
+}
+
+// ELA row / column means into the scratch layout of bsyolo_ops.hip (the gate kernel there is f32 already and is reused)
+__global__ __launch_bounds__(256) void ela_stats32_kernel(const float* src, int lds_, int H, int W, int C, float* scratch, size_t per_img) {
+    const int n = blockIdx.y, dir = blockIdx.z;
+    const int L = dir ? W : H, R = dir ? H : W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)L * C) return;
+    const int c = (int)(idx % C), line = (int)(idx / C);
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const int y = dir ? r : line, x = dir ? line : r;
+        a += src[((size_t)(n * H + y) * W + x) * lds_ + c];
+    }
+    scratch[(size_t)n * per_img + (dir ? (size_t)H * C : 0) + (size_t)line * C + c] = a / (float)R;
+}
+
+__global__ __launch_bounds__(256) void ela_apply32_kernel(const float* src, int lds_, int B, int H, int W, int C, const float* scratch,
+                                                          size_t per_img, float ca, float sb, float rr, float* dst, int ldd) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * H * W * C) return;
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const float* base = scratch + (size_t)n * per_img + (size_t)(H + W + 1) * C;
+    const float hg = base[(size_t)y * C + c], wg = base[(size_t)H * C + (size_t)x * C + c], cg = base[(size_t)(H + W) * C + c];
+    const size_t pix = (size_t)(n * H + y) * W + x;
+    const float xv = src[pix * lds_ + c];
+    dst[pix * ldd + c] = xv * (ca * cg + sb * (hg * wg)) + rr * xv;
+}
+
+inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+}  // namespace
+
+int launch_conv32(const Conv32Args& a, hipStream_t s) {
+    if (!a.src0 || !a.w || !a.bias || !a.dst || a.Cout <= 0 || a.B <= 0) BSY_FAIL(BSY_ERR_ARG, "conv32: bad argument");
+    if (a.C1 && !a.src1) BSY_FAIL(BSY_ERR_ARG, "conv32: src1 missing");
+    const long long M = (long long)a.B * a.OH * a.OW;
+    const long long threads = (M + 3) / 4 * a.Cout;
+    if (threads <= 0 || threads > 0x7fffffffLL * 256) BSY_FAIL(BSY_ERR_ARG, "conv32: extent out of range");
+    if (a.first) hipLaunchKernelGGL(conv32_kernel<true>, dim3(nblk(threads)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv32_kernel<false>, dim3(nblk(threads)), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_dw32(const Dw32Args& a, hipStream_t s) {
+    if (!a.src || !a.w || !a.b || !a.dst || a.kh < 1 || a.kw < 1 || (a.stride != 1 && a.stride != 2)) BSY_FAIL(BSY_ERR_ARG, "dw32: bad argument");
+    hipLaunchKernelGGL(dw32_kernel, dim3(nblk((long long)a.B * a.OH * a.OW * a.C)), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_sppf32(float* buf, int ld, int B, int H, int W, int C, hipStream_t s) {
+    if (!buf || ld < 4 * C) BSY_FAIL(BSY_ERR_ARG, "sppf32: bad argument");
+    hipLaunchKernelGGL(sppf32_kernel, dim3(nblk((long long)B * H * W * C)), dim3(256), 0, s, buf, ld, B, H, W, C);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_attn32(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s) {
+    if (!qkv || !out || hd > ATT32_MAXD || kd < 1 || hd < 1 || heads < 1) BSY_FAIL(BSY_ERR_ARG, "attn32: bad argument (head_dim <= %d)", ATT32_MAXD);
+    hipLaunchKernelGGL(attn32_kernel, dim3((N + 63) / 64, heads, B), dim3(64), 0, s, qkv, ld, B, N, heads, kd, hd, scale, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_nhwc2nchw32(const float* src, int ld, int B, int C, int hw, void* out, int out_dtype, hipStream_t s) {
+    if (!src || !out) BSY_FAIL(BSY_ERR_ARG, "nhwc2nchw32: null pointer");
+    hipLaunchKernelGGL(nhwc2nchw32_kernel, dim3(nblk((long long)B * C * hw)), dim3(256), 0, s, src, ld, B, C, hw, out, out_dtype);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_copy32(const float* src, int lds_, int up, int B, int H, int W, int C, float* dst, int ldd, hipStream_t s) {
+    if (!src || !dst) BSY_FAIL(BSY_ERR_ARG, "copy32: null pointer");
+    hipLaunchKernelGGL(copy32_kernel, dim3(nblk((long long)B * H * W * C)), dim3(256), 0, s, src, lds_, up, B, H, W, C, dst, ldd);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_gap32(const float* src, int lds_, int B, int H, int W, int C, float* out, int ldo, hipStream_t s) {
+    if (!src || !out) BSY_FAIL(BSY_ERR_ARG, "gap32: null pointer");
+    hipLaunchKernelGGL(gap32_kernel, dim3(C, B), dim3(256), 0, s, src, lds_, H * W, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_mix32(const Mix32Args& a, hipStream_t s) {
+    for (int i = 0; i < 4; ++i)
+        if (!a.br[i] || !a.lg[i]) BSY_FAIL(BSY_ERR_ARG, "mix32: branch %d missing", i);
+    hipLaunchKernelGGL(mix32_kernel, dim3(nblk((long long)a.B * a.HW * a.C)), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_mul32(const float* x, int ldx, const float* y, int ldy, long long npix, int C, float* dst, int ldd, hipStream_t s) {
+    if (!x || !y || !dst) BSY_FAIL(BSY_ERR_ARG, "mul32: null pointer");
+    hipLaunchKernelGGL(mul32_kernel, dim3(nblk(npix * C)), dim3(256), 0, s, x, ldx, y, ldy, npix, C, dst, ldd);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+int launch_ela32(const ElaArgs& a, const float* src, float* dst, hipStream_t s) {
+    if (!src || !dst || !a.scratch || !a.wsp || !a.wch || !a.gnw || !a.gnb || (a.C & 15) || a.k < 1 || !(a.k & 1) || a.k > 15)
+        BSY_FAIL(BSY_ERR_ARG, "ela32: bad argument");
+    const size_t per_img = ela_scratch_floats(a.H, a.W, a.C);
+    const int Lmax = a.H > a.W ? a.H : a.W;
+    hipLaunchKernelGGL(ela_stats32_kernel, dim3(nblk((long long)Lmax * a.C), a.B, 2), dim3(256), 0, s, src, a.lds, a.H, a.W, a.C, a.scratch, per_img);
+    HIP_TRY(hipGetLastError());
+    const int rc = launch_ela_gate(a, s);
+    if (rc != BSY_OK) return rc;
+    hipLaunchKernelGGL(ela_apply32_kernel, dim3(nblk((long long)a.B * a.H * a.W * a.C)), dim3(256), 0, s, src, a.lds, a.B, a.H, a.W, a.C,
+                       a.scratch, per_img, a.ch_coef, a.sp_coef, a.res_coef, dst, a.ldd);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}

@@ -59,6 +59,7 @@ class Op(C.Structure):
         ("mid_c", C.c_int32),
         ("w2_off", C.c_int64), ("b2_off", C.c_int64),
         ("aux_off", C.c_int64 * 18),
+        ("prec", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

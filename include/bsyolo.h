@@ -122,6 +122,10 @@ typedef struct bsy_op {
     int32_t mid_c;          /* STEM / BNECK: channels of the fused-away intermediate map */
     int64_t w2_off, b2_off; /* STEM / BNECK: second conv's weights / bias (byte offsets into the weight blob) */
     int64_t aux_off[18];    /* MSCA_SPATIAL: (weights, bias) byte offsets of its nine depthwise convs */
+    int32_t prec;           /* 0: the fp16-storage product path.  1: fp32 correctness mode -- every workspace view is NHWC f32,
+                             * dense conv weights are f32 [k*k*Cin][Cout], arithmetic is fp32 (csrc/ref32.hip); kinds CONV_FIRST,
+                             * CONV, DWCONV, DWCONV_G, SPPF_POOL, ATTN, DECODE, RAW_NCHW, NHWC2NCHW, COPY, GAP, MSCA_MIX, MUL, ELA */
+    int32_t reserved0;
 } bsy_op;
 
 int bsy_engine_create(int device, bsy_engine** out);

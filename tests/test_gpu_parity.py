@@ -1028,8 +1028,12 @@ def test_letterbox_golden_pixels():
 # outputs (fixtures layer0_i, generated by tests/golden/make_fixtures.py from the imported reference) and against the
 # oracle run with the engine's storage precision.  An end-to-end bound cannot localise a bad kernel; this one does.
 # ------------------------------------------------------------------------------------------------------------
-LAYER_TOL_EMU = 2e-3   # vs the fp16-storage oracle, as a share of the layer's range (max |ref|): kernel error only
-LAYER_TOL_REF = 4e-3   # vs the reference's fp32 outputs: adds the fp16 storage error accumulated up to that layer
+# Measured (r02, two boxes, tuned and heuristic kernel configurations): per layer, as shares of the layer's range, max error
+# 0.4-2.9e-3 (stock) / 0.4-2.8e-3 (BS-YOLO), 99.9th percentile <= 1.8e-3, mean <= 1.8e-4 -- against BOTH references: one f16
+# ulp of a value near the top of the range is 1e-3 of it, and the emulation does not share the kernels' summation order, so
+# "vs emulation" is tighter than "vs fp32 reference" only in the early layers and in the mean.  A kernel bug shows as a layer
+# whose error jumps by an order of magnitude against its predecessor; bounds (max, p99.9, mean) sit ~1.5x above the measurements.
+LAYER_TOL = {"yolo11n_detect": (4e-3, 2.5e-3, 2.5e-4), "bsyolo11n_detect": (5e-3, 3e-3, 3e-4)}
 
 
 @pytest.mark.parametrize("tag", ["yolo11n_detect", "bsyolo11n_detect"])
@@ -1061,13 +1065,17 @@ def test_engine_every_layer_matches_reference(tag, fused, monkeypatch):
         ref, q = z[f"layer0_{i}"], emu[i].numpy()
         assert got.shape == ref.shape == q.shape, (i, got.shape, ref.shape)
         scale = np.abs(ref).max()
-        rows.append((i, np.abs(got - q).max() / scale, np.abs(got - ref).max() / scale))
+        eq, er = np.abs(got - q).ravel() / scale, np.abs(got - ref).ravel() / scale
+        rows.append((i, eq.max(), np.quantile(eq, 0.999), eq.mean(), er.max(), np.quantile(er, 0.999), er.mean()))
         checked += 1
     eng.close()
     assert checked >= len(plan.layer_out) - 3
-    bad = [r for r in rows if r[1] > LAYER_TOL_EMU or r[2] > LAYER_TOL_REF]
-    assert not bad, "layer, err vs fp16-emulating oracle, err vs reference (shares of the layer's range): " + \
-        ", ".join(f"{i}: {a:.2e} / {b:.2e}" for i, a, b in rows)
+    tmax, tq, tmean = LAYER_TOL[tag]
+    bad = [r for r in rows if r[1] > tmax or r[4] > tmax or r[2] > tq or r[5] > tq or r[3] > tmean or r[6] > tmean]
+    assert not bad, "layer: max / p99.9 / mean error vs fp16-emulating oracle | vs reference (shares of the layer's range): " + \
+        "; ".join(f"{r[0]}: {r[1]:.1e} {r[2]:.1e} {r[3]:.1e} | {r[4]:.1e} {r[5]:.1e} {r[6]:.1e}" for r in rows)
+    print("per-layer worst: max %.2e p99.9 %.2e mean %.2e (vs emulation), max %.2e p99.9 %.2e mean %.2e (vs reference)" %
+          tuple(max(r[k] for r in rows) for k in range(1, 7)))
 
 
 def test_engine_memory_and_tuning_stay_bounded_over_rect_shapes():
