@@ -26,10 +26,13 @@ class YoloEngine:
                  autotune: Optional[bool] = None, fuse_stem: Optional[bool] = None,
                  fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None, fuse_dwpw: Optional[bool] = None,
                  merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None, fuse_tail: Optional[bool] = None,
-                 max_plans: Optional[int] = None):
+                 max_plans: Optional[int] = None, precision: str = "fp16"):
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
+        # "fp32": the correctness mode -- fp32 activation storage and arithmetic (csrc/ref32.hip), for callers that expect the
+        # fp32 model's numbers (|dscore| <= 1e-3 against the fp32 reference).  Slow by design; "fp16" is the product path.
+        self.precision = precision
         self.device = torch.device("cuda", device)
         self._h = C.c_void_p()
         L.check(L.lib.bsy_engine_create(device, C.byref(self._h)))
@@ -59,7 +62,7 @@ class YoloEngine:
         # liveness-based buffer reuse (Plan.assign_offsets).  Off under BSY_ARENA_REUSE=0 (tests that read intermediate
         # layers back) and under BSY_PLAN_GUARD (guard bands behind every buffer: the plan then owns a private workspace)
         self.reuse = os.environ.get("BSY_ARENA_REUSE", "1") != "0" and not os.environ.get("BSY_PLAN_GUARD")
-        self.autotune = (os.environ.get("BSY_AUTOTUNE", "1") != "0") if autotune is None else bool(autotune)
+        self.autotune = ((os.environ.get("BSY_AUTOTUNE", "1") != "0") if autotune is None else bool(autotune)) and precision == "fp16"
         # pack once with a throw-away plan (op list structure does not depend on the input size)
         self.fuse_stem = fuse_stem  # None: BSY_FUSE_STEM env (default on); False keeps layers 0 and 1 as two launches
         self.fuse_bneck = fuse_bneck
@@ -80,7 +83,7 @@ class YoloEngine:
 
     def _fuse_kw(self):
         return dict(fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head, fuse_dwpw=self.fuse_dwpw,
-                    merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail)
+                    merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail, precision=self.precision)
 
     # -- plans --------------------------------------------------------------------------------------------------
     def plan_for(self, B: int, H: int, W: int, in_dtype: torch.dtype, out_dtype: torch.dtype):

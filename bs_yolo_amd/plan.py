@@ -96,8 +96,14 @@ class Plan:
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
                  fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None,
-                 fuse_tail: Optional[bool] = None):
+                 fuse_tail: Optional[bool] = None, precision: str = "fp16"):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
+        if precision not in ("fp16", "fp32"):
+            raise ValueError(f"precision must be 'fp16' or 'fp32', not {precision!r}")
+        # fp32: the correctness mode (csrc/ref32.hip) -- every buffer f32, no fused kernels, same op list otherwise
+        self.f32_mode = precision == "fp32"
+        if self.f32_mode:
+            fuse_stem = fuse_bneck = fuse_head = fuse_dwpw = merge_c3k = fuse_msca = fuse_tail = False
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
@@ -121,6 +127,9 @@ class Plan:
 
     # ---- buffers -------------------------------------------------------------------------------------------
     def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
+        if self.f32_mode:
+            self.buf_bytes.append(self.B * H * W * make_divisible(C, 8) * 4)
+            return T(len(self.buf_bytes) - 1, make_divisible(C, 8), 0, C, H, W, False, True)
         ld = make_divisible(C, 4) if f32 else make_divisible(C, 8)
         self.buf_bytes.append(self.B * H * W * ld * (4 if f32 else 2))
         return T(len(self.buf_bytes) - 1, ld, 0, C, H, W, False, f32)
@@ -139,13 +148,13 @@ class Plan:
         srcs = [src] if isinstance(src, T) else list(src)
         assert 1 <= len(srcs) <= 2, "at most two concat operands per conv"
         H, W = srcs[0].H, srcs[0].W
-        assert all(t.H == H and t.W == W and not t.f32 for t in srcs)
+        assert all(t.H == H and t.W == W and (t.f32 == self.f32_mode) for t in srcs)
         cin = sum(t.C for t in srcs)
         p = k // 2
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         if dst is None:
             dst = self.alloc(cout, OH, OW, out_f32)
-        assert dst.C == cout and dst.H == OH and dst.W == OW and dst.f32 == out_f32 and not dst.up
+        assert dst.C == cout and dst.H == OH and dst.W == OW and dst.f32 == (out_f32 or self.f32_mode) and not dst.up
         if res is not None:
             assert res.C == cout and res.H == OH and res.W == OW and not res.up
         if name2 is not None:
@@ -186,7 +195,7 @@ class Plan:
                  post: Optional[str] = None) -> T:
         """Depthwise kh x kw conv with "same" padding (csrc/bsyolo_ops.hip); SiLU on the first act_c channels.
         kind: "dwg" (Conv + BN), "dwg_plain" (bare nn.Conv2d with bias), "dwg_ext" (PMSFA.conv3, see pmsfa())."""
-        assert not src.up and not src.f32
+        assert not src.up and src.f32 == self.f32_mode
         OH, OW = (src.H + 2 * (kh // 2) - kh) // s + 1, (src.W + 2 * (kw // 2) - kw) // s + 1
         if dst is None:
             dst = self.alloc(src.C, OH, OW)
@@ -405,7 +414,7 @@ class Plan:
                 if key not in self.wrecs:
                     self.wrecs[key] = WRec(name=name + ".upsample", kind="deconv", cout=c_, cin=c_, k=1, tap=(dy, dx))
                 self.ops.append(dict(kind=L.OP_CONV, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=t, src1=None,
-                                     dst=T(up.buf, up.ld, 0, c_, x.H, x.W), res=None, ksize=1, stride=1, pad=0, act=0,
+                                     dst=T(up.buf, up.ld, 0, c_, x.H, x.W, False, up.f32), res=None, ksize=1, stride=1, pad=0, act=0,
                                      out_f32=0, wkey=key, dst_scale=2, dst_dy=dy, dst_dx=dx, name=key,
                                      mfma_flops=2 * self.B * x.H * x.W * c_ * c_))
                 self.flops += 2 * self.B * x.H * x.W * c_ * c_
@@ -552,7 +561,7 @@ class Plan:
                 cout = x.C
             elif m == "nn.Upsample":
                 assert isinstance(x, T) and not x.up and args[1] == 2 and args[2] == "nearest"
-                y = T(x.buf, x.ld, x.coff, x.C, x.H * 2, x.W * 2, True)
+                y = T(x.buf, x.ld, x.coff, x.C, x.H * 2, x.W * 2, True, x.f32)
                 cout = x.C
             elif m == "Concat":
                 assert isinstance(x, list) and len(x) == 2, "only two-operand Concat feeding a conv is accelerated"
@@ -696,7 +705,7 @@ class Plan:
     def conv_signature(self, o: dict) -> Optional[tuple]:
         """What decides which kernel configuration is fastest for a conv op (and which are valid): the key of the engine's
         autotune cache.  None for ops the autotuner does not touch."""
-        if o["kind"] != L.OP_CONV:
+        if o["kind"] != L.OP_CONV or self.f32_mode:
             return None
         s0, s1, d, r = o["src0"], o.get("src1"), o["dst"], o.get("res")
         return (self.B, o["H"], o["W"], s0.C, s0.ld, int(s0.up), s1.C if s1 else 0, s1.ld if s1 else 0, int(s1.up) if s1 else 0,
@@ -746,4 +755,5 @@ class Plan:
                 o.lvl_stride[j] = d["lvl_stride"][j] if j < len(d.get("lvl_stride", [])) else 0.0
             o.in_dtype, o.out_dtype, o.level = d.get("in_dtype", 0), d.get("out_dtype", 0), d.get("level", 0)
             o.lane, o.join, o.tuned_cfg = d.get("lane", 0), d.get("join", 0), 0
+            o.prec = 1 if self.f32_mode else 0
         return arr

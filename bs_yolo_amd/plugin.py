@@ -64,32 +64,40 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
     """Install the engine behind ``model.forward``.  Returns the same model object.
 
     fp32_inputs: what an fp32 image tensor gets (the reference's ``predict()`` default is ``half=False``,
-    engine/predictor.py:131).  The engine stores activations in fp16, which is NOT the fp32 model's arithmetic (DESIGN.md
-    section 4: max |dscore| up to 6e-3 against the fp32 reference, vs the north-star's 1e-3), so the default
-    ``"reference"`` sends fp32 inputs to the original forward; ``"engine"`` opts in to the fp16-storage engine for them
-    (outputs still come back as fp32).  ``BSY_FP32_INPUTS`` overrides the default.  fp16 inputs (``half=True`` /
-    ``model.half()``) always run on the engine: there the reference itself computes in fp16."""
+    engine/predictor.py:131).  The product path stores activations in fp16, which is NOT the fp32 model's arithmetic
+    (max |dscore| up to 6e-3 against the fp32 reference, vs the north-star's 1e-3), so it is never
+    applied to fp32 callers silently:
+      ``"engine_fp32"`` (default)  the engine's fp32 correctness mode: fp32 storage and arithmetic on the GPU
+                                   (csrc/ref32.hip; |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz against the fp32 reference;
+                                   simple kernels, a few TFLOP/s);
+      ``"engine"``                 opt in to the fast fp16-storage path for fp32 inputs (outputs come back as fp32);
+      ``"reference"``              leave fp32 inputs to the original forward.
+    ``BSY_FP32_INPUTS`` overrides the default.  fp16 inputs (``half=True`` / ``model.half()``) always run on the fp16
+    engine: there the reference itself computes in fp16."""
     import os
     cfg = cfg_of(model)
     orig_forward = model.forward
-    state = {"engine": None, "key": None, "fallbacks": 0, "engine_calls": 0, "rebuilds": 0}
-    fp32_mode = fp32_inputs or os.environ.get("BSY_FP32_INPUTS", "reference")
-    if fp32_mode not in ("reference", "engine"):
-        raise ValueError(f"fp32_inputs must be 'reference' or 'engine', not {fp32_mode!r}")
+    state = {"engine": None, "engine32": None, "key": None, "fallbacks": 0, "engine_calls": 0, "fp32_calls": 0, "rebuilds": 0}
+    fp32_mode = fp32_inputs or os.environ.get("BSY_FP32_INPUTS", "engine_fp32")
+    if fp32_mode not in ("reference", "engine", "engine_fp32"):
+        raise ValueError(f"fp32_inputs must be 'engine_fp32', 'engine' or 'reference', not {fp32_mode!r}")
 
-    def _engine_for(dev: torch.device) -> YoloEngine:
+    def _engine_for(dev: torch.device, precision: str = "fp16") -> YoloEngine:
         key = (dev.index or 0, _weights_version(model))
-        if state["engine"] is None or state["key"] != key:
-            if state["engine"] is not None:
-                state["engine"].close()
-                state["engine"] = None
+        if state["key"] != key:
+            for k in ("engine", "engine32"):
+                if state[k] is not None:
+                    state[k].close()
+                    state[k] = None
+            state["key"] = key
+        slot = "engine32" if precision == "fp32" else "engine"
+        if state[slot] is None:
             # weights are read at this moment: after AutoBackend has called fuse()/half() (autobackend.py:139-145); the key
             # makes a later in-place update (EMA, load_state_dict, a training step) or a .half()/.to() rebuild the engine
             sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-            state["engine"] = YoloEngine(cfg, sd, device=dev.index or 0, bn_eps=model_bn_eps(model))
-            state["key"] = key
+            state[slot] = YoloEngine(cfg, sd, device=dev.index or 0, bn_eps=model_bn_eps(model), precision=precision)
             state["rebuilds"] += 1
-        return state["engine"]
+        return state[slot]
 
     def forward(self, x, *args, **kwargs):
         augment = kwargs.get("augment", False)
@@ -98,18 +106,19 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
         profile = kwargs.get("profile", False)
         if (self.training or augment or visualize or embed or profile or args or not isinstance(x, torch.Tensor)
                 or not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float16, torch.float32)
-                or (x.dtype == torch.float32 and fp32_mode != "engine")
+                or (x.dtype == torch.float32 and fp32_mode == "reference")
                 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32 or x.shape[0] == 0):
             state["fallbacks"] += 1
             return orig_forward(x, *args, **kwargs)
+        want32 = x.dtype == torch.float32 and fp32_mode == "engine_fp32"
         try:
-            y, raws = _engine_for(x.device)(x)
+            y, raws = _engine_for(x.device, "fp32" if want32 else "fp16")(x)
         except (_L.BsyError, NotImplementedError, AssertionError) as e:  # a shape / graph the engine rejects: the reference runs it
             if verbose:
                 print(f"bs_yolo_amd: falling back to the reference forward ({e})")
             state["fallbacks"] += 1
             return orig_forward(x, *args, **kwargs)
-        state["engine_calls"] += 1
+        state["fp32_calls" if want32 else "engine_calls"] += 1
         return y, raws
 
     model.forward = types.MethodType(forward, model)
@@ -122,8 +131,9 @@ def restore(model):
     if hasattr(model, "_bsy_orig_forward"):
         model.forward = model._bsy_orig_forward
         st = model._bsy_state
-        if st["engine"] is not None:
-            st["engine"].close()
+        for k in ("engine", "engine32"):
+            if st.get(k) is not None:
+                st[k].close()
         del model._bsy_orig_forward, model._bsy_state
     return model
 

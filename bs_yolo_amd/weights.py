@@ -44,8 +44,10 @@ def _align(n: int, a: int = 256) -> int:
     return (n + a - 1) // a * a
 
 
-def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
-    """-> (weight bytes, bias bytes) for one op."""
+def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f32: bool = False):
+    """-> (weight bytes, bias bytes) for one op.  f32: the fp32 correctness mode's layout for dense convs -- f32
+    [k*k*cin][cout] (K order (kh, kw, cin) as in the fp16 layout, cout fastest), bias f32 [cout], no padding
+    (csrc/ref32.hip); depthwise / ELA records are f32 in both modes."""
     if r.kind == "ela":
         # ELA (nn/Addmodules/ELA.py:36-72): [spatial_conv (C,k)][ch_att.2 (C,k)][gn.weight][gn.bias]; the three scalar mixing
         # weights enter the op record as their sigmoids
@@ -73,6 +75,9 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
         if r.perm is not None:
             idx = torch.as_tensor(r.perm, dtype=torch.long)
             w, b = w[idx], b[idx]
+        if f32:
+            return (w.permute(2, 3, 1, 0).reshape(k * k * cin, cout).contiguous().numpy().tobytes(),
+                    b.contiguous().numpy().tobytes())
         if r.kind == "first":  # image conv: zero 4th input channel, k = (kh, kw, c4)  (csrc/image_conv.h)
             w = torch.cat([w, torch.zeros(cout, 4 - cin, k, k)], 1)
             cin = 4
@@ -108,10 +113,10 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS):
 
 
 def pack_plan_weights(plan: Plan, sd: Mapping[str, torch.Tensor], eps: float = BN_EPS) -> bytes:
-    """Packs every record of `plan` (sets w_off / b_off on the records) -> host blob."""
+    """Packs every record of `plan` (sets w_off / b_off on the records) -> host blob (fp32 layouts for an fp32-mode plan)."""
     chunks, off = [], 0
     for r in plan.wrecs.values():
-        wb, bb = pack_record(sd, r, eps)
+        wb, bb = pack_record(sd, r, eps, f32=getattr(plan, "f32_mode", False))
         r.w_off = off
         chunks.append(wb)
         pad = _align(len(wb)) - len(wb)

@@ -94,11 +94,38 @@ def test_accelerate_falls_back_where_the_engine_does_not_apply():
         n += 1
         assert m.calls == n, kw
     m(_x().half()); n += 1                      # CPU tensor
-    m(_x().to(DEV)); n += 1                     # fp32 caller, default policy: the reference's fp32 arithmetic
     m.train(); m(xh); n += 1; m.eval()          # training mode (head.py:71-72)
     assert m.calls == n and m._bsy_state["engine_calls"] == 0 and m._bsy_state["fallbacks"] == n
     m(xh)
     assert m.calls == n and m._bsy_state["engine_calls"] == 1
+    plugin.restore(m)
+
+
+def test_accelerate_never_downcasts_fp32_callers_silently():
+    """predict()'s default is half=False (engine/predictor.py:131).  fp32 images get the fp32 correctness mode by default
+    (the fp32 model's numbers: |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz against the reference forward), the fp16-storage
+    engine only on request, and the reference forward under fp32_inputs="reference"."""
+    x = _x(seed=7).to(DEV)
+    ref = StandIn().to(DEV)
+    y_ref, raws_ref = ref(x)
+    m = plugin.accelerate(StandIn().to(DEV))
+    y, raws = m(x)
+    assert m.calls == 0 and m._bsy_state["fp32_calls"] == 1 and m._bsy_state["engine_calls"] == 0 and y.dtype == torch.float32
+    assert float((y[:, 4:] - y_ref[:, 4:]).abs().max()) <= 1e-3
+    assert float((y[:, :4] - y_ref[:, :4]).abs().max()) <= 1e-3 * 96
+    for a, b in zip(raws, raws_ref):
+        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
+    m(x.half())                                 # an fp16 caller of the same model: the fp16 engine
+    assert m._bsy_state["engine_calls"] == 1
+    plugin.restore(m)
+    m = plugin.accelerate(StandIn().to(DEV), fp32_inputs="engine")
+    y16, _ = m(x)
+    assert m._bsy_state["engine_calls"] == 1 and m._bsy_state["fp32_calls"] == 0 and y16.dtype == torch.float32
+    assert float((y16[:, 4:] - y_ref[:, 4:]).abs().max()) < 1e-2  # fp16 storage: the documented, looser bound
+    plugin.restore(m)
+    m = plugin.accelerate(StandIn().to(DEV), fp32_inputs="reference")
+    m(x)
+    assert m.calls == 1 and m._bsy_state["fallbacks"] == 1
     plugin.restore(m)
 
 

@@ -1130,3 +1130,76 @@ def test_engine_splits_batches_by_the_largest_view():
     widest = max((t.H * t.W * t.ld) for o in p1.ops for t in [o.get("dst")] if t is not None and t.buf < 0x100000)
     assert per_img >= widest
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fp32 correctness mode (csrc/ref32.hip): the north-star's tolerance, asserted as stated -- |dscore| <= 1e-3 and
+# |dbox| <= 1e-3 * imgsz against the REFERENCE's own fp32 outputs, on all seven golden graphs and every golden input.
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
+                                 "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect"])
+def test_engine_fp32_mode_meets_the_north_star_tolerance(tag):
+    z = np.load(GOLDEN / f"graph_{tag}.npz")
+    meta = json.loads(str(z["meta"]))
+    m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
+    P = R.synth_params(m, meta["seed"])
+    eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), P, precision="fp32")
+    nc, si = meta["nc"], 0
+    while f"x{si}" in z:
+        x = torch.from_numpy(z[f"x{si}"])
+        y, aux = eng(x.to(DEV))
+        torch.cuda.synchronize()
+        y, yref = y.cpu().numpy(), z[f"y{si}"]
+        imgsz = max(x.shape[2], x.shape[3])
+        es, eb = np.abs(y[:, 4:4 + nc] - yref[:, 4:4 + nc]).max(), np.abs(y[:, :4] - yref[:, :4]).max()
+        assert es <= 1e-3, (tag, si, "score", es)
+        assert eb <= 1e-3 * imgsz, (tag, si, "box", eb, imgsz)
+        raws = aux[0] if meta["task"] == "segment" else aux
+        for l, r in enumerate(raws):
+            rr = z[f"raw{si}_{l}"]
+            assert np.abs(r.cpu().numpy() - rr).max() <= 1e-3 * max(1.0, np.abs(rr).max()), (tag, si, "raw", l)
+        if meta["task"] == "segment":
+            mc, proto = aux[1], aux[2]
+            em = np.abs(y[:, 4 + nc:] - yref[:, 4 + nc:]).max()
+            assert em <= 1e-3 * max(1.0, np.abs(yref[:, 4 + nc:]).max()), (tag, si, "mask coefficients", em)
+            pr = z[f"proto{si}"]
+            assert np.abs(proto.cpu().numpy() - pr).max() <= 1e-3 * max(1.0, np.abs(pr).max()), (tag, si, "proto")
+        si += 1
+    assert si >= 1
+    # per-layer, where the fixtures hold the reference's layer outputs: fp32 storage tracks them to 1e-4 of the range
+    if "layer0_0" in z:
+        x = torch.from_numpy(z["x0"])
+        plan, h = eng.plan_for(x.shape[0], x.shape[2], x.shape[3], torch.float32, torch.float32)
+        if not eng.reuse:
+            for i, t in enumerate(plan.layer_out):
+                if t is None:
+                    continue
+                got = (torch.cat([eng.read_view(plan, h, v) for v in t], 1) if isinstance(t, list) else eng.read_view(plan, h, t)).numpy()
+                ref = z[f"layer0_{i}"]
+                assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (tag, "layer", i)
+    eng.close()
+
+
+def test_engine_fp32_mode_layers_match_reference(monkeypatch):
+    """The same per layer (buffers kept alive: BSY_ARENA_REUSE=0): every top-level layer of the fp32 mode against the
+    reference's own layer outputs, 1e-4 of the layer's range."""
+    monkeypatch.setenv("BSY_ARENA_REUSE", "0")
+    for tag in ("yolo11n_detect", "bsyolo11n_detect"):
+        z = np.load(GOLDEN / f"graph_{tag}.npz")
+        meta = json.loads(str(z["meta"]))
+        m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
+        eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), R.synth_params(m, meta["seed"]), precision="fp32")
+        x = torch.from_numpy(z["x0"])
+        eng(x.to(DEV))
+        torch.cuda.synchronize()
+        plan, h = eng.plan_for(x.shape[0], x.shape[2], x.shape[3], torch.float32, torch.float32)
+        n = 0
+        for i, t in enumerate(plan.layer_out):
+            if t is None:
+                continue
+            got = (torch.cat([eng.read_view(plan, h, v) for v in t], 1) if isinstance(t, list) else eng.read_view(plan, h, t)).numpy()
+            ref = z[f"layer0_{i}"]
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (tag, i, np.abs(got - ref).max(), np.abs(ref).max())
+            n += 1
+        assert n >= 22
+        eng.close()
