@@ -424,14 +424,22 @@ def test_engine_matches_reference_golden(tag, dtype):
     # fp16-storage emulation of the oracle already differs from the fp32 reference by 1.31 px max / 0.074 px mean on boxes
     # and 1.5e-4 mean on scores (stock graphs: 0.41 px / 0.02 px / 2.5e-5), so its bounds are 3x wider.  Per-layer outputs
     # agree with the reference to ~1e-3 of each layer's range in both families (tools/gpu_explore.py layers).
+    # Bounds = stated statistics (max, 99.9th percentile, mean), set ~2x above the measurements of tools/parity_stats.py
+    # (r02: stock graphs score max 4.6e-3 / p99.9 2.6e-3 / mean 2.4e-5, box max 0.72 px / mean 0.03 px; BS-YOLO score max
+    # 5.5e-3 / mean 1.6e-4, box max 2.0 px / mean 0.07 px) -- NOT the north-star's 1e-3: fp16 storage cannot meet that on
+    # these random weights (the CPU emulation of fp16 storage shows the same gap), the fp32 mode does and is tested for it
+    # (test_engine_fp32_mode_meets_the_north_star_tolerance).
     k = 3.0 if tag.startswith("bsyolo") else 1.0
+
+    def q(e):
+        return float(np.quantile(e, 0.999))
     for y, yref, yq, raws, rawref, nc in _engine_vs_oracle(tag, dtype):
         es, eb = np.abs(y[:, 4:4 + nc] - yref[:, 4:4 + nc]), np.abs(y[:, :4] - yref[:, :4])
-        assert es.max() < k * 1e-2 and es.mean() < k * 1e-4, (es.max(), es.mean())
-        assert eb.max() < k * 1.0 and eb.mean() < k * 0.05, (eb.max(), eb.mean())
+        assert es.max() < k * 1e-2 and q(es) < k * 5e-3 and es.mean() < k * 1e-4, (es.max(), q(es), es.mean())
+        assert eb.max() < k * 1.0 and q(eb) < k * 0.8 and eb.mean() < k * 0.05, (eb.max(), q(eb), eb.mean())
         qs, qb = np.abs(y[:, 4:4 + nc] - yq[:, 4:4 + nc]), np.abs(y[:, :4] - yq[:, :4])
-        assert qs.max() < k * 1e-2 and qs.mean() < k * 5e-5, (qs.max(), qs.mean())
-        assert qb.max() < k * 1.0 and qb.mean() < k * 0.03, (qb.max(), qb.mean())
+        assert qs.max() < k * 1e-2 and q(qs) < k * 5e-3 and qs.mean() < k * 5e-5, (qs.max(), q(qs), qs.mean())
+        assert qb.max() < k * 1.0 and q(qb) < k * 0.8 and qb.mean() < k * 0.03, (qb.max(), q(qb), qb.mean())
         if y.shape[1] > 4 + nc:  # mask coefficients (raw conv outputs, O(1..10) magnitude)
             em = np.abs(y[:, 4 + nc:] - yref[:, 4 + nc:])
             assert em.max() < 2e-2 * np.abs(yref[:, 4 + nc:]).max(), em.max()
@@ -1203,3 +1211,30 @@ def test_engine_fp32_mode_layers_match_reference(monkeypatch):
             n += 1
         assert n >= 22
         eng.close()
+
+
+def test_engine_fp16_path_vs_fp32_mode_at_the_benchmark_size():
+    """The benchmark configuration itself (YOLO11s, 64 x 640 x 640, bench weights, fp16 in): the fp16-storage product path
+    against the engine's fp32 correctness mode on the same device -- the full-size parity statement.  Measured (r02): score
+    max 2.7e-3 / p99.9 4.1e-4 / mean 2.2e-5; box max 7.3 px / p99.9 2.0 px / mean 0.11 px (a DFL expectation over a flat
+    16-bin distribution at stride 32 moves 6 px for a 0.2-bin shift: random weights); 0.5 % of the anchors change side of
+    conf 0.25.  Bounds ~2x above."""
+    from bs_yolo_amd.plan import Plan
+    from bs_yolo_amd.weights import synth_state_dict
+    cfg = stock_cfg("yolo11", "s")
+    sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
+    x = torch.rand(64, 3, 640, 640, generator=torch.Generator().manual_seed(1234)).half().to(DEV)
+    e16, e32 = YoloEngine(cfg, sd), YoloEngine(cfg, sd, precision="fp32")
+    y16 = e16(x, want_raw=False)[0].float()
+    y32 = e32(x.float(), want_raw=False)[0]
+    torch.cuda.synchronize()
+    assert tuple(y16.shape) == tuple(y32.shape) == (64, 84, 8400)
+    ds, db = (y16[:, 4:] - y32[:, 4:]).abs(), (y16[:, :4] - y32[:, :4]).abs()
+    qs = float(torch.quantile(ds.flatten()[::7].float(), 0.999))  # every 7th element: torch.quantile caps the input size
+    qb = float(torch.quantile(db.flatten().float(), 0.999))
+    assert float(ds.max()) < 6e-3 and qs < 1e-3 and float(ds.mean()) < 5e-5, (float(ds.max()), qs, float(ds.mean()))
+    assert float(db.max()) < 16.0 and qb < 4.0 and float(db.mean()) < 0.25, (float(db.max()), qb, float(db.mean()))
+    n16, n32 = int((y16[:, 4:].amax(1) > 0.25).sum()), int((y32[:, 4:].amax(1) > 0.25).sum())
+    assert abs(n16 - n32) <= 0.02 * n32 and n32 > 5000, (n16, n32)
+    e16.close()
+    e32.close()
