@@ -26,6 +26,7 @@ SOURCES = {
     "conv_first.hip": [],
     "stem_fused.hip": [],
     "bneck_fused.hip": [],
+    "c3k2_fused.hip": [],
     "bsyolo_ops.hip": [],
     "elementwise.hip": [],
     "attention.hip": [],

@@ -1,0 +1,323 @@
+// Fused C3k2 block (block.py:3796-3804 with c3k = False, n = 1; C2f.forward :3308-3312; Bottleneck :3405-3419):
+//     y0, y1 = cv1(x).chunk(2);  y2 = y1 + m.cv2(m.cv1(y1));  out = cv2(cat(y0, y1, y2))
+// -- four Conv+BN+SiLU layers and a shortcut, 1x1 / 3x3 / 3x3 / 1x1 -- as ONE launch for the thin block at 1/4 resolution
+// (YOLO11s model.2: x 64 ch -> c = 32, hidden 16 -> out 128 ch at 160 x 160; YOLO11n model.4 has the same widths).
+//
+// Unfused (round 1: cv1 conv + fused Bottleneck + cv2 conv) this block moved 1.36 GB through HBM per batch of 64 for
+// 0.21 GB in and 0.42 GB out and took 0.33 ms of a 3.3 ms forward: the [y0 | y1 | y2] concat buffer is written by three
+// launches and read back by two.  Here a workgroup (8 waves, persistent) owns an 8 x 16 output tile:
+//   * the 12 x 20 input patch (halo 2 for the two 3x3 convs; zeros outside the image) is fetched into registers one tile
+//     ahead and parked in LDS (padded entries: every MFMA B fragment is one ds_read_b128 at a compile-time offset from a
+//     per-lane base, conflict-free);
+//   * S1  cv1 on all 240 patch pixels -> y1 patch (zeros outside the MAP: the bottleneck's zero padding applies to y1, not
+//         to x) and the interior y0 tile, both in LDS;
+//   * S2  m.cv1 3x3 on the 10 x 18 hidden patch (zeros outside the map), S3  m.cv2 3x3 + shortcut -> y2 tile: the
+//         arithmetic of bneck_fused.hip;
+//   * S4  cv2 over K = [y0 | y1 | y2] straight from the three LDS tiles -> output tile in LDS -> coalesced 16-byte stores.
+// All weights stay on chip for the whole launch (LDS; m.cv1's as MFMA A fragments in registers).  K orders (channels
+// ascending for the 1x1 convs, tap-major for the 3x3 convs) and the epilogue arithmetic (f16(SiLU), shortcut added in f32)
+// equal conv_mfma.hip's / bneck_fused.hip's, so the block returns bit for bit what the three-launch path returns.
+#include "common.h"
+
+#define CK_TH 8
+#define CK_TW 16
+#define CK_XR (CK_TH + 4)
+#define CK_XC (CK_TW + 4)
+#define CK_NX (CK_XR * CK_XC)  // 240 patch pixels (x and y1)
+#define CK_MR (CK_TH + 2)
+#define CK_MC (CK_TW + 2)
+#define CK_NM (CK_MR * CK_MC)  // 180 hidden pixels
+#define CK_NPX (CK_TH * CK_TW)  // 128 output pixels
+
+struct C3k2K {
+    const half_t* src;
+    half_t* dst;
+    const half_t *w1, *wa, *wb, *w4;  // packed [CoutPad][Kpad] (cv1, m.cv1, m.cv2, cv2)
+    const float *b1, *ba, *bb, *b4;
+    int B, H, W, lds, ldd, K1, Ka, Kb, K4, tiles_x, tiles_y, ntiles;
+    unsigned magic_x, magic_y;
+};
+
+template <int CIN, int C, int C2>
+__global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
+    constexpr int CH = C / 2;
+    constexpr int XS = CIN + 8, YS = C + 8, MS = CH + 8, OS = C2 + 8;          // padded LDS entries (halves)
+    constexpr int W1S = CIN + 8, WBS = 9 * CH + 8, W4S = 3 * C + 8;            // padded weight rows (halves)
+    constexpr int KS1 = CIN / 16, KSA = 9 * C / 16, KSB = 9 * CH / 16, KSEG = C / 16;  // MFMA K-steps
+    constexpr int XCH = CIN / 8, NITEM = CK_NX * XCH, NLOAD = (NITEM + 511) / 512;
+    static_assert(C == 32 && CH == 16 && CIN % 16 == 0 && C2 % 64 == 0 && C2 <= 128, "instantiated for the c = 32 C3k2 block");
+    constexpr int SX = 256 * XS > CK_NPX * OS ? 256 * XS : CK_NPX * OS;        // x patch (8 MFMA pixel tiles), later the output tile
+    constexpr int SY1 = CK_NX * YS, SY0 = CK_NPX * YS, SM = CK_NM * MS, SY2 = CK_NPX * YS;
+    constexpr int SW1 = 2 * C * W1S, SWB = C * WBS, SW4 = C2 * W4S;
+    __shared__ __attribute__((aligned(16))) half_t lds[SX + SY1 + SY0 + SM + SY2 + SW1 + SWB + SW4 + 2 * (2 * C + CH + C + C2)];
+    half_t* sx = lds;
+    half_t* sout = lds;  // aliases sx: x is dead after S1, the output tile is written in S4
+    half_t* sy1 = sx + SX;
+    half_t* sy0 = sy1 + SY1;
+    half_t* smid = sy0 + SY0;
+    half_t* sy2 = smid + SM;
+    half_t* sw1 = sy2 + SY2;
+    half_t* swb = sw1 + SW1;
+    half_t* sw4 = swb + SWB;
+    float* sb1 = reinterpret_cast<float*>(sw4 + SW4);
+    float* sba = sb1 + 2 * C;
+    float* sbb = sba + CH;
+    float* sb4 = sbb + C;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    for (int i = tid; i < 2 * C; i += 512) sb1[i] = p.b1[i];
+    if (tid < CH) sba[tid] = p.ba[tid];
+    if (tid < C) sbb[tid] = p.bb[tid];
+    for (int i = tid; i < C2; i += 512) sb4[i] = p.b4[i];
+    // m.cv1's weights: MFMA A fragments in registers for the whole launch (rows >= CH of the packed matrix are zero)
+    half8 a1[KSA];
+#pragma unroll
+    for (int ks = 0; ks < KSA; ++ks) a1[ks] = *reinterpret_cast<const half8*>(p.wa + (size_t)lrow * p.Ka + 16 * ks + 8 * lh);
+    for (int i = tid; i < 2 * C * (CIN / 8); i += 512) {
+        const int row = i / (CIN / 8), ch = i - row * (CIN / 8);
+        *reinterpret_cast<half8*>(sw1 + row * W1S + ch * 8) = *reinterpret_cast<const half8*>(p.w1 + (size_t)row * p.K1 + ch * 8);
+    }
+    for (int i = tid; i < C * (9 * CH / 8); i += 512) {
+        const int row = i / (9 * CH / 8), ch = i - row * (9 * CH / 8);
+        *reinterpret_cast<half8*>(swb + row * WBS + ch * 8) = *reinterpret_cast<const half8*>(p.wb + (size_t)row * p.Kb + ch * 8);
+    }
+    for (int i = tid; i < C2 * (3 * C / 8); i += 512) {
+        const int row = i / (3 * C / 8), ch = i - row * (3 * C / 8);
+        *reinterpret_cast<half8*>(sw4 + row * W4S + ch * 8) = *reinterpret_cast<const half8*>(p.w4 + (size_t)row * p.K4 + ch * 8);
+    }
+
+    // tile-independent lane tables for the input prefetch
+    int it_off[NLOAD], it_rc[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int idx = tid + 512 * i;
+        const int e = idx / XCH, ch = idx - e * XCH;
+        const int r = e / CK_XC, c = e - r * CK_XC;
+        it_rc[i] = r | (c << 8) | (ch << 16);
+        it_off[i] = e * XS + ch * 8;
+    }
+    auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
+        const int r = (int)__umulhi((unsigned)tile, p.magic_x);
+        const int tx = tile - r * p.tiles_x;
+        n = (int)__umulhi((unsigned)r, p.magic_y);
+        const int ty = r - n * p.tiles_y;
+        oy0 = ty * CK_TH;
+        ox0 = tx * CK_TW;
+    };
+    half8 pre[NLOAD];
+    int nn = 0, noy0 = 0, nox0 = 0;
+    auto fetch = [&](int tile) {
+        tile_origin(tile, nn, noy0, nox0);
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int y = noy0 - 2 + (it_rc[i] & 255), x = nox0 - 2 + ((it_rc[i] >> 8) & 255);
+            pre[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (tid + 512 * i < NITEM && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                pre[i] = *reinterpret_cast<const half8*>(p.src + ((size_t)(nn * p.H + y) * p.W + x) * p.lds + (it_rc[i] >> 16) * 8);
+        }
+    };
+
+    // lane constants of the pixel this lane owns in S3 / S4 (MFMA pixel tile pt = 2 tile rows x 16 columns)
+    const int pt = wave & 3;
+    const int ty2 = 2 * pt + (lrow >> 4), tx2 = lrow & 15;
+    const int prow = pt * 32 + lrow;                                               // = ty2 * 16 + tx2
+    const half_t* b2base = smid + (ty2 * CK_MC + tx2) * MS + 8 * lh;               // hidden entry of tap (0, 0)
+    const half_t* y1own = sy1 + ((ty2 + 2) * CK_XC + tx2 + 2) * YS;                // the pixel's own y1 entry
+    const half_t* a2base = swb + lrow * WBS + 8 * lh;
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the weight loads here, not inside the tile loop (bneck_fused.hip)
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) fetch(tile);
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        const int n = nn, oy0 = noy0, ox0 = nox0;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i)
+            if (tid + 512 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
+        __syncthreads();  // (A) x patch visible (and, first iteration, the weights)
+        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+
+        // ---- S1: cv1 (1x1, CIN -> 2C) on the patch: MFMA pixel tile `wave` (entries 32 wave ..), both cout tiles --------
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+            const half_t* xb = sx + (32 * wave + lrow) * XS + 8 * lh;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const half8 bf = *reinterpret_cast<const half8*>(xb + 16 * ks);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(sw1 + (32 * ct + lrow) * W1S + 16 * ks + 8 * lh),
+                                                                     bf, acc[ct], 0, 0, 0);
+            }
+            const int e = 32 * wave + lrow;
+            const int r = e / CK_XC, c = e - r * CK_XC;
+            if (e < CK_NX) {
+                const unsigned keep = ((unsigned)(oy0 - 2 + r) < (unsigned)p.H && (unsigned)(ox0 - 2 + c) < (unsigned)p.W) ? 0xffffffffu : 0u;
+                const bool inner = r >= 2 && r < 2 + CK_TH && c >= 2 && c < 2 + CK_TW;
+                half_t* d0 = sy0 + ((r - 2) * CK_TW + (c - 2)) * YS;
+#pragma unroll
+                for (int g = 0; g < C / 8; ++g) {
+                    // y1 = channels C .. 2C-1 (cout tile 1): zero outside the map (the Bottleneck's convs pad y1 with zeros)
+                    {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + C + 8 * g + 4 * lh);
+                        union { half4 h; unsigned u[2]; } o;
+                        const f32x4 t = silu4_f(add4_f(f32x4{acc[1][4 * g], acc[1][4 * g + 1], acc[1][4 * g + 2], acc[1][4 * g + 3]}, bv));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
+                        o.u[0] &= keep;
+                        o.u[1] &= keep;
+                        *reinterpret_cast<half4*>(sy1 + e * YS + 8 * g + 4 * lh) = o.h;
+                    }
+                    if (inner) {  // y0 = channels 0 .. C-1 (cout tile 0): only cv2 reads it, on the tile's own pixels
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + 8 * g + 4 * lh);
+                        half4 o;
+                        const f32x4 t = silu4_f(add4_f(f32x4{acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]}, bv));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = (half_t)t[q];
+                        *reinterpret_cast<half4*>(d0 + 8 * g + 4 * lh) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // (B) y1 patch + y0 tile complete
+
+        // ---- S2: m.cv1 3x3 (C -> CH) on the 10 x 18 hidden patch: 6 MFMA pixel tiles, waves 0 .. 5 -------------------------
+        if (wave < (CK_NM + 31) / 32) {
+            const int mm = wave * 32 + lrow;
+            const int mc = mm < CK_NM ? mm : CK_NM - 1;
+            const int r = mc / CK_MC, c = mc - r * CK_MC;
+            const half_t* yb = sy1 + (r * CK_XC + c) * YS + 8 * lh;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSA; ++ks) {
+                const int k0 = 16 * ks, tap = k0 / C, ch0 = (k0 % C) / 8;  // compile-time
+                const half8 bf = *reinterpret_cast<const half8*>(yb + ((tap / 3) * CK_XC + tap % 3) * YS + ch0 * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks], bf, acc, 0, 0, 0);
+            }
+            const unsigned keep = ((unsigned)(oy0 - 1 + r) < (unsigned)p.H && (unsigned)(ox0 - 1 + c) < (unsigned)p.W) ? 0xffffffffu : 0u;
+            if (mm < CK_NM) {
+#pragma unroll
+                for (int g = 0; g < CH / 8; ++g) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sba + 8 * g + 4 * lh);
+                    union { half4 h; unsigned u[2]; } o;
+                    const f32x4 t = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
+                    o.u[0] &= keep;  // outside the map: m.cv2's zero padding
+                    o.u[1] &= keep;
+                    *reinterpret_cast<half4*>(smid + mm * MS + 8 * g + 4 * lh) = o.h;
+                }
+            }
+        }
+        __syncthreads();  // (C) hidden patch complete
+
+        // ---- S3: m.cv2 3x3 (CH -> C) + shortcut on the tile: one MFMA pixel tile per wave, waves 0 .. 3 ---------------------
+        if (wave < 4) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const int k0 = 16 * ks, tap = k0 / CH, ch0 = (k0 % CH) / 8;
+                const half8 bf = *reinterpret_cast<const half8*>(b2base + ((tap / 3) * CK_MC + tap % 3) * MS + ch0 * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(a2base + 16 * ks), bf, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < C / 8; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbb + 8 * g + 4 * lh);
+                const half4 rv = *reinterpret_cast<const half4*>(y1own + 8 * g + 4 * lh);
+                half4 o;
+                const f32x4 t = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)t[q] + (float)rv[q]);
+                *reinterpret_cast<half4*>(sy2 + prow * YS + 8 * g + 4 * lh) = o;
+            }
+        }
+        __syncthreads();  // (D) y2 tile complete
+
+        // ---- S4: cv2 (1x1, 3C -> C2) over [y0 | y1 | y2]: pixel tile pt, cout tiles (wave >> 2) * NCT .. ---------------------
+        {
+            constexpr int NCT = C2 / 64;  // cout tiles of 32 per wave
+            f32x16 acc[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+            const int ct0 = (wave >> 2) * NCT;
+#pragma unroll
+            for (int ks = 0; ks < 3 * KSEG; ++ks) {
+                const int seg = ks / KSEG, kk = ks - seg * KSEG;  // compile-time: 0 = y0, 1 = y1, 2 = y2
+                const half_t* sp = seg == 0 ? sy0 + prow * YS : (seg == 1 ? y1own : sy2 + prow * YS);
+                const half8 bf = *reinterpret_cast<const half8*>(sp + 16 * kk + 8 * lh);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        *reinterpret_cast<const half8*>(sw4 + (32 * (ct0 + ct) + lrow) * W4S + 16 * ks + 8 * lh), bf, acc[ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cc = 32 * (ct0 + ct) + 8 * g + 4 * lh;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb4 + cc);
+                    half4 o;
+                    const f32x4 t = silu4_f(add4_f(f32x4{acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]}, bv));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = (half_t)t[q];
+                    *reinterpret_cast<half4*>(sout + prow * OS + cc) = o;
+                }
+        }
+        __syncthreads();  // (E) output tile complete
+
+        constexpr int CPRW = C2 / 8;
+#pragma unroll
+        for (int id = tid; id < CK_NPX * CPRW; id += 512) {
+            const int pr = id / CPRW, cc = (id % CPRW) * 8;
+            const int oy = oy0 + pr / CK_TW, ox = ox0 + pr % CK_TW;
+            if (oy < p.H && ox < p.W)
+                *reinterpret_cast<half8*>(p.dst + ((size_t)(n * p.H + oy) * p.W + ox) * p.ldd + cc) =
+                    *reinterpret_cast<const half8*>(sout + pr * OS + cc);
+        }
+        __syncthreads();  // (F) output tile read: the next iteration overwrites it with the next x patch
+    }
+}
+
+bool c3k2_fused_supported(int Cin, int C, int C2) { return Cin == 64 && C == 32 && C2 == 128; }
+
+int launch_c3k2_fused(const C3k2Args& a, hipStream_t s) {
+    if (!c3k2_fused_supported(a.Cin, a.C, a.C2)) BSY_FAIL(BSY_ERR_ARG, "c3k2: unsupported widths (Cin %d, c %d, C2 %d): need (64, 32, 128)", a.Cin, a.C, a.C2);
+    if (a.B <= 0 || a.H <= 0 || a.W <= 0) BSY_FAIL(BSY_ERR_ARG, "c3k2: bad extent");
+    const void* ptrs[10] = {a.src, a.dst, a.w1, a.wa, a.wb, a.w4, a.b1, a.ba, a.bb, a.b4};
+    for (const void* q : ptrs)
+        if (!q || ((uintptr_t)q & 15)) BSY_FAIL(BSY_ERR_ARG, "c3k2: null or misaligned pointer");
+    if ((a.lds & 7) || (a.ldd & 7) || a.lds < a.Cin || a.ldd < a.C2) BSY_FAIL(BSY_ERR_ARG, "c3k2: bad leading dimension");
+    C3k2K k;
+    k.src = a.src; k.dst = a.dst; k.w1 = (const half_t*)a.w1; k.wa = (const half_t*)a.wa; k.wb = (const half_t*)a.wb; k.w4 = (const half_t*)a.w4;
+    k.b1 = a.b1; k.ba = a.ba; k.bb = a.bb; k.b4 = a.b4;
+    k.B = a.B; k.H = a.H; k.W = a.W; k.lds = a.lds; k.ldd = a.ldd;
+    int cp = 0;
+    bsy_conv_packed_dims(2 * a.C, a.Cin, 1, &cp, &k.K1);
+    bsy_conv_packed_dims(a.C / 2, a.C, 3, &cp, &k.Ka);
+    bsy_conv_packed_dims(a.C, a.C / 2, 3, &cp, &k.Kb);
+    bsy_conv_packed_dims(a.C2, 3 * a.C, 1, &cp, &k.K4);
+    k.tiles_x = ceil_div(a.W, CK_TW); k.tiles_y = ceil_div(a.H, CK_TH);
+    if (k.tiles_x < 2) k.tiles_x = 2;  // keep the multiply-high divisions exact; the extra tiles lie outside the map
+    if (k.tiles_y < 2) k.tiles_y = 2;
+    const long long nt = (long long)a.B * k.tiles_x * k.tiles_y;
+    if (nt * (k.tiles_x > k.tiles_y ? k.tiles_x : k.tiles_y) >= (1LL << 32)) BSY_FAIL(BSY_ERR_ARG, "c3k2: tile count out of range");
+    k.ntiles = (int)nt;
+    k.magic_x = (unsigned)(((1ULL << 32) + k.tiles_x - 1) / k.tiles_x);
+    k.magic_y = (unsigned)(((1ULL << 32) + k.tiles_y - 1) / k.tiles_y);
+    const int grid = k.ntiles < 256 ? k.ntiles : 256;  // one 512-thread workgroup (131 KiB of LDS) per CU
+    hipLaunchKernelGGL((c3k2_fused_kernel<64, 32, 128>), dim3(grid), dim3(512), 0, s, k);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}

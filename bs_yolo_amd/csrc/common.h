@@ -108,6 +108,19 @@ struct BneckArgs {
 bool bneck_fused_supported(int C, int CH);
 int launch_bneck_fused(const BneckArgs& a, hipStream_t s);
 
+// Fused C3k2 block (c3k2_fused.hip): out = cv2(cat(y0, y1, y1 + m.cv2(m.cv1(y1)))), [y0 | y1] = cv1(x); nothing but x and out in HBM.
+struct C3k2Args {
+    const half_t* src;  // (B,H,W,lds) view of Cin channels
+    int lds;
+    int B, H, W, Cin, C, C2;           // C = hidden width c of the block (cv1 -> 2c), bottleneck hidden c/2, output C2
+    const void *w1, *wa, *wb, *w4;     // packed f16 [CoutPad][Kpad]: cv1 (Cin -> 2c), m.cv1 (c -> c/2, 3x3), m.cv2 (c/2 -> c, 3x3), cv2 (3c -> C2)
+    const float *b1, *ba, *bb, *b4;
+    half_t* dst;
+    int ldd;
+};
+bool c3k2_fused_supported(int Cin, int C, int C2);
+int launch_c3k2_fused(const C3k2Args& a, hipStream_t s);
+
 // ---- BS-YOLO-only modules (bsyolo_ops.hip) ----------------------------------------------------------------------------
 struct DwGenArgs {       // depthwise kh x kw, stride 1 / 2, "same" padding, + bias (+SiLU)
     const half_t* src;

@@ -384,6 +384,18 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok) return BSY_ERR_ARG;
             return launch_bneck_fused(a, s);
         }
+        case BSY_OP_C3K2: {
+            C3k2Args a;
+            a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W;
+            a.Cin = op.src0.C; a.C = op.mid_c; a.C2 = op.dst.C;
+            a.w1 = wb + op.aux_off[0]; a.b1 = (const float*)(wb + op.aux_off[1]);
+            a.wa = wb + op.aux_off[2]; a.ba = (const float*)(wb + op.aux_off[3]);
+            a.wb = wb + op.aux_off[4]; a.bb = (const float*)(wb + op.aux_off[5]);
+            a.w4 = wb + op.aux_off[6]; a.b4 = (const float*)(wb + op.aux_off[7]);
+            a.dst = R.h(op.dst); a.ldd = op.dst.ld;
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_c3k2_fused(a, s);
+        }
         case BSY_OP_DWPW: {
             DwPwArgs a;
             a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C;
@@ -768,6 +780,18 @@ extern "C" int bsy_bottleneck_fused(const void* x, int ldx, int B, int H, int W,
 }
 
 extern "C" int bsy_bottleneck_fused_supported(int C, int CH) { return bneck_fused_supported(C, CH) ? 1 : 0; }
+
+extern "C" int bsy_c3k2_fused(const void* x, int ldx, int B, int H, int W, int Cin, int c, int C2, const void* w1, const float* b1,
+                              const void* wa, const float* ba, const void* wb, const float* bb, const void* w4, const float* b4,
+                              void* y, int ldy, bsy_stream stream) {
+    C3k2Args a;
+    a.src = (const half_t*)x; a.lds = ldx; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.C = c; a.C2 = C2;
+    a.w1 = w1; a.b1 = b1; a.wa = wa; a.ba = ba; a.wb = wb; a.bb = bb; a.w4 = w4; a.b4 = b4;
+    a.dst = (half_t*)y; a.ldd = ldy;
+    return launch_c3k2_fused(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_c3k2_fused_supported(int Cin, int c, int C2) { return c3k2_fused_supported(Cin, c, C2) ? 1 : 0; }
 
 extern "C" int bsy_dwconv(const void* x, int ldx, int B, int H, int W, int C, int kh, int kw, int stride, const float* w,
                           int wld, const float* b, void* y, int ldy, int act, bsy_stream stream) {

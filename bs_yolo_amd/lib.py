@@ -17,11 +17,11 @@ LIB_PATH = Path(os.environ["BSY_LIB"]) if os.environ.get("BSY_LIB") else PKG / "
 
 BSY_F16, BSY_F32, BSY_U8 = 0, 1, 2
 BSY_EXT_BASE = 0x100000
-(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW, OP_MSCA_SPATIAL) = range(18)
+(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW, OP_MSCA_SPATIAL, OP_C3K2) = range(19)
 
 SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_create_arena", "bsy_engine_arena_bytes", "bsy_plan_set_tuning", "bsy_plan_destroy",
-    "bsy_plan_run", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_check_guards", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_conv2d", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
+    "bsy_plan_run", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_check_guards", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_conv2d", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_c3k2_fused", "bsy_c3k2_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
     "bsy_sppf_pool", "bsy_attention", "bsy_detect_decode", "bsy_nms_workspace_bytes", "bsy_nms", "bsy_scale_boxes",
     "bsy_letterbox", "bsy_process_mask", "bsy_val_match", "bsy_slice_tiles", "bsy_sahi_merge_workspace_bytes",
     "bsy_sahi_merge", "bsy_ap_workspace_bytes", "bsy_ap_per_class", "bsy_last_error", "bsy_version",
@@ -103,6 +103,8 @@ def _load() -> C.CDLL:
     lib.bsy_val_match.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_float), i32, vp, vp]
     lib.bsy_bottleneck_fused.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.bsy_bottleneck_fused_supported.argtypes = [i32, i32]
+    lib.bsy_c3k2_fused.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.bsy_c3k2_fused_supported.argtypes = [i32, i32, i32]
     lib.bsy_dwconv.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp]
     lib.bsy_ela_scratch_bytes.argtypes = [i32, i32, i32, i32]
     lib.bsy_dwpw_fused.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]

@@ -102,6 +102,22 @@ def bottleneck_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: to
     return out
 
 
+def c3k2_fused(x: torch.Tensor, w1, b1, wa, ba, wb, bb, w4, b4, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Whole C3k2 block (c3k = False, one Bottleneck; block.py:3796-3804) in one launch: x (B,H,W,Cin) fp16 NHWC view ->
+    (B,H,W,C2).  w1 (2c,Cin,1,1), wa (c/2,c,3,3), wb (c,c/2,3,3), w4 (C2,3c,1,1) fp32 with BN folded, biases fp32."""
+    B, H, W, cin = x.shape
+    assert x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and x.stride(0) == H * W * x.stride(2)
+    c, c2 = wb.shape[0], w4.shape[0]
+    packs = [pack_conv_weight(w, b, x.device) for w, b in ((w1, b1), (wa, ba), (wb, bb), (w4, b4))]
+    if out is None:
+        out = torch.empty((B, H, W, c2), dtype=torch.float16, device=x.device)
+    assert out.shape == (B, H, W, c2) and out.stride(3) == 1 and out.stride(1) == W * out.stride(2)
+    L.check(L.lib.bsy_c3k2_fused(_p(x), x.stride(2), B, H, W, cin, c, c2, _p(packs[0][0]), _p(packs[0][1]), _p(packs[1][0]),
+                                 _p(packs[1][1]), _p(packs[2][0]), _p(packs[2][1]), _p(packs[3][0]), _p(packs[3][1]), _p(out),
+                                 out.stride(2), _stream(x)))
+    return out
+
+
 def dwpw_fused(x: torch.Tensor, wd: torch.Tensor, bd: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: bool = True) -> torch.Tensor:
     """DWConv 3x3 + SiLU -> Conv 1x1 (+act) in one launch.  x (B,H,W,C) fp16; wd (C,1,3,3), bd (C); w (C2,C,1,1), b (C2)."""
     B, H, W, Cc = x.shape

@@ -82,6 +82,11 @@ def dwpw_supported(c: int, cout: int) -> bool:
     return c > 0 and c % 32 == 0 and c <= 256 and cout % 8 == 0
 
 
+def c3k2_supported(cin: int, c: int, c2: int) -> bool:
+    """Widths csrc/c3k2_fused.hip is instantiated for (mirror of bsy_c3k2_fused_supported)."""
+    return (cin, c, c2) == (64, 32, 128)
+
+
 def bneck_supported(c: int, ch: int) -> bool:
     """Widths csrc/bneck_fused.hip accepts (mirror of bsy_bottleneck_fused_supported)."""
     return (c, ch) == (32, 16)
@@ -123,7 +128,7 @@ class Plan:
             for o in self.ops:
                 if "lane" in o:
                     o["lane"] = 0
-        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK, L.OP_DWCONV_G, L.OP_DWPW) for o in self.ops)
+        assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK, L.OP_DWCONV_G, L.OP_DWPW, L.OP_C3K2) for o in self.ops)
 
     # ---- buffers -------------------------------------------------------------------------------------------
     def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
@@ -264,6 +269,18 @@ class Plan:
         """block.py:3295-3317 (C2f) / :3796-3804 (C3k2).  inner: 'c2f' | 'bottleneck' | 'c3k'."""
         xs = [x] if isinstance(x, T) else list(x)
         c = int(c2 * e)
+        if (self.fuse_tail and inner == "bottleneck" and n == 1 and shortcut and len(xs) == 1 and not xs[0].up and not xs[0].f32
+                and c3k2_supported(xs[0].C, c, c2)):
+            # the whole block in one launch (csrc/c3k2_fused.hip): x in, out out, the [y0 | y1 | y2] concat never reaches HBM
+            names = [name + ".cv1", name + ".m.0.cv1", name + ".m.0.cv2", name + ".cv2"]
+            shapes = [(2 * c, xs[0].C, 1), (c // 2, c, 3), (c, c // 2, 3), (c2, 3 * c, 1)]
+            keys = [self._wrec(nm, name=nm, kind="conv", cout=co, cin=ci, k=k, perm=None) for nm, (co, ci, k) in zip(names, shapes)]
+            dst = self.alloc(c2, xs[0].H, xs[0].W)
+            fl = 2 * self.B * xs[0].H * xs[0].W * sum(co * ci * k * k for co, ci, k in shapes)
+            self.ops.append(dict(kind=L.OP_C3K2, H=xs[0].H, W=xs[0].W, OH=xs[0].H, OW=xs[0].W, src0=xs[0], dst=dst, ksize=3, stride=1, pad=1,
+                                 act=1, wkeys=keys, mid_c=c, name=name, lane=self._lane, mfma_flops=fl))
+            self.flops += fl
+            return dst
         cat = self.alloc((2 + n) * c, xs[0].H, xs[0].W)
         self.conv(name + ".cv1", xs, 2 * c, 1, 1, dst=cat.slice(0, 2 * c))
         for i in range(n):

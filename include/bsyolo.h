@@ -81,6 +81,9 @@ enum bsy_op_kind {
                             * strip-conv branch maps box[0..2] + res and their global means cls[0..2] + msk[0] ((B,1,1,C) f16);
                             * aux_off = (w, b) byte offsets of conv0, conv0_1, conv0_2, conv1_1, .. conv3_2 (f32 [taps][C] /
                             * [C], `dilconv` folded into conv{0,1,2}_2).  H * W <= 1890                                  */
+    BSY_OP_C3K2 = 18,      /* whole C3k2 block (c3k = False, n = 1; block.py:3796-3804) as one launch: src0 (Cin channels) -> dst
+                            * (C2 channels); mid_c = the block's hidden width c; aux_off = (weights, bias) byte offsets of cv1,
+                            * m.0.cv1, m.0.cv2, cv2.  Widths (Cin, c, C2) = (64, 32, 128): YOLO11s model.2, YOLO11n model.4        */
     BSY_OP_ELA = 15        /* ELA (nn/Addmodules/ELA.py:77-101): ksize = Conv1d taps; w_off -> f32 blob [spatial_conv C*k]
                             * [ch_att conv C*k][gn.weight C][gn.bias C]; scale, lvl_stride[0], lvl_stride[1] =
                             * sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight);
@@ -200,6 +203,13 @@ int bsy_stem_fused_supported(int C0, int C1, int H, int W);
 int bsy_bottleneck_fused(const void* x, int ldx, int B, int H, int W, int C, int CH, const void* w1, const float* b1,
                          const void* w2, const float* b2, void* y, int ldy, int act, bsy_stream stream);
 int bsy_bottleneck_fused_supported(int C, int CH);
+/* Whole C3k2 block (c3k = False, one Bottleneck; block.py:3796-3804 / :3308-3312 / :3405-3419) in one launch:
+ * y = cv2(cat(y0, y1, y1 + m.cv2(m.cv1(y1)))) with [y0 | y1] = cv1(x); x (B,H,W,ldx) NHWC f16 view of Cin channels, y (B,H,W,ldy)
+ * of C2 channels; weights packed as for bsy_conv2d (cv1: Cin -> 2c 1x1; m.cv1: c -> c/2 3x3; m.cv2: c/2 -> c 3x3; cv2: 3c -> C2 1x1).
+ * bsy_c3k2_fused_supported(Cin, c, C2) tells which widths the kernel is instantiated for. */
+int bsy_c3k2_fused(const void* x, int ldx, int B, int H, int W, int Cin, int c, int C2, const void* w1, const float* b1, const void* wa,
+                   const float* ba, const void* wb, const float* bb, const void* w4, const float* b4, void* y, int ldy, bsy_stream stream);
+int bsy_c3k2_fused_supported(int Cin, int c, int C2);
 
 /* Modules of the BS-YOLO graph (csrc/bsyolo_ops.hip), NHWC f16 views.
  * bsy_dwconv: depthwise kh x kw conv (odd sizes <= 31), stride 1 / 2, padding k/2, + bias (+SiLU when act);

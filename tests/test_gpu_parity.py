@@ -252,6 +252,70 @@ def test_bottleneck_fused_matches_unfused_and_oracle(shape):
     np.testing.assert_allclose(nchw(two.float().cpu()).numpy(), ref.numpy(), rtol=4e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 40, 24), (3, 9, 13), (300, 8, 16), (1, 3, 5), (2, 33, 47)])
+def test_c3k2_fused_matches_unfused_and_oracle(shape):
+    """The whole C3k2 block (c3k = False, one Bottleneck; block.py:3796-3804) as ONE launch (csrc/c3k2_fused.hip): bit-identical
+    to the three-launch path it replaces (cv1 conv -> fused Bottleneck on the y1 slice of the concat buffer -> cv2 conv) and
+    equal to the fp32 reference with every intermediate map rounded to fp16.  Shapes: ragged tiles, maps smaller than one
+    tile, more tiles than persistent workgroups; the input is a channel slice of a wider buffer."""
+    B, H, W = shape
+    cin, c, c2 = 64, 32, 128
+    g = torch.Generator().manual_seed(33)
+
+    def wt(co, ci, k):
+        return h16(torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5), torch.randn(co, generator=g) * 0.2
+    (w1, b1), (wa, ba), (wb, bb), (w4, b4) = wt(2 * c, cin, 1), wt(c // 2, c, 3), wt(c, c // 2, 3), wt(c2, 3 * c, 1)
+    buf = h16(torch.randn(B, H, W, cin + 16, generator=g))
+    dbuf = buf.half().to(DEV)
+    x = dbuf[..., 8:8 + cin]
+    out = O.c3k2_fused(x, w1, b1, wa, ba, wb, bb, w4, b4)
+    # the three-launch path through the same C ABI
+    p1, pb1 = O.pack_conv_weight(w1, b1, DEV)
+    p4, pb4 = O.pack_conv_weight(w4, b4, DEV)
+    cat = torch.zeros(B, H, W, 3 * c, dtype=torch.float16, device=DEV)
+    cat[..., :2 * c] = O.conv2d_nhwc(x.contiguous(), p1, pb1, 2 * c, 1, 1, True)
+    O.bottleneck_fused(cat[..., c:2 * c], wa, ba, wb, bb, out=cat[..., 2 * c:])
+    three = O.conv2d_nhwc(cat, p4, pb4, c2, 1, 1, True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, three)
+    assert torch.equal(dbuf.cpu(), buf.half())  # the input buffer is untouched
+    xr = nchw(buf[..., 8:8 + cin])
+    y01 = h16(F.silu(F.conv2d(xr, w1, b1)))
+    y1 = y01[:, c:]
+    y2 = h16(y1 + h16(F.silu(F.conv2d(h16(F.silu(F.conv2d(y1, wa, ba, 1, 1))), wb, bb, 1, 1))))
+    ref = F.silu(F.conv2d(torch.cat([y01, y2], 1), w4, b4))
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=4e-3, atol=4e-3)
+
+
+def test_c3k2_fused_rejects_unsupported():
+    assert L.lib.bsy_c3k2_fused_supported(64, 32, 128) == 1 and L.lib.bsy_c3k2_fused_supported(128, 64, 256) == 0
+    x = torch.zeros(1, 8, 8, 128, dtype=torch.float16, device=DEV)
+    with pytest.raises(L.BsyError):
+        O.c3k2_fused(x, torch.zeros(128, 128, 1, 1), torch.zeros(128), torch.zeros(32, 64, 3, 3), torch.zeros(32),
+                     torch.zeros(64, 32, 3, 3), torch.zeros(64), torch.zeros(256, 192, 1, 1), torch.zeros(256))
+
+
+def test_engine_c3k2_fusion_is_bit_identical():
+    """Engine level: YOLO11s with the C3k2 block of model.2 as one launch vs the three-launch plan (fuse_tail=False), and
+    YOLO11n (model.4 has the same widths)."""
+    for scale, shape in (("s", (3, 96, 160)), ("n", (2, 128, 64))):
+        m = R.Model("yolo11", scale, 80, "detect")
+        P = R.synth_params(m, 2)
+        cfg = stock_cfg("yolo11", scale)
+        fused = YoloEngine(cfg, P, autotune=False, fuse_tail=True)
+        plain = YoloEngine(cfg, P, autotune=False, fuse_tail=False)
+        B, H, W = shape
+        pf, _ = fused.plan_for(B, H, W, torch.float16, torch.float16)
+        pp, _ = plain.plan_for(B, H, W, torch.float16, torch.float16)
+        assert sum(o["kind"] == L.OP_C3K2 for o in pf.ops) == 1 and len(pp.ops) - len(pf.ops) == 2
+        x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(9)).half().to(DEV)
+        yf, rf = fused(x)
+        yp, rp = plain(x)
+        assert torch.equal(yf, yp) and all(torch.equal(a, b) for a, b in zip(rf, rp))
+        fused.close()
+        plain.close()
+
+
 def test_bottleneck_fused_rejects_unsupported():
     assert L.lib.bsy_bottleneck_fused_supported(32, 16) == 1 and L.lib.bsy_bottleneck_fused_supported(64, 32) == 0
     x = torch.zeros(1, 8, 8, 64, device=DEV).half()

@@ -59,7 +59,7 @@ def test_op_struct_layout():
 def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     """Dense-conv FLOPs per 640x640 image equal the reference graph (BASELINE.md section 2 / SURVEY 8d); the
     reference counts 81 dense convs for n/s because DFL is a 1x1 conv there (block.py:58-77), here it lives in decode."""
-    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False)
+    p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False, fuse_tail=False)
     dense = 0
     n = 0
     for o in p.ops:
@@ -97,8 +97,8 @@ def test_stem_fusion_peephole():
     """Layers 0 + 1 become one OP_STEM launch where csrc/stem_fused.hip supports the widths (n: 16/32, s: 32/64);
     m/l/x keep two launches.  Work accounting (plan.flops) and the parameter records do not change."""
     for scale, fused in (("n", True), ("s", True), ("m", False)):
-        a = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=False, fuse_bneck=False)
-        b = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=True, fuse_bneck=False)
+        a = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_tail=False)
+        b = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_stem=True, fuse_bneck=False, fuse_tail=False)
         assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
         if fused:
             assert len(b.ops) == len(a.ops) - 1 and b.ops[0]["kind"] == L.OP_STEM
@@ -115,8 +115,8 @@ def test_stem_fusion_peephole():
 def test_bottleneck_fusion_peephole():
     """C3k2's thin Bottleneck (32 -> 16 -> 32 with shortcut: model.2.m.0 of YOLO11s) becomes one OP_BNECK launch;
     other widths keep two convs.  FLOP accounting and parameter records are unchanged."""
-    a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=False)
-    b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=True)
+    a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_tail=False)
+    b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=True, fuse_tail=False)
     assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
     fused = [o for o in b.ops if o["kind"] == L.OP_BNECK]
     assert [o["name"] for o in fused] == ["model.2.m.0"] and len(b.ops) == len(a.ops) - 1
@@ -126,10 +126,29 @@ def test_bottleneck_fusion_peephole():
     for r in ("cv1", "cv2"):
         ra, rb = a.wrecs[f"model.2.m.0.{r}"], b.wrecs[f"model.2.m.0.{r}"]
         assert (ra.kind, ra.cout, ra.cin, ra.k) == (rb.kind, rb.cout, rb.cin, rb.k)
-    n = Plan(stock_cfg("yolo11", "n"), 1, 64, 64, fuse_bneck=True)  # same widths one level down
+    n = Plan(stock_cfg("yolo11", "n"), 1, 64, 64, fuse_bneck=True, fuse_tail=False)  # same widths one level down
     assert [o["name"] for o in n.ops if o["kind"] == L.OP_BNECK] == ["model.4.m.0", "model.16.m.0"]
     m = Plan(stock_cfg("yolo11", "m"), 1, 64, 64, fuse_bneck=True)  # C3k blocks, e = 1.0: not fused
     assert not any(o["kind"] == L.OP_BNECK for o in m.ops)
+
+
+def test_c3k2_fusion_peephole():
+    """A whole C3k2 block with one thin Bottleneck (Cin 64 -> c 32 -> 128: model.2 of YOLO11s, model.4 of YOLO11n) becomes ONE
+    OP_C3K2 launch (csrc/c3k2_fused.hip); blocks fed by a Concat (model.16 of YOLO11n) and C3k blocks keep their launches.
+    FLOP accounting, parameter records and their order (synth_state_dict draws follow it) are unchanged."""
+    for scale, want in (("s", ["model.2"]), ("n", ["model.4"]), ("m", [])):
+        a = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_tail=False)
+        b = Plan(stock_cfg("yolo11", scale), 2, 640, 640, fuse_tail=True)
+        assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
+        fused = [o for o in b.ops if o["kind"] == L.OP_C3K2]
+        assert [o["name"] for o in fused] == want
+        assert sum(o.get("mfma_flops", 0) for o in a.ops) == sum(o.get("mfma_flops", 0) for o in b.ops)
+        for o in fused:
+            assert (o["src0"].C, o["mid_c"], o["dst"].C) == (64, 32, 128) and len(o["wkeys"]) == 4
+            assert o["wkeys"] == [o["name"] + sfx for sfx in (".cv1", ".m.0.cv1", ".m.0.cv2", ".cv2")]
+            assert len(a.ops) - len(b.ops) == 2  # cv1 conv + fused Bottleneck + cv2 conv -> one op
+            assert sum(b.buf_bytes) < sum(a.buf_bytes)  # no concat buffer
+    assert L.OP_C3K2 == 18 and L.Op.aux_off.offset % 8 == 0
 
 
 def test_dwpw_fusion_peephole():
@@ -398,7 +417,7 @@ def test_isa_has_no_packed_f32():
     bad, n, scratch = isa_scan.scan()
     assert n >= 130, f"only {n} kernels found: the disassembly failed"
     assert not bad, f"packed f32 arithmetic in {bad}"
-    conv_scratch = [k for k in scratch if "conv_mfma_kernel" in k or "conv3x3_patch" in k or "conv1x1_persist" in k or "c3k2_tail" in k]
+    conv_scratch = [k for k in scratch if "conv_mfma_kernel" in k or "conv3x3_patch" in k or "conv1x1_persist" in k or "c3k2_fused" in k or "bneck_fused" in k]
     assert not conv_scratch, f"scratch frames in {conv_scratch}"
 
 
