@@ -5,29 +5,30 @@
 //
 // Unfused (round 1: cv1 conv + fused Bottleneck + cv2 conv) this block moved 1.36 GB through HBM per batch of 64 for
 // 0.21 GB in and 0.42 GB out and took 0.33 ms of a 3.3 ms forward: the [y0 | y1 | y2] concat buffer is written by three
-// launches and read back by two.  Here a workgroup (8 waves, persistent) owns an 8 x 16 output tile:
-//   * the 12 x 20 input patch (halo 2 for the two 3x3 convs; zeros outside the image) is fetched into registers one tile
+// launches and read back by two.  Here a workgroup (4 waves, persistent, two per CU) owns a 4 x 16 output tile:
+//   * the 8 x 20 input patch (halo 2 for the two 3x3 convs; zeros outside the image) is fetched into registers one tile
 //     ahead and parked in LDS (padded entries: every MFMA B fragment is one ds_read_b128 at a compile-time offset from a
 //     per-lane base, conflict-free);
-//   * S1  cv1 on all 240 patch pixels -> y1 patch (zeros outside the MAP: the bottleneck's zero padding applies to y1, not
+//   * S1  cv1 on all 160 patch pixels -> y1 patch (zeros outside the MAP: the bottleneck's zero padding applies to y1, not
 //         to x) and the interior y0 tile, both in LDS;
-//   * S2  m.cv1 3x3 on the 10 x 18 hidden patch (zeros outside the map), S3  m.cv2 3x3 + shortcut -> y2 tile: the
+//   * S2  m.cv1 3x3 on the 6 x 18 hidden patch (zeros outside the map), S3  m.cv2 3x3 + shortcut -> y2 tile: the
 //         arithmetic of bneck_fused.hip;
 //   * S4  cv2 over K = [y0 | y1 | y2] straight from the three LDS tiles -> output tile in LDS -> coalesced 16-byte stores.
-// All weights stay on chip for the whole launch (LDS; m.cv1's as MFMA A fragments in registers).  K orders (channels
+// All weights stay on chip for the whole launch (cv1's and m.cv2's in LDS; m.cv1's and each wave's 32 output channels of
+// cv2 as MFMA A fragments in registers).  K orders (channels
 // ascending for the 1x1 convs, tap-major for the 3x3 convs) and the epilogue arithmetic (f16(SiLU), shortcut added in f32)
 // equal conv_mfma.hip's / bneck_fused.hip's, so the block returns bit for bit what the three-launch path returns.
 #include "common.h"
 
-#define CK_TH 8
+#define CK_TH 4
 #define CK_TW 16
 #define CK_XR (CK_TH + 4)
 #define CK_XC (CK_TW + 4)
-#define CK_NX (CK_XR * CK_XC)  // 240 patch pixels (x and y1)
+#define CK_NX (CK_XR * CK_XC)  // 160 patch pixels (x and y1) = 5 MFMA pixel tiles
 #define CK_MR (CK_TH + 2)
 #define CK_MC (CK_TW + 2)
-#define CK_NM (CK_MR * CK_MC)  // 180 hidden pixels
-#define CK_NPX (CK_TH * CK_TW)  // 128 output pixels
+#define CK_NM (CK_MR * CK_MC)  // 108 hidden pixels (4 MFMA pixel tiles)
+#define CK_NPX (CK_TH * CK_TW)  // 64 output pixels (2 MFMA pixel tiles)
 
 struct C3k2K {
     const half_t* src;
@@ -38,18 +39,22 @@ struct C3k2K {
     unsigned magic_x, magic_y;
 };
 
+// 4 waves, TWO workgroups per CU (71 KiB of LDS each): the block is bound by its SiLU evaluations (38 k per 128 output pixels,
+// ~34 VALU cycles per 64 of them) -- two independent workgroups drift apart, so one's MFMA / LDS / memory phases run under the
+// other's VALU phases; a single 8-wave workgroup (first version: 8 x 16 tile, 131 KiB) kept both waves of a SIMD in the same
+// phase and ran at the unfused speed (0.31 ms vs 0.33 ms).
 template <int CIN, int C, int C2>
-__global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
+__global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
     constexpr int CH = C / 2;
     constexpr int XS = CIN + 8, YS = C + 8, MS = CH + 8, OS = C2 + 8;          // padded LDS entries (halves)
-    constexpr int W1S = CIN + 8, WBS = 9 * CH + 8, W4S = 3 * C + 8;            // padded weight rows (halves)
+    constexpr int W1S = CIN + 8, WBS = 9 * CH + 8;                             // padded weight rows (halves)
     constexpr int KS1 = CIN / 16, KSA = 9 * C / 16, KSB = 9 * CH / 16, KSEG = C / 16;  // MFMA K-steps
-    constexpr int XCH = CIN / 8, NITEM = CK_NX * XCH, NLOAD = (NITEM + 511) / 512;
-    static_assert(C == 32 && CH == 16 && CIN % 16 == 0 && C2 % 64 == 0 && C2 <= 128, "instantiated for the c = 32 C3k2 block");
-    constexpr int SX = 256 * XS > CK_NPX * OS ? 256 * XS : CK_NPX * OS;        // x patch (8 MFMA pixel tiles), later the output tile
+    constexpr int XCH = CIN / 8, NITEM = CK_NX * XCH, NLOAD = (NITEM + 255) / 256;
+    static_assert(C == 32 && CH == 16 && CIN % 16 == 0 && C2 == 128 && CK_NX == 160 && CK_NPX == 64, "instantiated for the c = 32 C3k2 block");
+    constexpr int SX = CK_NX * XS > CK_NPX * OS ? CK_NX * XS : CK_NPX * OS;    // x patch, later the output tile
     constexpr int SY1 = CK_NX * YS, SY0 = CK_NPX * YS, SM = CK_NM * MS, SY2 = CK_NPX * YS;
-    constexpr int SW1 = 2 * C * W1S, SWB = C * WBS, SW4 = C2 * W4S;
-    __shared__ __attribute__((aligned(16))) half_t lds[SX + SY1 + SY0 + SM + SY2 + SW1 + SWB + SW4 + 2 * (2 * C + CH + C + C2)];
+    constexpr int SW1 = 2 * C * W1S, SWB = C * WBS;
+    __shared__ __attribute__((aligned(16))) half_t lds[SX + SY1 + SY0 + SM + SY2 + SW1 + SWB + 2 * (2 * C + CH + C + C2)];
     half_t* sx = lds;
     half_t* sout = lds;  // aliases sx: x is dead after S1, the output tile is written in S4
     half_t* sy1 = sx + SX;
@@ -58,8 +63,7 @@ __global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
     half_t* sy2 = smid + SM;
     half_t* sw1 = sy2 + SY2;
     half_t* swb = sw1 + SW1;
-    half_t* sw4 = swb + SWB;
-    float* sb1 = reinterpret_cast<float*>(sw4 + SW4);
+    float* sb1 = reinterpret_cast<float*>(swb + SWB);
     float* sba = sb1 + 2 * C;
     float* sbb = sba + CH;
     float* sb4 = sbb + C;
@@ -68,32 +72,31 @@ __global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lh = lane >> 5;
 
-    for (int i = tid; i < 2 * C; i += 512) sb1[i] = p.b1[i];
+    for (int i = tid; i < 2 * C; i += 256) sb1[i] = p.b1[i];
     if (tid < CH) sba[tid] = p.ba[tid];
     if (tid < C) sbb[tid] = p.bb[tid];
-    for (int i = tid; i < C2; i += 512) sb4[i] = p.b4[i];
-    // m.cv1's weights: MFMA A fragments in registers for the whole launch (rows >= CH of the packed matrix are zero)
-    half8 a1[KSA];
+    for (int i = tid; i < C2; i += 256) sb4[i] = p.b4[i];
+    // register-resident MFMA A fragments for the whole launch: m.cv1 (rows >= CH of the packed matrix are zero) and THIS wave's
+    // 32 output channels of cv2 (S4 splits cv2 by cout tile: wave = cout tile)
+    half8 a1[KSA], a4[3 * KSEG];
 #pragma unroll
     for (int ks = 0; ks < KSA; ++ks) a1[ks] = *reinterpret_cast<const half8*>(p.wa + (size_t)lrow * p.Ka + 16 * ks + 8 * lh);
-    for (int i = tid; i < 2 * C * (CIN / 8); i += 512) {
+#pragma unroll
+    for (int ks = 0; ks < 3 * KSEG; ++ks) a4[ks] = *reinterpret_cast<const half8*>(p.w4 + (size_t)(32 * wave + lrow) * p.K4 + 16 * ks + 8 * lh);
+    for (int i = tid; i < 2 * C * (CIN / 8); i += 256) {
         const int row = i / (CIN / 8), ch = i - row * (CIN / 8);
         *reinterpret_cast<half8*>(sw1 + row * W1S + ch * 8) = *reinterpret_cast<const half8*>(p.w1 + (size_t)row * p.K1 + ch * 8);
     }
-    for (int i = tid; i < C * (9 * CH / 8); i += 512) {
+    for (int i = tid; i < C * (9 * CH / 8); i += 256) {
         const int row = i / (9 * CH / 8), ch = i - row * (9 * CH / 8);
         *reinterpret_cast<half8*>(swb + row * WBS + ch * 8) = *reinterpret_cast<const half8*>(p.wb + (size_t)row * p.Kb + ch * 8);
-    }
-    for (int i = tid; i < C2 * (3 * C / 8); i += 512) {
-        const int row = i / (3 * C / 8), ch = i - row * (3 * C / 8);
-        *reinterpret_cast<half8*>(sw4 + row * W4S + ch * 8) = *reinterpret_cast<const half8*>(p.w4 + (size_t)row * p.K4 + ch * 8);
     }
 
     // tile-independent lane tables for the input prefetch
     int it_off[NLOAD], it_rc[NLOAD];
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-        const int idx = tid + 512 * i;
+        const int idx = tid + 256 * i;
         const int e = idx / XCH, ch = idx - e * XCH;
         const int r = e / CK_XC, c = e - r * CK_XC;
         it_rc[i] = r | (c << 8) | (ch << 16);
@@ -115,17 +118,13 @@ __global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
         for (int i = 0; i < NLOAD; ++i) {
             const int y = noy0 - 2 + (it_rc[i] & 255), x = nox0 - 2 + ((it_rc[i] >> 8) & 255);
             pre[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (tid + 512 * i < NITEM && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+            if (tid + 256 * i < NITEM && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
                 pre[i] = *reinterpret_cast<const half8*>(p.src + ((size_t)(nn * p.H + y) * p.W + x) * p.lds + (it_rc[i] >> 16) * 8);
         }
     };
 
-    // lane constants of the pixel this lane owns in S3 / S4 (MFMA pixel tile pt = 2 tile rows x 16 columns)
-    const int pt = wave & 3;
-    const int ty2 = 2 * pt + (lrow >> 4), tx2 = lrow & 15;
-    const int prow = pt * 32 + lrow;                                               // = ty2 * 16 + tx2
-    const half_t* b2base = smid + (ty2 * CK_MC + tx2) * MS + 8 * lh;               // hidden entry of tap (0, 0)
-    const half_t* y1own = sy1 + ((ty2 + 2) * CK_XC + tx2 + 2) * YS;                // the pixel's own y1 entry
+    // lane constants of the output pixel (MFMA pixel tile q = tile rows 2q, 2q + 1): prow = 32 q + lrow
+    const int lty = lrow >> 4, ltx = lrow & 15;
     const half_t* a2base = swb + lrow * WBS + 8 * lh;
 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the weight loads here, not inside the tile loop (bneck_fused.hip)
@@ -135,60 +134,48 @@ __global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
         const int n = nn, oy0 = noy0, ox0 = nox0;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i)
-            if (tid + 512 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
+            if (tid + 256 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
         __syncthreads();  // (A) x patch visible (and, first iteration, the weights)
         if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
 
-        // ---- S1: cv1 (1x1, CIN -> 2C) on the patch: MFMA pixel tile `wave` (entries 32 wave ..), both cout tiles --------
-        {
-            f32x16 acc[2];
+        // ---- S1: cv1 (1x1, CIN -> 2C).  Seven jobs of one MFMA tile (32 pixels x 32 channels) over four waves: y1 = channels
+        //      C .. 2C-1 on the five pixel tiles of the patch (zero outside the MAP: the Bottleneck's convs pad y1, not x), y0 =
+        //      channels 0 .. C-1 on the two pixel tiles of the tile's own pixels (only cv2 reads y0) --------------------------------
+        auto s1_job = [&](const bool is_y0, const int t) {
+            // is_y0: pixel = output pixel 32 t + lrow -> patch entry (row + 2, column + 2); else pixel = patch entry 32 t + lrow
+            const int e = is_y0 ? (2 * t + lty + 2) * CK_XC + ltx + 2 : 32 * t + lrow;
+            const half_t* xb = sx + e * XS + 8 * lh;
+            const half_t* ab = sw1 + ((is_y0 ? 0 : C) + lrow) * W1S + 8 * lh;
+            f32x16 acc;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
-            const half_t* xb = sx + (32 * wave + lrow) * XS + 8 * lh;
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const half8 bf = *reinterpret_cast<const half8*>(xb + 16 * ks);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(sw1 + (32 * ct + lrow) * W1S + 16 * ks + 8 * lh),
-                                                                     bf, acc[ct], 0, 0, 0);
-            }
-            const int e = 32 * wave + lrow;
+            for (int ks = 0; ks < KS1; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(ab + 16 * ks), *reinterpret_cast<const half8*>(xb + 16 * ks),
+                                                             acc, 0, 0, 0);
             const int r = e / CK_XC, c = e - r * CK_XC;
-            if (e < CK_NX) {
-                const unsigned keep = ((unsigned)(oy0 - 2 + r) < (unsigned)p.H && (unsigned)(ox0 - 2 + c) < (unsigned)p.W) ? 0xffffffffu : 0u;
-                const bool inner = r >= 2 && r < 2 + CK_TH && c >= 2 && c < 2 + CK_TW;
-                half_t* d0 = sy0 + ((r - 2) * CK_TW + (c - 2)) * YS;
+            const unsigned keep = (is_y0 || ((unsigned)(oy0 - 2 + r) < (unsigned)p.H && (unsigned)(ox0 - 2 + c) < (unsigned)p.W)) ? 0xffffffffu : 0u;
+            half_t* d = is_y0 ? sy0 + (32 * t + lrow) * YS : sy1 + e * YS;
+            const float* bb_ = sb1 + (is_y0 ? 0 : C);
 #pragma unroll
-                for (int g = 0; g < C / 8; ++g) {
-                    // y1 = channels C .. 2C-1 (cout tile 1): zero outside the map (the Bottleneck's convs pad y1 with zeros)
-                    {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + C + 8 * g + 4 * lh);
-                        union { half4 h; unsigned u[2]; } o;
-                        const f32x4 t = silu4_f(add4_f(f32x4{acc[1][4 * g], acc[1][4 * g + 1], acc[1][4 * g + 2], acc[1][4 * g + 3]}, bv));
+            for (int g = 0; g < C / 8; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bb_ + 8 * g + 4 * lh);
+                union { half4 h; unsigned u[2]; } o;
+                const f32x4 tv = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
-                        o.u[0] &= keep;
-                        o.u[1] &= keep;
-                        *reinterpret_cast<half4*>(sy1 + e * YS + 8 * g + 4 * lh) = o.h;
-                    }
-                    if (inner) {  // y0 = channels 0 .. C-1 (cout tile 0): only cv2 reads it, on the tile's own pixels
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + 8 * g + 4 * lh);
-                        half4 o;
-                        const f32x4 t = silu4_f(add4_f(f32x4{acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]}, bv));
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = (half_t)t[q];
-                        *reinterpret_cast<half4*>(d0 + 8 * g + 4 * lh) = o;
-                    }
-                }
+                for (int q = 0; q < 4; ++q) o.h[q] = (half_t)tv[q];
+                o.u[0] &= keep;
+                o.u[1] &= keep;
+                *reinterpret_cast<half4*>(d + 8 * g + 4 * lh) = o.h;
             }
-        }
+        };
+        s1_job(false, wave);
+        if (wave == 0) s1_job(false, 4);
+        else if (wave < 3) s1_job(true, wave - 1);
         __syncthreads();  // (B) y1 patch + y0 tile complete
 
-        // ---- S2: m.cv1 3x3 (C -> CH) on the 10 x 18 hidden patch: 6 MFMA pixel tiles, waves 0 .. 5 -------------------------
-        if (wave < (CK_NM + 31) / 32) {
+        // ---- S2: m.cv1 3x3 (C -> CH) on the 6 x 18 hidden patch: MFMA pixel tile `wave` ------------------------------------------
+        {
             const int mm = wave * 32 + lrow;
             const int mc = mm < CK_NM ? mm : CK_NM - 1;
             const int r = mc / CK_MC, c = mc - r * CK_MC;
@@ -208,9 +195,9 @@ __global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
                 for (int g = 0; g < CH / 8; ++g) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sba + 8 * g + 4 * lh);
                     union { half4 h; unsigned u[2]; } o;
-                    const f32x4 t = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
+                    const f32x4 tv = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
+                    for (int q = 0; q < 4; ++q) o.h[q] = (half_t)tv[q];
                     o.u[0] &= keep;  // outside the map: m.cv2's zero padding
                     o.u[1] &= keep;
                     *reinterpret_cast<half4*>(smid + mm * MS + 8 * g + 4 * lh) = o.h;
@@ -219,8 +206,11 @@ __global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
         }
         __syncthreads();  // (C) hidden patch complete
 
-        // ---- S3: m.cv2 3x3 (CH -> C) + shortcut on the tile: one MFMA pixel tile per wave, waves 0 .. 3 ---------------------
-        if (wave < 4) {
+        // ---- S3: m.cv2 3x3 (CH -> C) + shortcut: the two MFMA pixel tiles of the output tile, waves 0 and 1 ------------------------
+        if (wave < 2) {
+            const int ty2 = 2 * wave + lty;
+            const half_t* b2base = smid + (ty2 * CK_MC + ltx) * MS + 8 * lh;       // hidden entry of tap (0, 0)
+            const half_t* y1own = sy1 + ((ty2 + 2) * CK_XC + ltx + 2) * YS;        // the pixel's own y1 entry (the shortcut)
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -235,51 +225,49 @@ __global__ __launch_bounds__(512) void c3k2_fused_kernel(const C3k2K p) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(sbb + 8 * g + 4 * lh);
                 const half4 rv = *reinterpret_cast<const half4*>(y1own + 8 * g + 4 * lh);
                 half4 o;
-                const f32x4 t = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
+                const f32x4 tv = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)t[q] + (float)rv[q]);
-                *reinterpret_cast<half4*>(sy2 + prow * YS + 8 * g + 4 * lh) = o;
+                for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)tv[q] + (float)rv[q]);
+                *reinterpret_cast<half4*>(sy2 + (32 * wave + lrow) * YS + 8 * g + 4 * lh) = o;
             }
         }
         __syncthreads();  // (D) y2 tile complete
 
-        // ---- S4: cv2 (1x1, 3C -> C2) over [y0 | y1 | y2]: pixel tile pt, cout tiles (wave >> 2) * NCT .. ---------------------
+        // ---- S4: cv2 (1x1, 3C -> C2) over [y0 | y1 | y2]: cout tile `wave`, both pixel tiles ----------------------------------------
         {
-            constexpr int NCT = C2 / 64;  // cout tiles of 32 per wave
-            f32x16 acc[NCT];
+            f32x16 acc[2];
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
+            for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
-            const int ct0 = (wave >> 2) * NCT;
+                for (int q = 0; q < 16; ++q) acc[q2][q] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 3 * KSEG; ++ks) {
                 const int seg = ks / KSEG, kk = ks - seg * KSEG;  // compile-time: 0 = y0, 1 = y1, 2 = y2
-                const half_t* sp = seg == 0 ? sy0 + prow * YS : (seg == 1 ? y1own : sy2 + prow * YS);
-                const half8 bf = *reinterpret_cast<const half8*>(sp + 16 * kk + 8 * lh);
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                        *reinterpret_cast<const half8*>(sw4 + (32 * (ct0 + ct) + lrow) * W4S + 16 * ks + 8 * lh), bf, acc[ct], 0, 0, 0);
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int prow = 32 * q2 + lrow;
+                    const half_t* sp = seg == 0 ? sy0 + prow * YS : (seg == 1 ? sy1 + ((2 * q2 + lty + 2) * CK_XC + ltx + 2) * YS : sy2 + prow * YS);
+                    acc[q2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a4[ks], *reinterpret_cast<const half8*>(sp + 16 * kk + 8 * lh), acc[q2], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
+            for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int cc = 32 * (ct0 + ct) + 8 * g + 4 * lh;
+                    const int cc = 32 * wave + 8 * g + 4 * lh;
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb4 + cc);
                     half4 o;
-                    const f32x4 t = silu4_f(add4_f(f32x4{acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]}, bv));
+                    const f32x4 tv = silu4_f(add4_f(f32x4{acc[q2][4 * g], acc[q2][4 * g + 1], acc[q2][4 * g + 2], acc[q2][4 * g + 3]}, bv));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = (half_t)t[q];
-                    *reinterpret_cast<half4*>(sout + prow * OS + cc) = o;
+                    for (int q = 0; q < 4; ++q) o[q] = (half_t)tv[q];
+                    *reinterpret_cast<half4*>(sout + (32 * q2 + lrow) * OS + cc) = o;
                 }
         }
         __syncthreads();  // (E) output tile complete
 
         constexpr int CPRW = C2 / 8;
 #pragma unroll
-        for (int id = tid; id < CK_NPX * CPRW; id += 512) {
+        for (int id = tid; id < CK_NPX * CPRW; id += 256) {
             const int pr = id / CPRW, cc = (id % CPRW) * 8;
             const int oy = oy0 + pr / CK_TW, ox = ox0 + pr % CK_TW;
             if (oy < p.H && ox < p.W)
@@ -316,8 +304,8 @@ int launch_c3k2_fused(const C3k2Args& a, hipStream_t s) {
     k.ntiles = (int)nt;
     k.magic_x = (unsigned)(((1ULL << 32) + k.tiles_x - 1) / k.tiles_x);
     k.magic_y = (unsigned)(((1ULL << 32) + k.tiles_y - 1) / k.tiles_y);
-    const int grid = k.ntiles < 256 ? k.ntiles : 256;  // one 512-thread workgroup (131 KiB of LDS) per CU
-    hipLaunchKernelGGL((c3k2_fused_kernel<64, 32, 128>), dim3(grid), dim3(512), 0, s, k);
+    const int grid = k.ntiles < 512 ? k.ntiles : 512;  // two 256-thread workgroups (71 KiB of LDS each) per CU
+    hipLaunchKernelGGL((c3k2_fused_kernel<64, 32, 128>), dim3(grid), dim3(256), 0, s, k);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }

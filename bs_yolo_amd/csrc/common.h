@@ -309,8 +309,14 @@ __device__ __forceinline__ void fma_mix8(float (&a)[8], const half8& v, const f3
 
 // SiLU in fp32: x * sigmoid(x) = x / (1 + 2^(-x*log2 e)); v_exp_f32 + v_rcp_f32 (1 ulp each) -- the result is rounded
 // to fp16 right after, so the IEEE-division expansion (~10 VALU) would buy nothing.  exp2 overflow -> inf -> rcp -> 0.
+// The product passes through an empty asm: where a conversion to f16 follows directly, the compiler otherwise folds the final
+// multiply and the conversion into v_fma_mixlo/hi_f16 -- ONE rounding of the exact product -- in some kernels and not in others
+// (it did in c3k2_fused.hip's Bottleneck stage, not in bneck_fused.hip: 2 pixels in 1000 differed by one f16 ulp).  Every
+// kernel rounds twice (f32, then f16), so fused and unfused launches agree bit for bit.
 __device__ __forceinline__ float silu_f(float x) {
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+    float r = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+    asm("" : "+v"(r));
+    return r;
 }
 // a + b element by element: a vector-typed `a + b` is a pair of v_pk_add_f32, this is four v_add_f32 (the kernels that run
 // beside other streams' MFMA kernels carry no packed f32 arithmetic at all; see the note on fma_mix_lo above)
