@@ -92,15 +92,21 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
         *reinterpret_cast<half8*>(swb + row * WBS + ch * 8) = *reinterpret_cast<const half8*>(p.wb + (size_t)row * p.Kb + ch * 8);
     }
 
-    // tile-independent lane tables for the input prefetch
-    int it_off[NLOAD], it_rc[NLOAD];
+    // Tile-independent lane tables (the block is bound by VALU issue: nothing that depends only on the lane is recomputed per
+    // tile).  Prefetch item i of this thread = 16-byte chunk ch of patch entry (r, c): LDS offset, element offset from the
+    // patch origin pixel (a uniform per-tile base pointer is added: `saddr + 32-bit voffset` addressing), and (r, c) for the
+    // bounds test.
+    int it_off[NLOAD], it_r[NLOAD], it_c[NLOAD];
+    unsigned it_rel[NLOAD];
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
         const int idx = tid + 256 * i;
         const int e = idx / XCH, ch = idx - e * XCH;
         const int r = e / CK_XC, c = e - r * CK_XC;
-        it_rc[i] = r | (c << 8) | (ch << 16);
+        it_r[i] = idx < NITEM ? r : 0x40000000;  // items past the patch: never in bounds
+        it_c[i] = c;
         it_off[i] = e * XS + ch * 8;
+        it_rel[i] = (unsigned)((r * p.W + c) * p.lds + ch * 8);
     }
     auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
         const int r = (int)__umulhi((unsigned)tile, p.magic_x);
@@ -114,17 +120,37 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
     int nn = 0, noy0 = 0, nox0 = 0;
     auto fetch = [&](int tile) {
         tile_origin(tile, nn, noy0, nox0);
+        // patch origin pixel (oy0 - 2, ox0 - 2): may lie outside the image -- only a base for pointer arithmetic
+        const half_t* tb = p.src + ((long long)(nn * p.H + noy0 - 2) * p.W + (nox0 - 2)) * p.lds;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int y = noy0 - 2 + (it_rc[i] & 255), x = nox0 - 2 + ((it_rc[i] >> 8) & 255);
             pre[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (tid + 256 * i < NITEM && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-                pre[i] = *reinterpret_cast<const half8*>(p.src + ((size_t)(nn * p.H + y) * p.W + x) * p.lds + (it_rc[i] >> 16) * 8);
+            if ((unsigned)(noy0 - 2 + it_r[i]) < (unsigned)p.H && (unsigned)(nox0 - 2 + it_c[i]) < (unsigned)p.W)
+                pre[i] = *reinterpret_cast<const half8*>(tb + it_rel[i]);
         }
     };
-
-    // lane constants of the output pixel (MFMA pixel tile q = tile rows 2q, 2q + 1): prow = 32 q + lrow
+    // output items of this thread: 16-byte piece cc of output pixel pr
+    constexpr int CPRW = C2 / 8, NST = CK_NPX * CPRW / 256;
+    int st_y[NST], st_x[NST], st_off[NST];
+    unsigned st_rel[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int id = tid + 256 * j;
+        const int pr = id / CPRW, cc = (id % CPRW) * 8;
+        st_y[j] = pr / CK_TW;
+        st_x[j] = pr % CK_TW;
+        st_off[j] = pr * OS + cc;
+        st_rel[j] = (unsigned)((st_y[j] * p.W + st_x[j]) * p.ldd + cc);
+    }
+    // S1 jobs of this wave (compile-time job list per wave, lane-constant entries): job A = y1 on patch pixel tile `wave`;
+    // job B = y1 on pixel tile 4 (wave 0) or y0 on output pixel tile wave - 1 (waves 1, 2)
     const int lty = lrow >> 4, ltx = lrow & 15;
+    const int eA = 32 * wave + lrow, rA = eA / CK_XC, cA = eA - rA * CK_XC;
+    const bool b_y0 = wave == 1 || wave == 2;
+    const int eB = b_y0 ? (2 * (wave - 1) + lty + 2) * CK_XC + ltx + 2 : 128 + lrow, rB = eB / CK_XC, cB = eB - rB * CK_XC;
+    // S2: hidden pixel of this lane
+    const int mm2 = wave * 32 + lrow, mc2 = mm2 < CK_NM ? mm2 : CK_NM - 1, r2 = mc2 / CK_MC, c2 = mc2 - r2 * CK_MC;
+
     const half_t* a2base = swb + lrow * WBS + 8 * lh;
 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the weight loads here, not inside the tile loop (bneck_fused.hip)
@@ -135,15 +161,15 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i)
             if (tid + 256 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
+        half_t* ob = p.dst + ((long long)(n * p.H + oy0) * p.W + ox0) * p.ldd;  // output tile origin (uniform)
         __syncthreads();  // (A) x patch visible (and, first iteration, the weights)
         if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
 
         // ---- S1: cv1 (1x1, CIN -> 2C).  Seven jobs of one MFMA tile (32 pixels x 32 channels) over four waves: y1 = channels
         //      C .. 2C-1 on the five pixel tiles of the patch (zero outside the MAP: the Bottleneck's convs pad y1, not x), y0 =
         //      channels 0 .. C-1 on the two pixel tiles of the tile's own pixels (only cv2 reads y0) --------------------------------
-        auto s1_job = [&](const bool is_y0, const int t) {
-            // is_y0: pixel = output pixel 32 t + lrow -> patch entry (row + 2, column + 2); else pixel = patch entry 32 t + lrow
-            const int e = is_y0 ? (2 * t + lty + 2) * CK_XC + ltx + 2 : 32 * t + lrow;
+        auto s1_job = [&](const bool is_y0, const int e, const int r, const int c, const int opix) {
+            // e = patch entry of this lane's pixel, (r, c) its patch coordinates; y0 jobs write output pixel opix
             const half_t* xb = sx + e * XS + 8 * lh;
             const half_t* ab = sw1 + ((is_y0 ? 0 : C) + lrow) * W1S + 8 * lh;
             f32x16 acc;
@@ -153,9 +179,8 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
             for (int ks = 0; ks < KS1; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(ab + 16 * ks), *reinterpret_cast<const half8*>(xb + 16 * ks),
                                                              acc, 0, 0, 0);
-            const int r = e / CK_XC, c = e - r * CK_XC;
             const unsigned keep = (is_y0 || ((unsigned)(oy0 - 2 + r) < (unsigned)p.H && (unsigned)(ox0 - 2 + c) < (unsigned)p.W)) ? 0xffffffffu : 0u;
-            half_t* d = is_y0 ? sy0 + (32 * t + lrow) * YS : sy1 + e * YS;
+            half_t* d = is_y0 ? sy0 + opix * YS : sy1 + e * YS;
             const float* bb_ = sb1 + (is_y0 ? 0 : C);
 #pragma unroll
             for (int g = 0; g < C / 8; ++g) {
@@ -169,16 +194,14 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
                 *reinterpret_cast<half4*>(d + 8 * g + 4 * lh) = o.h;
             }
         };
-        s1_job(false, wave);
-        if (wave == 0) s1_job(false, 4);
-        else if (wave < 3) s1_job(true, wave - 1);
+        s1_job(false, eA, rA, cA, 0);
+        if (wave == 0) s1_job(false, eB, rB, cB, 0);
+        else if (wave < 3) s1_job(true, eB, rB, cB, 32 * (wave - 1) + lrow);
         __syncthreads();  // (B) y1 patch + y0 tile complete
 
         // ---- S2: m.cv1 3x3 (C -> CH) on the 6 x 18 hidden patch: MFMA pixel tile `wave` ------------------------------------------
         {
-            const int mm = wave * 32 + lrow;
-            const int mc = mm < CK_NM ? mm : CK_NM - 1;
-            const int r = mc / CK_MC, c = mc - r * CK_MC;
+            const int mm = mm2, r = r2, c = c2;
             const half_t* yb = sy1 + (r * CK_XC + c) * YS + 8 * lh;
             f32x16 acc;
 #pragma unroll
@@ -265,15 +288,10 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
         }
         __syncthreads();  // (E) output tile complete
 
-        constexpr int CPRW = C2 / 8;
 #pragma unroll
-        for (int id = tid; id < CK_NPX * CPRW; id += 256) {
-            const int pr = id / CPRW, cc = (id % CPRW) * 8;
-            const int oy = oy0 + pr / CK_TW, ox = ox0 + pr % CK_TW;
-            if (oy < p.H && ox < p.W)
-                *reinterpret_cast<half8*>(p.dst + ((size_t)(n * p.H + oy) * p.W + ox) * p.ldd + cc) =
-                    *reinterpret_cast<const half8*>(sout + pr * OS + cc);
-        }
+        for (int j = 0; j < NST; ++j)
+            if (oy0 + st_y[j] < p.H && ox0 + st_x[j] < p.W)
+                *reinterpret_cast<half8*>(ob + st_rel[j]) = *reinterpret_cast<const half8*>(sout + st_off[j]);
         __syncthreads();  // (F) output tile read: the next iteration overwrites it with the next x patch
     }
 }

@@ -708,20 +708,20 @@ def test_engine_batch_independence_and_determinism():
 
 @pytest.mark.parametrize("scale", ["n", "s"])
 def test_engine_stem_fusion_is_bit_identical(scale):
-    """The OP_STEM / OP_BNECK / OP_DWPW plan (fused launches, merged C3k branch convs) returns exactly what the plan of plain
-    convs returns."""
+    """The OP_STEM / OP_BNECK / OP_C3K2 / OP_DWPW plan (fused launches, merged C3k branch convs) returns exactly what the plan of
+    plain convs returns."""
     m = R.Model("yolo11", scale, 80, "detect")
     P = R.synth_params(m, 0)
     cfg = stock_cfg("yolo11", scale)
     # autotune off: the tuner may pick kernels with different (equally valid) summation orders per plan
     fused = YoloEngine(cfg, P, fuse_stem=True, fuse_bneck=True, fuse_dwpw=True, autotune=False)
-    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False, fuse_tail=False, autotune=False)
     x = torch.rand(2, 3, 160, 96, generator=torch.Generator().manual_seed(3)).half().to(DEV)
     pf, _ = fused.plan_for(2, 160, 96, torch.float16, torch.float16)
     pp, _ = plain.plan_for(2, 160, 96, torch.float16, torch.float16)
     assert pf.ops[0]["kind"] == L.OP_STEM and pp.ops[0]["kind"] == L.OP_CONV_FIRST
-    assert (scale != "s") or any(o["kind"] == L.OP_BNECK for o in pf.ops)
-    assert not any(o["kind"] == L.OP_BNECK for o in pp.ops)
+    assert any(o["kind"] == L.OP_C3K2 for o in pf.ops) and ((scale != "n") or any(o["kind"] == L.OP_BNECK for o in pf.ops))
+    assert not any(o["kind"] in (L.OP_BNECK, L.OP_C3K2) for o in pp.ops)
     yf, rf = fused(x)
     yp, rp = plain(x)
     assert torch.equal(yf, yp)

@@ -2,7 +2,8 @@
 # HBM traffic of one bench step per kernel family: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes
 # (MI355X_MICROARCH.md "HBM": FETCH_SIZE reports exactly half of a wide coalesced read stream on gfx950 -> doubled;
 # WRITE_SIZE is exact; both in KiB).  Writes gpurun_out/traffic.json; copy it to profiles/ to have bench.py report it.
-# usage: tools/pmc_bench_traffic.sh <conv launches per forward>   ("conv_mfma_kernel" below = the whole conv family)
+# usage: tools/pmc_bench_traffic.sh <family launches per forward = roofline.launches_per_step>   ("conv_mfma_kernel" below = the whole
+# dense-conv family incl. the fused conv kernels)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -17,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{R}/gpurun_out/pmc_bench_{c}/*/*counter_collection.csv")[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel")  # kernels behind the plan's OP_CONV ops
+    CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")  # kernels behind the plan's OP_CONV ops
     conv = [r for r in rows if any(k in r["Kernel_Name"] for k in CONV)]
     last = conv[-NCONV:]  # the last forward (bench's final profile pass)
     t0 = int(last[0]["Start_Timestamp"])

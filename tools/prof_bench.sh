@@ -3,6 +3,7 @@
 # usage: tools/prof_bench.sh <tag> [steps=20]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-x}; STEPS=${2:-20}
+mkdir -p $R/gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_$TAG/bench_under_rocprof.json 2> $R/gpurun_out/prof_$TAG/bench.err
 echo "rocprof rc=$?"
@@ -18,4 +19,4 @@ tail -1 $R/gpurun_out/prof_$TAG/kernel_summary_serial_passes.txt
 python3 -c "
 import json
 d=json.loads(open('$R/gpurun_out/prof_$TAG/bench_under_rocprof.json').read().strip().splitlines()[-1])
-r=d['roofline']; print('bench (under rocprof): ms/step', d['ms_per_step'], 'conv avg launch us', r['avg_launch_ms']*1e3, 'conv ms/step', r['conv_ms_per_step'], 'achieved', r['achieved'], 'frac', r['frac'])"
+r=d['roofline']; print('bench (under rocprof): ms/step', d['ms_per_step'], 'conv avg launch us', r['avg_launch_ms']*1e3, 'family ms/step', r['family_ms_per_step'], 'achieved', r['achieved'], 'frac', r['frac'])"
