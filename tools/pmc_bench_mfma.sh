@@ -21,9 +21,6 @@ for r in rows:
 ds = sorted(disp.values(), key=lambda d: d["t"])
 conv = [d for d in ds if any(k in d["name"] for k in CONV)]
 t0 = conv[-NCONV]["t"]  # the last forward (bench's final serial profile pass)
-first = [d for d in ds if d["t"] < t0 and ("stem_fused" in d["name"] or "conv_first" in d["name"])]
-if first:
-    t0 = first[-1]["t"]  # the forward starts with the image conv
 fam = {}
 for d in ds:
     if d["t"] < t0:
