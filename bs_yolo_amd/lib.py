@@ -23,7 +23,7 @@ SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_create_arena", "bsy_engine_arena_bytes", "bsy_plan_set_tuning", "bsy_plan_destroy",
     "bsy_plan_run", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_check_guards", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_conv2d", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_c3k2_fused", "bsy_c3k2_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
     "bsy_sppf_pool", "bsy_attention", "bsy_detect_decode", "bsy_nms_workspace_bytes", "bsy_nms", "bsy_scale_boxes",
-    "bsy_letterbox", "bsy_process_mask", "bsy_val_match", "bsy_slice_tiles", "bsy_sahi_merge_workspace_bytes",
+    "bsy_letterbox", "bsy_process_mask", "bsy_process_mask_native", "bsy_scale_masks", "bsy_val_match", "bsy_slice_tiles", "bsy_sahi_merge_workspace_bytes",
     "bsy_sahi_merge", "bsy_ap_workspace_bytes", "bsy_ap_per_class", "bsy_last_error", "bsy_version",
 ]
 
@@ -123,6 +123,8 @@ def _load() -> C.CDLL:
                             C.c_size_t, vp]
     lib.bsy_scale_boxes.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.bsy_process_mask.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.bsy_process_mask_native.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.bsy_scale_masks.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.bsy_letterbox.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, vp]
     lib.bsy_slice_tiles.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.bsy_ap_workspace_bytes.argtypes = [i32, i32]

@@ -176,6 +176,29 @@ def install_masks(ops_module):
     process_mask._bsy = True
     process_mask._bsy_orig = orig
     ops_module.process_mask = process_mask
+    # the retina_masks path (segment/predict.py:48-50): process_mask_native and scale_masks (utils/ops.py:696-737)
+    if hasattr(ops_module, "process_mask_native") and not getattr(ops_module.process_mask_native, "_bsy", False):
+        orig_n = ops_module.process_mask_native
+
+        def process_mask_native(protos, masks_in, bboxes, shape):
+            if not (isinstance(protos, torch.Tensor) and protos.is_cuda):
+                return orig_n(protos, masks_in, bboxes, shape)
+            return _masks.process_mask_native(protos, masks_in, bboxes, shape)
+
+        process_mask_native._bsy = True
+        process_mask_native._bsy_orig = orig_n
+        ops_module.process_mask_native = process_mask_native
+    if hasattr(ops_module, "scale_masks") and not getattr(ops_module.scale_masks, "_bsy", False):
+        orig_s = ops_module.scale_masks
+
+        def scale_masks(masks, shape, padding=True):
+            if not (isinstance(masks, torch.Tensor) and masks.is_cuda and masks.dim() == 4 and masks.dtype in (torch.float16, torch.float32)):
+                return orig_s(masks, shape, padding)
+            return _masks.scale_masks(masks, shape, padding)
+
+        scale_masks._bsy = True
+        scale_masks._bsy_orig = orig_s
+        ops_module.scale_masks = scale_masks
     return process_mask
 
 

@@ -293,6 +293,17 @@ int bsy_process_mask(const void* protos, int proto_dtype, int nm, int mh, int mw
                      const float* boxes, int ldb, int n, int ih, int iw, int upsample, float* lowres, void* out,
                      int out_dtype, bsy_stream stream);
 
+/* process_mask_native (utils/ops.py:696-709; segment/predict.py:48-50 with retina_masks) for ONE image: the (n, mh, mw) masks
+ * coef @ protos, their window [top:bottom, left:right] (scale_masks' letterbox-padding cut, computed by the HOST with the
+ * reference's Python arithmetic) resized bilinearly (align_corners=False) to (oh, ow) = the ORIGINAL image, cropped to `boxes`
+ * (xyxy in original-image pixels), thresholded at 0 -> out (n, oh, ow) u8 / f32.  lowres = n*mh*mw f32 scratch. */
+int bsy_process_mask_native(const void* protos, int proto_dtype, int nm, int mh, int mw, const float* coef, int ldc,
+                            const float* boxes, int ldb, int n, int top, int left, int bottom, int right, int oh, int ow,
+                            float* lowres, void* out, int out_dtype, bsy_stream stream);
+/* scale_masks (utils/ops.py:712-737): masks (n, mh, mw) f16 / f32 -> (n, oh, ow) of the same dtype, window as above. */
+int bsy_scale_masks(const void* masks, int dtype, int n, int mh, int mw, int top, int left, int bottom, int right, int oh, int ow,
+                    void* out, bsy_stream stream);
+
 /* Validator matching (engine/validator.py:222-258 match_predictions on utils/metrics.py:52-70 box_iou, as called by
  * DetectionValidator._process_batch, models/yolo/detect/val.py:209-228), whole batch at once.
  * det (B, max_det, row >= 6) f32 rows [x1 y1 x2 y2 conf cls ...] + counts (B): the layout bsy_nms writes;

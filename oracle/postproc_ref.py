@@ -162,3 +162,25 @@ def process_mask(protos, masks_in, bboxes, shape, upsample=False):  # utils/ops.
     if upsample:
         masks = F.interpolate(masks[None], shape, mode="bilinear", align_corners=False)[0]
     return masks.gt_(0.0)
+
+
+def scale_masks(masks, shape, padding=True):  # utils/ops.py:712-737
+    import torch.nn.functional as F
+    mh, mw = masks.shape[2:]
+    gain = min(mh / shape[0], mw / shape[1])
+    pad = [mw - shape[1] * gain, mh - shape[0] * gain]
+    if padding:
+        pad[0] /= 2
+        pad[1] /= 2
+    top, left = (int(pad[1]), int(pad[0])) if padding else (0, 0)
+    bottom, right = (int(mh - pad[1]), int(mw - pad[0]))
+    masks = masks[..., top:bottom, left:right]
+    return F.interpolate(masks, shape, mode="bilinear", align_corners=False)
+
+
+def process_mask_native(protos, masks_in, bboxes, shape):  # utils/ops.py:696-709
+    c, mh, mw = protos.shape
+    masks = (masks_in @ protos.float().view(c, -1)).view(-1, mh, mw)
+    masks = scale_masks(masks[None], shape)[0]
+    masks = crop_mask(masks, bboxes)
+    return masks.gt_(0.0)

@@ -319,6 +319,32 @@ def val_match_fixtures():
     print("wrote val_match", len(cases), "cases")
 
 
+def masks_native_fixtures():
+    """Known answers of the retina_masks path: the reference's own process_mask_native and scale_masks (utils/ops.py:696-737)
+    on synthetic prototypes / coefficients / boxes; original-image shapes with letterbox padding on either axis, none, and
+    a down-scaling case."""
+    out, cases = {}, []
+    g = torch.Generator().manual_seed(91)
+    for ci, (nm, mh, mw, n, shape) in enumerate([(32, 40, 40, 6, (120, 160)), (32, 40, 40, 5, (160, 90)), (16, 24, 32, 3, (96, 128)),
+                                                 (8, 80, 80, 4, (200, 320)), (8, 20, 20, 2, (15, 17)), (32, 40, 40, 0, (64, 64))]):
+        protos = torch.randn(nm, mh, mw, generator=g)
+        coef = torch.randn(n, nm, generator=g) * 0.5
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([shape[1] * 0.6, shape[0] * 0.6])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([shape[1] * 0.5, shape[0] * 0.5]) + 3.0
+        boxes = torch.cat([xy, xy + wh], 1)
+        with torch.inference_mode():
+            native = rops.process_mask_native(protos, coef, boxes, shape) if n else torch.zeros(0, *shape)
+            scaled = rops.scale_masks(protos[None, :2], shape)  # two channels: the arithmetic is per channel
+            scaled_np = rops.scale_masks(protos[None, :2], shape, padding=False)
+        out[f"c{ci}.protos"], out[f"c{ci}.coef"], out[f"c{ci}.boxes"] = protos.numpy(), coef.numpy(), boxes.numpy()
+        out[f"c{ci}.native"] = native.numpy().astype(np.uint8)
+        out[f"c{ci}.scaled"], out[f"c{ci}.scaled_nopad"] = scaled.numpy(), scaled_np.numpy()
+        cases.append({"ci": ci, "shape": list(shape)})
+    out["cases"] = json.dumps(cases)
+    np.savez_compressed(HERE / "masks_native.npz", **out)
+    print("wrote masks_native", len(cases), "cases")
+
+
 def synth_pred(b, nc, a, nm, seed, peaky, dtype=torch.float32):
     """(B, 4+nc+nm, A) prediction tensor in Detect's output format with duplicated / overlapping boxes."""
     g = torch.Generator().manual_seed(seed)
@@ -456,6 +482,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "val":  # only the validator-matching vectors
         val_match_fixtures()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "masks_native":  # only the retina-masks vectors (round 2)
+        masks_native_fixtures()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ap":  # only the ap_per_class vectors
         ap_fixtures()

@@ -222,6 +222,35 @@ def test_install_masks_dispatch():
     assert len(calls) == 1
 
 
+def test_install_masks_covers_the_retina_masks_functions():
+    """install_masks also swaps process_mask_native and scale_masks (utils/ops.py:696-737; segment/predict.py:48-50 with
+    retina_masks) when the module has them: GPU tensors to the device kernels, everything else to the originals."""
+    calls = []
+
+    def ref_native(protos, masks_in, bboxes, shape):
+        calls.append("native")
+        return PP.process_mask_native(protos.float().cpu(), masks_in.float().cpu(), bboxes.float().cpu(), shape)
+
+    def ref_scale(masks, shape, padding=True):
+        calls.append("scale")
+        return PP.scale_masks(masks.float().cpu(), shape, padding)
+
+    ops = types.SimpleNamespace(process_mask=lambda *a, **k: None, process_mask_native=ref_native, scale_masks=ref_scale)
+    plugin.install_masks(ops)
+    g = torch.Generator().manual_seed(2)
+    protos, mc = torch.randn(32, 40, 40, generator=g), torch.randn(4, 32, generator=g)
+    xy = torch.rand(4, 2, generator=g) * 60
+    boxes = torch.cat([xy, xy + torch.rand(4, 2, generator=g) * 50 + 4], 1)
+    want = PP.process_mask_native(protos, mc, boxes, (120, 160))
+    got = ops.process_mask_native(protos.to(DEV), mc.to(DEV), boxes.to(DEV), (120, 160))
+    assert not calls and got.is_cuda and torch.equal(got.cpu().bool(), want.bool())
+    s = ops.scale_masks(protos[None].to(DEV), (120, 160))
+    assert not calls and torch.allclose(s.cpu(), PP.scale_masks(protos[None], (120, 160)), atol=1e-5, rtol=0)
+    ops.process_mask_native(protos, mc, boxes, (120, 160))
+    ops.scale_masks(protos[None], (120, 160), padding=False)
+    assert calls == ["native", "scale"]
+
+
 def test_install_val_metrics_and_ap_per_class():
     iouv = torch.linspace(0.5, 0.95, 10)
 

@@ -1302,3 +1302,36 @@ def test_engine_fp16_path_vs_fp32_mode_at_the_benchmark_size():
     assert abs(n16 - n32) <= 0.02 * n32 and n32 > 5000, (n16, n32)
     e16.close()
     e32.close()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# retina_masks path: process_mask_native + scale_masks (utils/ops.py:696-737) on the device
+# ------------------------------------------------------------------------------------------------------------
+def test_process_mask_native_and_scale_masks_match_reference_golden():
+    """bs_yolo_amd.masks.process_mask_native / scale_masks (csrc/masks.hip) against the REFERENCE's own outputs
+    (tests/golden/masks_native.npz): the 0/1 masks bit-exact up to pixels whose pre-threshold value is within float rounding
+    of zero (none in the fixtures), the resized maps within 1e-5; fp16 prototypes against the oracle on the same values."""
+    from bs_yolo_amd import masks as HM
+    z = np.load(GOLDEN / "masks_native.npz")
+    for case in json.loads(str(z["cases"])):
+        ci, shape = case["ci"], tuple(case["shape"])
+        protos, coef, boxes = (torch.from_numpy(z[f"c{ci}.{k}"]) for k in ("protos", "coef", "boxes"))
+        got = HM.process_mask_native(protos.to(DEV), coef.to(DEV), boxes.to(DEV), shape)
+        assert tuple(got.shape) == (len(coef),) + shape and got.dtype == torch.float32
+        want = z[f"c{ci}.native"]
+        diff = got.cpu().numpy().astype(np.uint8) != want
+        if diff.any():  # only where the reference's own pre-threshold value is ~0 (fp32 summation order of the nm-term dot)
+            pre = PP.scale_masks((coef @ protos.view(protos.shape[0], -1)).view(-1, *protos.shape[1:])[None], shape)[0].numpy()
+            assert np.abs(pre[diff]).max() < 1e-5, (ci, int(diff.sum()), np.abs(pre[diff]).max())
+        for pad, key in ((True, "scaled"), (False, "scaled_nopad")):
+            s = HM.scale_masks(protos[None, :2].to(DEV), shape, padding=pad)
+            np.testing.assert_allclose(s.cpu().numpy(), z[f"c{ci}.{key}"], rtol=0, atol=1e-5, err_msg=f"case {ci} {key}")
+        if len(coef):  # fp16 prototypes (what a half=True Segment head returns)
+            ph = protos.half()
+            g16 = HM.process_mask_native(ph.to(DEV), coef.to(DEV), boxes.to(DEV), shape, out_dtype=torch.uint8)
+            w16 = PP.process_mask_native(ph.float(), coef, boxes, shape).numpy().astype(np.uint8)
+            d16 = g16.cpu().numpy() != w16
+            assert d16.mean() < 1e-4, (ci, d16.mean())
+            s16 = HM.scale_masks(ph[None, :2].to(DEV), shape)
+            assert s16.dtype == torch.float16
+            np.testing.assert_allclose(s16.float().cpu().numpy(), PP.scale_masks(ph[None, :2].float(), shape).numpy(), rtol=0, atol=2e-3)

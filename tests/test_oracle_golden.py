@@ -253,3 +253,19 @@ def test_ap_per_class_golden():
             want = z[f"c{ci}.out.{k}"]
             assert np.asarray(g).shape == want.shape, (ci, k, np.asarray(g).shape, want.shape)
             np.testing.assert_allclose(np.asarray(g, dtype=np.float64), want.astype(np.float64), rtol=0, atol=1e-12, err_msg=f"case {ci} {k}")
+
+
+def test_masks_native_oracle_matches_reference_golden():
+    """oracle.postproc_ref.process_mask_native / scale_masks against the reference's own outputs (utils/ops.py:696-737;
+    fixture written by tests/golden/make_fixtures.py masks_native)."""
+    import json
+    from oracle import postproc_ref as PP
+    z = np.load(GOLDEN / "masks_native.npz")
+    for case in json.loads(str(z["cases"])):
+        ci, shape = case["ci"], tuple(case["shape"])
+        protos, coef, boxes = (torch.from_numpy(z[f"c{ci}.{k}"]) for k in ("protos", "coef", "boxes"))
+        if len(coef):
+            got = PP.process_mask_native(protos, coef, boxes, shape)
+            assert np.array_equal(got.numpy().astype(np.uint8), z[f"c{ci}.native"])
+        np.testing.assert_allclose(PP.scale_masks(protos[None, :2], shape).numpy(), z[f"c{ci}.scaled"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(PP.scale_masks(protos[None, :2], shape, padding=False).numpy(), z[f"c{ci}.scaled_nopad"], rtol=0, atol=1e-6)
