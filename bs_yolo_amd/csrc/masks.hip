@@ -10,7 +10,7 @@
 // lowres reads nm*mh*mw prototypes once per 8 masks, upsample writes n*ih*iw outputs.
 #include "common.h"
 
-template <typename T>
+template <typename T, bool CROP>
 __global__ __launch_bounds__(256) void mask_lowres_kernel(const T* __restrict__ protos, int nm, int mh, int mw,
                                                           const float* __restrict__ coef, int ldc,
                                                           const float* __restrict__ boxes, int ldb, int n, float wr,
@@ -31,13 +31,15 @@ __global__ __launch_bounds__(256) void mask_lowres_kernel(const T* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (n0 + j >= n) break;
-        bool in = true;
-        if (boxes) {  // process_mask crops at prototype resolution; process_mask_native (boxes == nullptr here) after the resize
+        // process_mask crops at prototype resolution (CROP); process_mask_native crops after the resize (boxes unused here)
+        float v = acc[j];
+        if (CROP) {
             const float* b = boxes + (size_t)(n0 + j) * ldb;
             const float x1 = b[0] * wr, y1 = b[1] * hr, x2 = b[2] * wr, y2 = b[3] * hr;  // ops.py:684-688
-            in = x >= x1 && x < x2 && y >= y1 && y < y2;                                 // ops.py:660
+            const bool inside = x >= x1 && x < x2 && y >= y1 && y < y2;                  // ops.py:660
+            v = inside ? v : 0.f;
         }
-        low[((size_t)(n0 + j) * mh * mw) + p] = in ? acc[j] : 0.f;
+        low[((size_t)(n0 + j) * mh * mw) + p] = v;
     }
 }
 
@@ -126,9 +128,9 @@ extern "C" int bsy_process_mask_native(const void* protos, int proto_dtype, int 
     if (out_dtype != BSY_U8 && out_dtype != BSY_F32) BSY_FAIL(BSY_ERR_ARG, "process_mask_native: output dtype must be u8 or f32");
     dim3 g1((mh * mw + 255) / 256, (n + 7) / 8);
     if (proto_dtype == BSY_F16)
-        hipLaunchKernelGGL(mask_lowres_kernel<half_t>, g1, dim3(256), 0, s, (const half_t*)protos, nm, mh, mw, coef, ldc, nullptr, 0, n, 1.f, 1.f, lowres);
+        hipLaunchKernelGGL((mask_lowres_kernel<half_t, false>), g1, dim3(256), 0, s, (const half_t*)protos, nm, mh, mw, coef, ldc, nullptr, 0, n, 1.f, 1.f, lowres);
     else if (proto_dtype == BSY_F32)
-        hipLaunchKernelGGL(mask_lowres_kernel<float>, g1, dim3(256), 0, s, (const float*)protos, nm, mh, mw, coef, ldc, nullptr, 0, n, 1.f, 1.f, lowres);
+        hipLaunchKernelGGL((mask_lowres_kernel<float, false>), g1, dim3(256), 0, s, (const float*)protos, nm, mh, mw, coef, ldc, nullptr, 0, n, 1.f, 1.f, lowres);
     else
         BSY_FAIL(BSY_ERR_ARG, "process_mask_native: proto dtype %d unsupported", proto_dtype);
     dim3 g2((ow + 255) / 256, oh, n);
@@ -153,10 +155,10 @@ extern "C" int bsy_process_mask(const void* protos, int proto_dtype, int nm, int
     const float wr = (float)mw / (float)iw, hr = (float)mh / (float)ih;
     dim3 g1((mh * mw + 255) / 256, (n + 7) / 8);
     if (proto_dtype == BSY_F16)
-        hipLaunchKernelGGL(mask_lowres_kernel<half_t>, g1, dim3(256), 0, s, (const half_t*)protos, nm, mh, mw, coef, ldc,
+        hipLaunchKernelGGL((mask_lowres_kernel<half_t, true>), g1, dim3(256), 0, s, (const half_t*)protos, nm, mh, mw, coef, ldc,
                            boxes, ldb, n, wr, hr, lowres);
     else if (proto_dtype == BSY_F32)
-        hipLaunchKernelGGL(mask_lowres_kernel<float>, g1, dim3(256), 0, s, (const float*)protos, nm, mh, mw, coef, ldc,
+        hipLaunchKernelGGL((mask_lowres_kernel<float, true>), g1, dim3(256), 0, s, (const float*)protos, nm, mh, mw, coef, ldc,
                            boxes, ldb, n, wr, hr, lowres);
     else
         BSY_FAIL(BSY_ERR_ARG, "process_mask: proto dtype %d unsupported", proto_dtype);
