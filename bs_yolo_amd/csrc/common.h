@@ -63,7 +63,7 @@ struct ConvArgs {
     int raw_f32, rawC;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
-#define BSY_CONV_MAX_CFG 32
+#define BSY_CONV_MAX_CFG 64
 int conv_candidates(const ConvArgs& a, int* out, int max_out);  // valid configuration ids, heuristic best first
 bool conv_cfg_valid(const ConvArgs& a, int cfg);
 

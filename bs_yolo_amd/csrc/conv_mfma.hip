@@ -905,13 +905,19 @@ static int launch_persist(const ConvK& k, hipStream_t s) {
 // step left 4-8 MFMAs between barriers and a two-step prefetch distance far below the L2 latency.)
 // WM = wave rows: 2 -> 8 x 16 output tile, 4 waves (the shipped form).  4 -> 16 x 16 tile, 8 waves: measured 8-25 % SLOWER
 // on every YOLO11s layer (r01 notes in DESIGN.md) and therefore not instantiated.
-template <int NT, int STAGES, int WM>
+// TW_ = tile width: 16 (8 x 16 tile: 128 pixels = the 128 pixel slots of the four MFMA pixel tiles) or 20 (6 x 20 tile: 120
+// pixels in the 128 slots, slot i = pixel (i / 20, i % 20)) -- a 20 x 20 map is 4 tiles of 6 x 20 instead of 6 tiles of
+// 8 x 16 (48 % of whose slots lie outside the map), a 40 x 40 map 14 instead of 15.
+template <int NT, int STAGES, int WM, int TW_ = CP_TW>
 __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) {
-    constexpr int CP_TH = 4 * WM, NW = 2 * WM, NTHR = 64 * NW;
-    constexpr int CP_NPX = (CP_TH + 2) * CP_PW;             // 180 / 324 patch entries
+    constexpr int CP_TH = TW_ == 16 ? 4 * WM : 6, NW = 2 * WM, NTHR = 64 * NW;
+    constexpr int PW_ = TW_ + 2;                            // patch row length (entries)
+    constexpr int NVALID = CP_TH * TW_;                     // pixels of the tile (<= TM slots)
+    static_assert(TW_ == 16 || (TW_ == 20 && WM == 2), "tile shapes: 8 x 16, 16 x 16 (8 waves), 6 x 20");
+    constexpr int CP_NPX = (CP_TH + 2) * PW_;               // 180 / 324 / 176 patch entries
     constexpr int PIW = (CP_NPX + 16 * NW - 1) / (16 * NW);  // patch DMA wave-instructions per wave per chunk (16 entries each)
     constexpr int CP_NPI = PIW * NW;
-    constexpr int TN = 64 * NT, TM = CP_TH * CP_TW;
+    constexpr int TN = 64 * NT, TM = 64 * WM;
     constexpr int PBUF = CP_NPI * 16 * 32;  // halves per patch buffer
     constexpr int WTAP = TN * 32;           // halves per tap of a weight stage
     constexpr int WST = 3 * WTAP;           // halves per weight stage (3 taps)
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
     t /= p.tiles_x;
     const int ty = t % p.tiles_y;
     const int n = t / p.tiles_y;
-    const int oy0 = ty * CP_TH, ox0 = tx * CP_TW, n0 = tn_idx * TN;
+    const int oy0 = ty * CP_TH, ox0 = tx * TW_, n0 = tn_idx * TN;
 
     const bsy_rsrc_t rs0 = make_rsrc(p.src0, p.span0), rsw = make_rsrc(p.wgt, p.wspan);
     // patch DMA coordinates: instruction i of this wave fills entries 16 (wave + 4 i) .. +15; lane -> (entry, slot)
@@ -942,7 +948,7 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
 #pragma unroll
     for (int i = 0; i < PIW; ++i) {
         const int q = 16 * (wave + NW * i) + (lane >> 2);
-        const int pr = q / CP_PW, pc = q - pr * CP_PW;
+        const int pr = q / PW_, pc = q - pr * PW_;
         const int y = oy0 - 1 + pr, x = ox0 - 1 + pc;
         const int chunk = (lane & 3) ^ ((q >> 2) & 3);
         poff[i] = (q < CP_NPX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
@@ -989,7 +995,10 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
     // lane pixel of MFMA tile b: tile row wm*4 + 2b + (lrow >> 4), column lrow & 15 -> patch entry of tap (0, 0)
     int lq[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) lq[b] = (wm * 4 + 2 * b + (lrow >> 4)) * CP_PW + (lrow & 15);
+    for (int b = 0; b < 2; ++b) {
+        const int slot = (wm * 2 + b) * 32 + lrow;  // pixel slot -> pixel (slot / TW, slot % TW); slots past the tile read entry 0
+        lq[b] = slot < NVALID ? (slot / TW_) * PW_ + slot % TW_ : 0;
+    }
     int arow[NT], asw[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
@@ -1021,7 +1030,7 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
         const half_t* sWk = sW + (k % STAGES) * WST;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int toff = kh * CP_PW + kw;
+            const int toff = kh * PW_ + kw;
             half8 bfr[2][2], afr[2][NT];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -1076,8 +1085,8 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
     for (int i = 0; i < ITER; ++i) {
         const int id = tid + NTHR * i;
         const int prow = id / CPRW, cc = (id % CPRW) * 8;
-        const int oy = oy0 + (prow >> 4), ox = ox0 + (prow & 15), c = n0 + cc;
-        if (oy >= p.H || ox >= p.W || c >= p.Cout) continue;
+        const int oy = oy0 + prow / TW_, ox = ox0 + prow % TW_, c = n0 + cc;
+        if (prow >= NVALID || oy >= p.H || ox >= p.W || c >= p.Cout) continue;
         const size_t pix = (size_t)(n * p.H + oy) * p.W + ox;
         half8 v = *reinterpret_cast<const half8*>(smem + prow * LDT + cc);
         if (p.res) {
@@ -1089,15 +1098,15 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
     }
 }
 
-template <int NT, int STAGES, int WM>
+template <int NT, int STAGES, int WM, int TW_ = CP_TW>
 static int launch_patch(const ConvK& k, hipStream_t s) {
     ConvK p = k;
     p.ntn = ceil_div(k.Cout, 64 * NT);
-    p.tiles_x = ceil_div(k.W, CP_TW);
-    p.tiles_y = ceil_div(k.H, 4 * WM);
+    p.tiles_x = ceil_div(k.W, TW_);
+    p.tiles_y = ceil_div(k.H, TW_ == 16 ? 4 * WM : 6);
     const long long nblk = (long long)k.B * p.tiles_x * p.tiles_y * p.ntn;
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: tile count %lld out of range", nblk);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<NT, STAGES, WM>), dim3((unsigned)nblk), dim3(128 * WM), 0, s, p);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<NT, STAGES, WM, TW_>), dim3((unsigned)nblk), dim3(128 * WM), 0, s, p);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
@@ -1363,14 +1372,18 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 //            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128);
 //            8 = 128 x 128, 9 = 128 x 64 persistent 1x1 kernel (4 compute + 4 store waves, tiles walked per workgroup);
 //            10 = 8x16 px x 128 couts (2-stage weight ring), 11 = 8x16 px x 64 couts (variant 1: 3 stages, 2: 2 stages):
-//            patch-based 3x3 stride-1 kernel
+//            patch-based 3x3 stride-1 kernel; 12 / 13 = the same with 6x20-pixel tiles (maps whose width is a multiple of 20)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
-    if (cfg < 0 || tile > 11 || var > 3) return false;
+    if (cfg < 0 || tile > 13 || var > 3) return false;
     if (a.epi && tile >= 8) return false;           // fused decoder: implicit-GEMM kernel only
     if (a.epi == 3 && tile != 1) return false;      // DFL needs all 64 box couts in one wave: the 256 x 64 tile (4 x 1 waves, NT 2)
+    if (tile >= 12) {  // 6x20-pixel patch tiles
+        ConvArgs b = a;
+        return conv_cfg_valid(b, ((tile - 2) << 4) | var);
+    }
     if (tile >= 10) {  // patch-based 3x3 stride-1 kernel (TN 128 / 64)
         return (var == 1 || (var == 2 && tile == 11)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
                !(a.Cout & 7) && !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 &&
@@ -1408,7 +1421,9 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
     }
     // heuristic first (what an un-tuned plan runs: the r01 measurements' usual winners), then the exhaustive
     // (tile x variant) sweep the autotuner times
-    if (!a.epi && a.ksize == 3 && a.stride == 1 && a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) add(11, 2);  // patch kernel
+    // 6x20 tiles where they need fewer tiles than 8x16 ones (20 x 20 maps: 4 instead of 6 per image)
+    const bool t20 = ceil_div(a.W, 20) * ceil_div(a.H, 6) < ceil_div(a.W, 16) * ceil_div(a.H, 8);
+    if (!a.epi && a.ksize == 3 && a.stride == 1 && a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) add(t20 ? 13 : 11, 2);  // patch kernel
     if (!a.epi && !(a.Cout & 255) && aligned64 && M >= 16384) add(7, 3);  // 256 x 256, 64-deep K-steps
     add(tile, aligned64 ? 3 : 1);
     static const int tn[10] = {32, 64, 128, 64, 128, 128, 64, 256, 128, 64};
@@ -1420,7 +1435,10 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (t >= 8 && (M < 65536 || getenv("BSY_NO_PERSIST"))) continue;                      // persistent tiles need several tiles per workgroup
         for (int v = 1; v <= 3; ++v) add(t, v);
     }
-    if (a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) { add(10, 1); add(11, 1); add(11, 2); }  // 3x3 s1 patch kernel (small maps waste tiles)
+    if (a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) {  // 3x3 s1 patch kernel
+        add(10, 1); add(11, 1); add(11, 2);
+        if (t20) { add(12, 1); add(13, 1); add(13, 2); }
+    }
     return n;
 }
 
@@ -1489,6 +1507,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     } while (0)
 #define BSY_TILE(KS_)                                                                     \
     do {                                                                                  \
+        if (tile == 12) return launch_patch<2, 2, 2, 20>(k, s);                           \
+        if (tile == 13 && var == 1) return launch_patch<1, 3, 2, 20>(k, s);               \
+        if (tile == 13) return launch_patch<1, 2, 2, 20>(k, s);                           \
         if (tile == 10) return launch_patch<2, 2, 2>(k, s);                               \
         if (tile == 11 && var == 1) return launch_patch<1, 3, 2>(k, s);                   \
         if (tile == 11) return launch_patch<1, 2, 2>(k, s);                               \

@@ -96,12 +96,18 @@ PATCH_CASES = [
     (2, 33, 31, 64, 40, 177, False),
     (2, 24, 40, 96, 64, 178, True),       # 2-stage weight ring, 3 chunks
     (1, 33, 47, 128, 136, 161, False),    # ragged everywhere, 2 cout tiles of 128
+    # 6 x 20-pixel tiles (tiles 12 / 13; 20 x 20 and 40 x 40 maps: fewer tiles than 8 x 16), exact and ragged extents
+    (3, 20, 20, 128, 128, 193, True),
+    (2, 20, 20, 64, 64, 209, False),
+    (2, 40, 40, 64, 128, 210, True),
+    (1, 13, 27, 32, 24, 210, False),      # ragged: last tile row has 1 of 6 rows, last tile column 7 of 20 pixels
+    (5, 6, 20, 96, 64, 209, False),       # exactly one tile per image
 ]
 
 
 @pytest.mark.parametrize("case", PATCH_CASES)
 def test_conv_patch_kernel_matches_oracle(case, monkeypatch):
-    """3x3 stride-1 patch kernel (conv_mfma.hip, tiles 10/11) against the fp32 reference and against the implicit-GEMM
+    """3x3 stride-1 patch kernel (conv_mfma.hip, tiles 10/11 = 8x16-pixel tiles, 12/13 = 6x20) against the fp32 reference and against the implicit-GEMM
     kernel (same operands, chunk-major instead of tap-major summation: equal to fp32 rounding, i.e. <= 1 fp16 ulp)."""
     B, H, W, cin, cout, cfg, use_res = case
     g = torch.Generator().manual_seed(cfg * 1000 + cin)
