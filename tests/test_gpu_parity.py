@@ -672,6 +672,40 @@ def test_engine_no_out_of_bounds_stores(fam, scale, nc, task, shapes, monkeypatc
         eng.close()
 
 
+@pytest.mark.parametrize("fam,scale,nc,task,shapes", [
+    ("yolo11", "n", 80, "detect", [(1, 32, 32), (3, 96, 224)]),
+    ("yolo11", "s", 80, "detect", [(2, 160, 32), (8, 320, 320)]),
+    ("yolo11", "m", 80, "segment", [(1, 64, 96)]),
+    ("yolov8", "s", 80, "detect", [(2, 64, 64)]),
+    ("bsyolo11", "s", 12, "detect", [(1, 96, 160)]),
+])
+def test_engine_no_harmful_reads_past_the_weight_blob(fam, scale, nc, task, shapes, monkeypatch):
+    """The weight blob followed by 1 MiB of poison (BSY_WEIGHT_GUARD: f16 NaNs) returns bit for bit what the plain engine
+    returns, tuned (every kernel configuration the autotuner tries runs on the poisoned blob) and un-tuned: no kernel uses
+    bytes it read past the packed weights (the guard bands only caught out-of-bounds STORES)."""
+    from bs_yolo_amd.plan import Plan
+    from bs_yolo_amd.weights import synth_state_dict
+    cfg = stock_cfg(fam, scale, nc, task)
+    sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=3)
+    monkeypatch.delenv("BSY_WEIGHT_GUARD", raising=False)
+    plain = YoloEngine(cfg, sd, autotune=False)
+    monkeypatch.setenv("BSY_WEIGHT_GUARD", str(1 << 20))
+    poisoned = YoloEngine(cfg, sd, autotune=False)
+    tuned = YoloEngine(cfg, sd, autotune=True)
+    for (B, H, W) in shapes:
+        x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV)
+        y0, a0 = plain(x)
+        y1, a1 = poisoned(x)
+        y2, _ = tuned(x)
+        assert torch.equal(y0, y1) and bool(torch.isfinite(y2.float()).all())
+        r0, r1 = (a0[0], a1[0]) if task == "segment" else (a0, a1)
+        assert all(torch.equal(p, q) for p, q in zip(r0, r1))
+        # the tuned plan may pick kernels with another (equally valid) summation order: close, and never NaN
+        assert float((y2.float() - y0.float()).abs().max()) < 0.05 * max(1.0, float(y0.float().abs().max()))
+    for e in (plain, poisoned, tuned):
+        e.close()
+
+
 @pytest.mark.parametrize("fam,scale,nc,shape", [("yolo11", "s", 80, (8, 640, 640)), ("bsyolo11", "n", 12, (2, 1024, 1024))])
 def test_engine_lanes_equal_serial_schedule(fam, scale, nc, shape, monkeypatch):
     """The product schedule (Detect branches on six side streams, running beside each other) returns bit for bit what the
