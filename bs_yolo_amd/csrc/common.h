@@ -245,6 +245,7 @@ struct DwArgs {
 };
 int launch_dwconv(const DwArgs& a, hipStream_t s);
 int launch_sppf_pool(half_t* buf, int ld, int B, int H, int W, int C, hipStream_t s);
+int launch_s2d(const void* img, int img_dtype, int B, int H, int W, half_t* dst, int ldd, hipStream_t s);
 
 struct AttnArgs {
     const half_t* qkv;

@@ -240,3 +240,46 @@ int launch_sppf_pool(half_t* buf, int ld, int B, int H, int W, int C, hipStream_
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Space-to-depth of the input image for YOLOv5u's 6x6 stride-2 pad-2 stem (cfg/models/v5/yolov5.yaml:16): BCHW f16 / f32
+// -> NHWC f16 (B, H/2, W/2, ld >= 16), channel (dy * 2 + dx) * 3 + c = image[c][2Y + dy][2X + dx], channels 12 .. 15 zero.
+// The stem then is an ordinary 3x3 stride-1 pad-1 conv over 16 channels (weights re-laid-out by weights.py "first_s2d").
+// HBM-bound: reads 3 H W elements, writes 8 H W bytes.  One thread per output pixel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void s2d_kernel(const T* __restrict__ img, int B, int H, int W, half_t* __restrict__ dst, int ldd) {
+    const int OW = W >> 1, OH = H >> 1;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * OH * OW) return;
+    const int X = (int)(idx % OW);
+    const long long t = idx / OW;
+    const int Y = (int)(t % OH), n = (int)(t / OH);
+    half8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)0.f; hi[j] = (half_t)0.f; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const half_t v = (half_t)(float)img[((size_t)(n * 3 + c) * H + 2 * Y + (q >> 1)) * W + 2 * X + (q & 1)];
+            const int k = q * 3 + c;
+            if (k < 8) lo[k] = v; else hi[k - 8] = v;
+        }
+    half_t* o = dst + (size_t)idx * ldd;
+    *reinterpret_cast<half8*>(o) = lo;
+    *reinterpret_cast<half8*>(o + 8) = hi;
+}
+
+int launch_s2d(const void* img, int img_dtype, int B, int H, int W, half_t* dst, int ldd, hipStream_t s) {
+    if (!img || !dst || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || ldd < 16 || (ldd & 7) || ((uintptr_t)dst & 15))
+        BSY_FAIL(BSY_ERR_ARG, "s2d: bad argument (even H, W; dst row stride >= 16, 16-byte aligned)");
+    const long long total = (long long)B * (H / 2) * (W / 2);
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    if (img_dtype == BSY_F16) hipLaunchKernelGGL(s2d_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)img, B, H, W, dst, ldd);
+    else if (img_dtype == BSY_F32) hipLaunchKernelGGL(s2d_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)img, B, H, W, dst, ldd);
+    else BSY_FAIL(BSY_ERR_ARG, "s2d: image dtype %d unsupported", img_dtype);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}

@@ -391,6 +391,12 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok) return BSY_ERR_ARG;
             return launch_bneck_fused(a, s);
         }
+        case BSY_OP_S2D: {
+            const void* img = R.base(op.src0);
+            half_t* dst = R.h(op.dst);
+            if (!R.ok) return BSY_ERR_ARG;
+            return launch_s2d(img, op.in_dtype, op.B, op.H, op.W, dst, op.dst.ld, s);
+        }
         case BSY_OP_C3K2: {
             C3k2Args a;
             a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W;

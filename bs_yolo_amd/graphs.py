@@ -1,7 +1,8 @@
 """Stock model descriptions in the reference's yaml-dict schema (what ``model.yaml`` holds on a live reference model).
 
 The reference ships these graphs as cfg/models/11/yolo11-seg.yaml:15-47 (stock YOLO11 backbone+neck),
-cfg/models/v8/yolov8-seg.yaml:15-46 and cfg/models/11/yolo11.yaml:15-52 (the modified BS-YOLO graph, family "bsyolo11").  They are
+cfg/models/v8/yolov8-seg.yaml:15-46, cfg/models/v5/yolov5.yaml:14-50 and cfg/models/11/yolo11.yaml:15-52 (the modified BS-YOLO
+graph, family "bsyolo11").  They are
 restated here as data so the engine can be built where the reference is not installed (benchmarks, GPU box).
 """
 from __future__ import annotations
@@ -70,7 +71,26 @@ _BSYOLO11 = {
     "detect_from": [19, 23, 27],
 }
 
-_FAMILIES = {"yolo11": _YOLO11, "yolov8": _YOLOV8, "bsyolo11": _BSYOLO11}
+# YOLOv5u, cfg/models/v5/yolov5.yaml:14-50: 6x6 stride-2 pad-2 stem, C3 blocks, SPPF, the anchor-free Detect head
+_YOLOV5 = {
+    "scales": {"n": [0.33, 0.25, 1024], "s": [0.33, 0.50, 1024], "m": [0.67, 0.75, 1024], "l": [1.00, 1.00, 1024],
+               "x": [1.33, 1.25, 1024]},
+    "backbone": [
+        [-1, 1, "Conv", [64, 6, 2, 2]], [-1, 1, "Conv", [128, 3, 2]], [-1, 3, "C3", [128]],
+        [-1, 1, "Conv", [256, 3, 2]], [-1, 6, "C3", [256]], [-1, 1, "Conv", [512, 3, 2]],
+        [-1, 9, "C3", [512]], [-1, 1, "Conv", [1024, 3, 2]], [-1, 3, "C3", [1024]],
+        [-1, 1, "SPPF", [1024, 5]],
+    ],
+    "head": [
+        [-1, 1, "Conv", [512, 1, 1]], _UP, _cat(6), [-1, 3, "C3", [512, False]],
+        [-1, 1, "Conv", [256, 1, 1]], _UP, _cat(4), [-1, 3, "C3", [256, False]],
+        [-1, 1, "Conv", [256, 3, 2]], _cat(14), [-1, 3, "C3", [512, False]],
+        [-1, 1, "Conv", [512, 3, 2]], _cat(10), [-1, 3, "C3", [1024, False]],
+    ],
+    "detect_from": [17, 20, 23],
+}
+
+_FAMILIES = {"yolo11": _YOLO11, "yolov8": _YOLOV8, "bsyolo11": _BSYOLO11, "yolov5": _YOLOV5}
 
 
 def stock_cfg(family: str = "yolo11", scale: str = "s", nc: int = 80, task: str = "detect") -> dict:

@@ -147,7 +147,8 @@ class Plan:
 
     def conv(self, name: str, src: Union[T, Sequence[T]], cout: int, k: int = 1, s: int = 1, act: bool = True,
              dst: Optional[T] = None, res: Optional[T] = None, plain: bool = False, out_f32: bool = False,
-             perm: Optional[List[int]] = None, name2: Optional[str] = None) -> T:
+             perm: Optional[List[int]] = None, name2: Optional[str] = None, wkind: Optional[str] = None,
+             wshape: Optional[Tuple[int, int, int]] = None) -> T:
         """name2: a second Conv module of the same input and kernel whose output channels follow this one's (weights.py
         kind "conv2": the two folded weight matrices stacked along cout) -- one launch for both, cout = the total."""
         srcs = [src] if isinstance(src, T) else list(src)
@@ -166,7 +167,8 @@ class Plan:
             assert not plain and perm is None and cout % 2 == 0
             key = self._wrec(name + "+" + name2, name=name, kind="conv2", cout=cout, cin=cin, k=k, post=name2)
         else:
-            key = self._wrec(name, name=name, kind="plain" if plain else "conv", cout=cout, cin=cin, k=k, perm=perm)
+            wc, wi, wk = wshape or (cout, cin, k)  # wshape: the module's own weight shape where the op runs a re-laid-out copy
+            key = self._wrec(name, name=name, kind=wkind or ("plain" if plain else "conv"), cout=wc, cin=wi, k=wk, perm=perm)
         self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
                              src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
                              act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane, cout=cout,
@@ -174,8 +176,17 @@ class Plan:
         self.flops += 2 * self.B * OH * OW * cout * cin * k * k
         return dst
 
-    def conv_first(self, name: str, cout: int, k: int, s: int) -> T:
-        p = k // 2
+    def conv_first(self, name: str, cout: int, k: int, s: int, p: Optional[int] = None) -> T:
+        p = k // 2 if p is None else p
+        if (k, s, p) == (6, 2, 2) and not self.f32_mode:
+            # YOLOv5u's stem (cfg/models/v5/yolov5.yaml:16): space-to-depth of the image (one elementwise launch) + an ordinary
+            # 3x3 stride-1 conv over its 12 (+4 zero) channels with the weights re-laid-out to match (weights.py "first_s2d")
+            assert self.H % 2 == 0 and self.W % 2 == 0
+            sd = self.alloc(16, self.H // 2, self.W // 2)
+            self.ops.append(dict(kind=L.OP_S2D, H=self.H, W=self.W, OH=self.H // 2, OW=self.W // 2,
+                                 src0=T(L.BSY_EXT_BASE + self.EXT_IMG, 0, 0, 3, self.H, self.W), dst=sd, in_dtype=self.in_dtype,
+                                 name=name + ".s2d"))
+            return self.conv(name, sd, cout, 3, 1, wkind="first_s2d", wshape=(cout, 3, 6))
         OH, OW = (self.H + 2 * p - k) // s + 1, (self.W + 2 * p - k) // s + 1
         dst = self.alloc(cout, OH, OW)
         key = self._wrec(name, name=name, kind="first", cout=cout, cin=3, k=k)
@@ -247,10 +258,12 @@ class Plan:
         t = self.conv(name + ".cv1", x, c_, k[0], 1)
         self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=x if (shortcut and x.C == dst.C) else None)
 
-    def c3k(self, name: str, x: T, dst: T, n: int, shortcut: bool):
-        """block.py:3320-3334 + :3807-3815: cv3(cat(m(cv1 x), cv2 x)), m = n x Bottleneck(c_, c_, k=(3,3), e=1)."""
+    def c3k(self, name: str, x, dst: T, n: int, shortcut: bool, k=(3, 3)):
+        """block.py:3320-3334 + :3807-3815: cv3(cat(m(cv1 x), cv2 x)), m = n x Bottleneck(c_, c_, k=(3,3), e=1); C3 itself
+        (YOLOv5u) is the same with k = ((1,1), (3,3)) and may read a two-operand Concat."""
         c_ = int(dst.C * 0.5)
-        cat = self.alloc(2 * c_, x.H, x.W)
+        x0 = x if isinstance(x, T) else x[0]
+        cat = self.alloc(2 * c_, x0.H, x0.W)
         if self.merge_c3k and n >= 2:
             # cv1 and cv2 read the same x: ONE launch writes [cv1 x | cv2 x] into the concat buffer (twice the cout per
             # pixel tile, one launch less); the last bottleneck then overwrites the cv1 half, which only the first one reads
@@ -260,8 +273,8 @@ class Plan:
             cur = self.conv(name + ".cv1", x, c_, 1, 1)
             self.conv(name + ".cv2", x, c_, 1, 1, dst=cat.slice(c_, c_))
         for i in range(n):
-            out = cat.slice(0, c_) if i == n - 1 else self.alloc(c_, x.H, x.W)
-            self.bottleneck(f"{name}.m.{i}", cur, out, shortcut, (3, 3), 1.0)
+            out = cat.slice(0, c_) if i == n - 1 else self.alloc(c_, x0.H, x0.W)
+            self.bottleneck(f"{name}.m.{i}", cur, out, shortcut, k, 1.0)
             cur = out
         self.conv(name + ".cv3", cat, dst.C, 1, 1, dst=dst)
 
@@ -534,16 +547,34 @@ class Plan:
             n = max(round(n * depth), 1) if n > 1 else n
             if f != -1:
                 x = outs[f] if isinstance(f, int) else [x if j == -1 else outs[j] for j in f]
-            if m in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA", "C3k2_gai", "SCDown"):
+            if m in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA", "C3k2_gai", "SCDown", "C3", "DWConv"):
                 c2 = make_divisible(min(args[0], max_ch) * width, 8)
                 if m == "Conv":
                     k = args[1] if len(args) > 1 else 1
                     s = args[2] if len(args) > 2 else 1
+                    pad = args[3] if len(args) > 3 and args[3] is not None else k // 2
                     if i == 0:
-                        y = self.conv_first(name, c2, k, s)
+                        if (k, s, pad) not in ((3, 2, 1), (6, 2, 2)):
+                            raise NotImplementedError(f"image conv k={k} s={s} p={pad}: 3x3 s2 p1 or 6x6 s2 p2 only")
+                        y = self.conv_first(name, c2, k, s, pad)
                     else:
                         assert isinstance(x, T)
+                        if pad != k // 2:
+                            raise NotImplementedError(f"Conv with padding {pad} != k // 2 is not accelerated")
                         y = self.conv(name, x, c2, k, s)
+                elif m == "C3":  # block.py:3320-3334; parse_model inserts the repeat count (tasks.py:1038)
+                    xs = x if isinstance(x, list) else x
+                    shortcut = bool(args[1]) if len(args) > 1 else True
+                    x0 = xs[0] if isinstance(xs, list) else xs
+                    y = self.alloc(c2, x0.H, x0.W)
+                    self.c3k(name, xs, y, n, shortcut, k=(1, 3))
+                elif m == "DWConv":  # conv.py:224-229: Conv(c1, c2, k, s, g=gcd(c1, c2))
+                    assert isinstance(x, T)
+                    k = args[1] if len(args) > 1 else 1
+                    s = args[2] if len(args) > 2 else 1
+                    if c2 != x.C:
+                        raise NotImplementedError(f"DWConv {x.C} -> {c2}: only the depthwise case c1 == c2 is accelerated")
+                    y = self.dwconv_g(name, x, k, k, s, x.C)
                 elif m == "C3k2":
                     legacy = False
                     c3k = bool(args[1]) if len(args) > 1 else False

@@ -69,7 +69,19 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f3
         w, b = torch.cat([w, w2]), torch.cat([b, b2])
     else:
         w, b = fold_conv_bn(sd, r.name, eps)
-    if r.kind in ("conv", "conv2", "plain", "first", "deconv"):
+    if r.kind == "first_s2d" and not f32:
+        # 6x6 stride-2 pad-2 image conv (YOLOv5u's stem, cfg/models/v5/yolov5.yaml:16) = 3x3 stride-1 pad-1 conv over the
+        # space-to-depth image [Y][X][(dy, dx, c)] (csrc/elementwise.hip s2d_kernel): input row 2 oy - 2 + kh with kh = 2 a + dy is
+        # s2d row oy - 1 + a, so w3[co][(dy, dx, c)][a][b] = w[co][c][2a + dy][2b + dx]; channels 12 .. 15 are zero padding
+        cout = r.cout
+        assert tuple(w.shape) == (cout, 3, 6, 6), (r.name, tuple(w.shape))
+        w3 = torch.zeros(cout, 16, 3, 3)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                w3[:, (dy * 2 + dx) * 3:(dy * 2 + dx) * 3 + 3] = w[:, :, dy::2, dx::2]
+        w = w3
+        r = WRec(name=r.name, kind="conv", cout=cout, cin=16, k=3)
+    if r.kind in ("conv", "conv2", "plain", "first", "first_s2d", "deconv"):
         cout, cin, k = r.cout, r.cin, r.k
         assert tuple(w.shape) == (cout, cin, k, k), (r.name, tuple(w.shape), (cout, cin, k, k))
         if r.perm is not None:

@@ -84,6 +84,8 @@ enum bsy_op_kind {
     BSY_OP_C3K2 = 18,      /* whole C3k2 block (c3k = False, n = 1; block.py:3796-3804) as one launch: src0 (Cin channels) -> dst
                             * (C2 channels); mid_c = the block's hidden width c; aux_off = (weights, bias) byte offsets of cv1,
                             * m.0.cv1, m.0.cv2, cv2.  Widths (Cin, c, C2) = (64, 32, 128): YOLO11s model.2, YOLO11n model.4        */
+    BSY_OP_S2D = 19,       /* space-to-depth of the image for a 6x6 stride-2 pad-2 stem (YOLOv5u): src0 = image (BCHW, in_dtype) -> dst
+                            * NHWC f16 (B, H/2, W/2, 16): channel (dy*2+dx)*3 + c, 12..15 zero; an ordinary 3x3 s1 conv follows   */
     BSY_OP_ELA = 15        /* ELA (nn/Addmodules/ELA.py:77-101): ksize = Conv1d taps; w_off -> f32 blob [spatial_conv C*k]
                             * [ch_att conv C*k][gn.weight C][gn.bias C]; scale, lvl_stride[0], lvl_stride[1] =
                             * sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight);

@@ -76,7 +76,20 @@ GRAPHS["bsyolo11"] = [
     (-1, 1, "SCDown", (512, 3, 2)), ((-1, 10), 1, "Concat", ()), (-1, 2, "C3k2", (1024, True)), (-1, 1, "ELA", (1024,)),
 ]
 SCALES["bsyolo11"] = SCALES["yolo11"]
-HEAD_FROM = {"yolo11": (16, 19, 22), "yolov8": (15, 18, 21), "bsyolo11": (19, 23, 27)}
+# YOLOv5u: cfg/models/v5/yolov5.yaml:14-50 (6x6 stride-2 pad-2 stem, C3 blocks, SPPF, anchor-free Detect head)
+GRAPHS["yolov5"] = [
+    (-1, 1, "Conv", (64, 6, 2, 2)), (-1, 1, "Conv", (128, 3, 2)), (-1, 3, "C3", (128,)),
+    (-1, 1, "Conv", (256, 3, 2)), (-1, 6, "C3", (256,)), (-1, 1, "Conv", (512, 3, 2)),
+    (-1, 9, "C3", (512,)), (-1, 1, "Conv", (1024, 3, 2)), (-1, 3, "C3", (1024,)),
+    (-1, 1, "SPPF", (1024, 5)),
+    (-1, 1, "Conv", (512, 1, 1)), (-1, 1, "Upsample", ()), ((-1, 6), 1, "Concat", ()), (-1, 3, "C3", (512, False)),
+    (-1, 1, "Conv", (256, 1, 1)), (-1, 1, "Upsample", ()), ((-1, 4), 1, "Concat", ()), (-1, 3, "C3", (256, False)),
+    (-1, 1, "Conv", (256, 3, 2)), ((-1, 14), 1, "Concat", ()), (-1, 3, "C3", (512, False)),
+    (-1, 1, "Conv", (512, 3, 2)), ((-1, 10), 1, "Concat", ()), (-1, 3, "C3", (1024, False)),
+]
+SCALES["yolov5"] = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 1024), "l": (1.00, 1.00, 1024),
+                    "x": (1.33, 1.25, 1024)}
+HEAD_FROM = {"yolo11": (16, 19, 22), "yolov8": (15, 18, 21), "bsyolo11": (19, 23, 27), "yolov5": (17, 20, 23)}
 
 
 def make_divisible(x, d):  # utils/ops.py:130-143
@@ -196,6 +209,15 @@ class C3k:
 
     def __call__(self, P, x):
         return self.cv3(P, torch.cat((self.m(P, self.cv1(P, x)), self.cv2(P, x)), 1))
+
+
+class C3(C3k):
+    """block.py:3320-3334: cv3(cat(m(cv1 x), cv2 x)), m = n x Bottleneck(c_, c_, shortcut, g, k=((1,1),(3,3)), e=1.0)."""
+
+    def __init__(self, name, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__(name, c1, c2, n, shortcut, g, e)
+        c_ = int(c2 * e)
+        self.m = Seq(Bottleneck(f"{name}.m.{i}", c_, c_, shortcut, g, k=(1, 3), e=1.0) for i in range(n))
 
 
 class C2f:
@@ -619,7 +641,7 @@ class Model:
         for i, (f, n, t, args) in enumerate(GRAPHS[family]):
             name = f"model.{i}"
             n = max(round(n * depth), 1) if n > 1 else n  # tasks.py:972
-            if t in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA", "C3k2_gai", "SCDown"):
+            if t in ("Conv", "C3k2", "C2f", "SPPF", "C2PSA", "C3k2_gai", "SCDown", "C3", "DWConv"):
                 c1 = chans[f] if chans else ch  # tasks.py:1014 (ch[f]; the first layer sees the image)
                 c2 = make_divisible(min(args[0], max_ch) * width, 8)  # tasks.py:1016
                 if t == "Conv":
@@ -636,6 +658,10 @@ class Model:
                     m = SCDown(name, c1, c2, *args[1:])
                 elif t == "C2f":
                     m = C2f(name, c1, c2, n, *args[1:])
+                elif t == "C3":
+                    m = C3(name, c1, c2, n, *args[1:])
+                elif t == "DWConv":
+                    m = DWConv(name, c1, c2, *args[1:])
                 elif t == "SPPF":
                     m = SPPF(name, c1, c2, *args[1:])
                 else:

@@ -107,6 +107,9 @@ def stock_cfg(family, scale, task, nc=80):
     if family == "bsyolo11":  # the fork's own graph, exactly as shipped (cfg/models/11/yolo11.yaml, nc = 12)
         d = yaml.safe_load(open(CFG / "11" / "yolo11.yaml"))
         assert task == "detect"
+    elif family == "yolov5":  # YOLOv5u (cfg/models/v5/yolov5.yaml: 6x6 stem, C3 blocks, anchor-free Detect)
+        d = yaml.safe_load(open(CFG / "v5" / "yolov5.yaml"))
+        assert task == "detect"
     elif family == "yolo11":
         d = yaml.safe_load(open(CFG / "11" / "yolo11-seg.yaml"))  # stock backbone/neck (yolo11.yaml is the BS-YOLO graph)
         if task == "detect":
@@ -319,6 +322,30 @@ def val_match_fixtures():
     print("wrote val_match", len(cases), "cases")
 
 
+def c3_fixture():
+    """Known answers of the reference's C3 module (block.py:3320-3334; YOLOv5u), with and without shortcut."""
+    from ultralytics.utils.torch_utils import fuse_conv_and_bn
+    out, cases = {}, {}
+    g = torch.Generator().manual_seed(12)
+    for tag, mod, x, ctor in (("c3", rb.C3(32, 32, 2), torch.randn(2, 32, 9, 8, generator=g), ["C3", 32, 32, 2]),
+                              ("c3_noadd", rb.C3(48, 32, 1, False), torch.randn(1, 48, 6, 7, generator=g), ["C3", 48, 32, 1, False])):
+        mod.eval()
+        initialize_weights(mod)
+        fill(mod, "m.", 13)
+        for sm in mod.modules():
+            if isinstance(sm, rc.Conv) and hasattr(sm, "bn"):
+                sm.conv = fuse_conv_and_bn(sm.conv, sm.bn)
+                delattr(sm, "bn")
+                sm.forward = sm.forward_fuse
+        with torch.inference_mode():
+            y = mod(x)
+        out[tag + ".x"], out[tag + ".y"] = x.numpy(), y.numpy()
+        cases[tag] = ctor
+    out["cases"] = json.dumps(cases)
+    np.savez_compressed(HERE / "modules_c3.npz", **out)
+    print("wrote modules_c3", list(cases))
+
+
 def masks_native_fixtures():
     """Known answers of the retina_masks path: the reference's own process_mask_native and scale_masks (utils/ops.py:696-737)
     on synthetic prototypes / coefficients / boxes; original-image shapes with letterbox padding on either axis, none, and
@@ -482,6 +509,11 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "val":  # only the validator-matching vectors
         val_match_fixtures()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "yolov5":  # YOLOv5u graph + the C3 module (round 2)
+        graph_fixture("yolov5n_detect", "yolov5", "n", "detect", [(2, 64, 64), (1, 96, 160)], keep_layers=True)
+        graph_fixture("yolov5s_detect", "yolov5", "s", "detect", [(1, 64, 96)])
+        c3_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "masks_native":  # only the retina-masks vectors (round 2)
         masks_native_fixtures()

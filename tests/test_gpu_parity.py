@@ -479,7 +479,7 @@ def _engine_vs_oracle(tag, dtype):
 
 
 @pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
-                                 "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect"])
+                                 "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect", "yolov5n_detect", "yolov5s_detect"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_engine_matches_reference_golden(tag, dtype):
     """Whole graph through the engine vs (a) the REFERENCE's own fp32 CPU outputs (golden) and (b) the oracle run
@@ -1145,10 +1145,10 @@ def test_letterbox_golden_pixels():
 # ulp of a value near the top of the range is 1e-3 of it, and the emulation does not share the kernels' summation order, so
 # "vs emulation" is tighter than "vs fp32 reference" only in the early layers and in the mean.  A kernel bug shows as a layer
 # whose error jumps by an order of magnitude against its predecessor; bounds (max, p99.9, mean) sit ~1.5x above the measurements.
-LAYER_TOL = {"yolo11n_detect": (4e-3, 2.5e-3, 2.5e-4), "bsyolo11n_detect": (5e-3, 3e-3, 3e-4)}
+LAYER_TOL = {"yolo11n_detect": (4e-3, 2.5e-3, 2.5e-4), "bsyolo11n_detect": (5e-3, 3e-3, 3e-4), "yolov5n_detect": (4e-3, 2.5e-3, 2.5e-4)}
 
 
-@pytest.mark.parametrize("tag", ["yolo11n_detect", "bsyolo11n_detect"])
+@pytest.mark.parametrize("tag", ["yolo11n_detect", "bsyolo11n_detect", "yolov5n_detect"])
 @pytest.mark.parametrize("fused", [True, False])
 def test_engine_every_layer_matches_reference(tag, fused, monkeypatch):
     monkeypatch.setenv("BSY_ARENA_REUSE", "0")  # keep every layer's buffer alive until the end of the forward
@@ -1249,7 +1249,7 @@ def test_engine_splits_batches_by_the_largest_view():
 # |dbox| <= 1e-3 * imgsz against the REFERENCE's own fp32 outputs, on all seven golden graphs and every golden input.
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
-                                 "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect"])
+                                 "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect", "yolov5n_detect", "yolov5s_detect"])
 def test_engine_fp32_mode_meets_the_north_star_tolerance(tag):
     z = np.load(GOLDEN / f"graph_{tag}.npz")
     meta = json.loads(str(z["meta"]))
@@ -1296,7 +1296,7 @@ def test_engine_fp32_mode_layers_match_reference(monkeypatch):
     """The same per layer (buffers kept alive: BSY_ARENA_REUSE=0): every top-level layer of the fp32 mode against the
     reference's own layer outputs, 1e-4 of the layer's range."""
     monkeypatch.setenv("BSY_ARENA_REUSE", "0")
-    for tag in ("yolo11n_detect", "bsyolo11n_detect"):
+    for tag in ("yolo11n_detect", "bsyolo11n_detect", "yolov5n_detect"):
         z = np.load(GOLDEN / f"graph_{tag}.npz")
         meta = json.loads(str(z["meta"]))
         m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
@@ -1375,3 +1375,36 @@ def test_process_mask_native_and_scale_masks_match_reference_golden():
             s16 = HM.scale_masks(ph[None, :2].to(DEV), shape)
             assert s16.dtype == torch.float16
             np.testing.assert_allclose(s16.float().cpu().numpy(), PP.scale_masks(ph[None, :2].float(), shape).numpy(), rtol=0, atol=2e-3)
+
+
+def test_engine_top_level_dwconv_layers_match_oracle():
+    """A graph with `DWConv` layers of its own (conv.py:224-229; 3x3 s1 and 5x5 s2) through the engine, both precisions,
+    against the oracle."""
+    fam = "t_dw"
+    R.GRAPHS[fam] = [(-1, 1, "Conv", (16, 3, 2)), (-1, 1, "DWConv", (16, 3, 1)), (-1, 1, "Conv", (32, 3, 2)), (-1, 1, "DWConv", (32, 5, 2)),
+                     (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "Conv", (64, 3, 2))]
+    R.SCALES[fam] = {"n": (1.0, 1.0, 1024)}
+    R.HEAD_FROM[fam] = (3, 4, 5)
+    cfg = {"nc": 80, "scale": "n", "scales": {"n": [1.0, 1.0, 1024]},
+           "backbone": [[-1, 1, "Conv", [16, 3, 2]], [-1, 1, "DWConv", [16, 3, 1]], [-1, 1, "Conv", [32, 3, 2]], [-1, 1, "DWConv", [32, 5, 2]],
+                        [-1, 1, "Conv", [64, 3, 2]], [-1, 1, "Conv", [64, 3, 2]]],
+           "head": [[[3, 4, 5], 1, "Detect", ["nc"]]]}
+    try:
+        m = R.Model(fam, "n", 80, "detect")
+        P = R.synth_params(m, 4)
+        x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(4))
+        with torch.inference_mode():
+            yref, rref = m.forward(P, x)
+        e32 = YoloEngine(cfg, P, precision="fp32")
+        y32, r32 = e32(x.to(DEV))
+        assert float((y32.cpu()[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3 and float((y32.cpu()[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 128
+        e16 = YoloEngine(cfg, P)
+        y16, _ = e16(x.half().to(DEV))
+        d = (y16.float().cpu() - yref).abs()
+        assert float(d[:, 4:].max()) < 1e-2 and float(d[:, :4].max()) < 1.0, (float(d[:, 4:].max()), float(d[:, :4].max()))
+        assert sum(o["kind"] == L.OP_DWCONV_G for o in e16.plan_for(2, 96, 128, torch.float16, torch.float16)[0].ops) == 2
+        e16.close()
+        e32.close()
+    finally:
+        for d_ in (R.GRAPHS, R.SCALES, R.HEAD_FROM):
+            d_.pop(fam, None)

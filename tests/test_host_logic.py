@@ -132,6 +132,53 @@ def test_bottleneck_fusion_peephole():
     assert not any(o["kind"] == L.OP_BNECK for o in m.ops)
 
 
+def test_yolov5u_plan():
+    """YOLOv5u (cfg/models/v5/yolov5.yaml): the 6x6 stride-2 pad-2 stem becomes space-to-depth + a 3x3 conv over 16 channels
+    whose packed weights are the module's 6x6 weights re-laid-out (exactly: every 6x6 tap appears once, the padding channels
+    are zero); C3 blocks expand to cv1 / cv2 / n x (1x1, 3x3 + shortcut) / cv3; dense FLOPs match the documented model size."""
+    from bs_yolo_amd.weights import pack_record
+    p = Plan(stock_cfg("yolov5", "s"), 1, 640, 640, merge_c3k=False)
+    assert p.ops[0]["kind"] == L.OP_S2D and p.ops[1]["kind"] == L.OP_CONV and (p.ops[1]["ksize"], p.ops[1]["stride"], p.ops[1]["src0"].C) == (3, 1, 16)
+    r = p.wrecs["model.0"]
+    assert (r.kind, r.cout, r.cin, r.k) == ("first_s2d", 32, 3, 6)
+    g = torch.Generator().manual_seed(0)
+    sd = {"model.0.conv.weight": torch.randn(32, 3, 6, 6, generator=g), "model.0.conv.bias": torch.randn(32, generator=g)}
+    wb, _ = pack_record(sd, r)
+    wp = torch.frombuffer(bytearray(wb), dtype=torch.float16).view(128, -1)[:32, :144].float().view(32, 3, 3, 16)  # [co][a][b][(dy,dx,c)]
+    x = torch.randn(1, 3, 12, 16, generator=g).half().float()
+    s2d = torch.zeros(1, 16, 6, 8)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            s2d[:, (dy * 2 + dx) * 3:(dy * 2 + dx) * 3 + 3] = x[:, :, dy::2, dx::2]
+    got = F.conv2d(s2d, wp.permute(0, 3, 1, 2), None, 1, 1)
+    want = F.conv2d(x, sd["model.0.conv.weight"].half().float(), None, 2, 2)
+    assert torch.allclose(got, want, atol=1e-4)
+    assert abs(p.flops / 1e9 - 24.0) < 0.5  # docs/en/models/yolov5.md: YOLOv5su 24.0 GFLOPs
+    names = [o["name"] for o in p.ops if o["name"].startswith("model.2.")]
+    assert names == ["model.2.cv1", "model.2.cv2", "model.2.m.0.cv1", "model.2.m.0.cv2", "model.2.cv3"]
+    m0 = [o for o in p.ops if o["name"].startswith("model.2.m.0.")]
+    assert (m0[0]["ksize"], m0[1]["ksize"]) == (1, 3) and m0[1]["res"] is not None  # Bottleneck k = ((1,1),(3,3)) + shortcut
+    head_c3 = [o for o in p.ops if o["name"] == "model.13.m.0.cv2"][0]
+    assert head_c3["res"] is None  # C3(..., False) in the neck
+    assert [o["name"] for o in Plan(stock_cfg("yolov5", "m"), 1, 64, 64).ops if "+" in str(o.get("wkey", ""))][:1] == ["model.2.cv1"]  # merged cv1 + cv2
+
+
+def test_top_level_dwconv_layer():
+    """A `DWConv` layer of a yaml graph (conv.py:224-229) runs on the generic depthwise kernel; c1 != c2 (a grouped conv) is
+    refused so the caller keeps the reference forward."""
+    cfg = {"nc": 80, "scale": "n", "scales": {"n": [1.0, 1.0, 1024]},
+           "backbone": [[-1, 1, "Conv", [16, 3, 2]], [-1, 1, "DWConv", [16, 3, 1]], [-1, 1, "Conv", [32, 3, 2]], [-1, 1, "DWConv", [32, 5, 2]],
+                        [-1, 1, "Conv", [64, 3, 2]], [-1, 1, "Conv", [64, 3, 2]]],
+           "head": [[[3, 4, 5], 1, "Detect", ["nc"]]]}
+    p = Plan(cfg, 1, 64, 64)
+    dw = [o for o in p.ops if o["kind"] == L.OP_DWCONV_G]
+    assert [(o["ksize"], o["stride"], o["src0"].C) for o in dw] == [(3, 1, 16), (5, 2, 32)]
+    assert p.wrecs["model.1"].kind == "dwg" and p.wrecs["model.3"].k == 5
+    bad = dict(cfg, backbone=[[-1, 1, "Conv", [16, 3, 2]], [-1, 1, "DWConv", [32, 3, 1]]] + cfg["backbone"][2:])
+    with pytest.raises(NotImplementedError):
+        Plan(bad, 1, 64, 64)
+
+
 def test_c3k2_fusion_peephole():
     """A whole C3k2 block with one thin Bottleneck (Cin 64 -> c 32 -> 128: model.2 of YOLO11s, model.4 of YOLO11n) becomes ONE
     OP_C3K2 launch (csrc/c3k2_fused.hip); blocks fed by a Concat (model.16 of YOLO11n) and C3k blocks keep their launches.
@@ -164,7 +211,8 @@ def test_dwpw_fusion_peephole():
 
 
 def test_plan_consumes_exactly_the_reference_parameters():
-    for fam, scale in (("yolo11", "n"), ("yolo11", "x"), ("yolov8", "s"), ("bsyolo11", "n"), ("bsyolo11", "m")):
+    for fam, scale in (("yolo11", "n"), ("yolo11", "x"), ("yolov8", "s"), ("bsyolo11", "n"), ("bsyolo11", "m"), ("yolov5", "n"),
+                       ("yolov5", "l")):
         p = Plan(stock_cfg(fam, scale), 2, 96, 64)
         m = R.Model(fam, scale, 80, "detect")
         want = {n for n, _ in m.param_specs() if not n.endswith("dfl.conv.weight")}

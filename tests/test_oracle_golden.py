@@ -21,7 +21,7 @@ def _load(name):
     return np.load(GOLDEN / name, allow_pickle=False)
 
 
-@pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
+@pytest.mark.parametrize("tag", ["yolov5n_detect", "yolov5s_detect", "yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
                                  "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect"])
 def test_graph_matches_reference(tag):
     z = _load(f"graph_{tag}.npz")
@@ -55,7 +55,7 @@ def test_graph_matches_reference(tag):
     assert si >= 1
 
 
-@pytest.mark.parametrize("tag", ["yolo11n_detect", "bsyolo11n_detect"])
+@pytest.mark.parametrize("tag", ["yolo11n_detect", "bsyolo11n_detect", "yolov5n_detect"])
 def test_per_layer_outputs_match_reference(tag):
     z = _load(f"graph_{tag}.npz")
     meta = json.loads(str(z["meta"]))
@@ -96,6 +96,17 @@ def test_modules_match_reference():
     for tag, ctor in cases.items():
         mod = _build_module(ctor)
         P = {n: R.synth_param(n, s, 7) for n, s in mod.specs()}
+        with torch.inference_mode():
+            y = mod(P, torch.from_numpy(z[tag + ".x"]))
+        np.testing.assert_allclose(y.numpy(), z[tag + ".y"], err_msg=tag, **TOL)
+
+
+def test_c3_module_matches_reference():
+    """oracle C3 (block.py:3320-3334, the YOLOv5u block: Bottlenecks with k = ((1,1),(3,3))) against the reference's module."""
+    z = _load("modules_c3.npz")
+    for tag, ctor in json.loads(str(z["cases"])).items():
+        mod = _build_module(ctor)
+        P = {n: R.synth_param(n, s, 13) for n, s in mod.specs()}
         with torch.inference_mode():
             y = mod(P, torch.from_numpy(z[tag + ".x"]))
         np.testing.assert_allclose(y.numpy(), z[tag + ".y"], err_msg=tag, **TOL)
