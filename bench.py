@@ -124,7 +124,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("BSY_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on STDOUT when the first communicator is created; the contract is ONE JSON line there:
+        # everything up to the result goes to stderr (file descriptor level: the banner comes from C code)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -284,6 +290,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, sd)
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
