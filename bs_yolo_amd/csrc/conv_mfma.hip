@@ -1294,12 +1294,6 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
     }
     __syncthreads();
 
-    half8 af3[2][8];  // TAIL: A fragments of the tail conv, double-buffered by cout tile (dead code otherwise)
-    if (TAIL) {
-        const half_t* ar = p.w3 + (size_t)lrow * p.K3 + 8 * lh;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) af3[0][ks] = *reinterpret_cast<const half8*>(ar + 16 * ks);
-    }
     constexpr int LDT = TN + 8;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -1337,30 +1331,19 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
     // ---- TAIL: logits[px][c] = sum_k tile[px][k] W3[c][k] + b3[c] over the tile parked above (K = Cout <= 128), wave = MFMA pixel
     //      tile (32 pixels), cout tiles of 32 in turn with the A fragments straight from global memory (L2-resident, 16 KiB);
     //      then sigmoid, transposed through LDS, 16-byte runs of 8 consecutive anchors into y (head.py:147) --------------------
-    // The A fragments come straight from global memory (L2-resident: the whole matrix is 20 KiB), one cout tile (8 fragments,
-    // 32 VGPRs) AHEAD of the MFMAs that use them: cout tile 0 was requested before the epilogue above (its SiLU phase hides
-    // the latency), tile ct + 1 is requested before tile ct's MFMAs.  (First version: load -> MFMA pairs inside the K loop;
-    // every MFMA then waited for its own L2 round trip and the tail cost 0.047 ms at 80 x 80 instead of saving 0.05.)
-    const int nct = (p.nc + 31) >> 5;  // <= 3 (launch check: nc <= 96), K = Cout = 128 = 8 MFMA steps
-    f32x16 acc3[3];
-    half8 bfr3[8];
-    {
-        const half_t* bt = smem + (wave * 32 + lrow) * LDT + 8 * lh;
+    const int nct = (p.nc + 31) >> 5, ksteps = p.Cout >> 4;  // Cout % 16 == 0 (launch check)
+    f32x16 acc3[4];  // nc <= 128 (launch check); every index below is a compile-time constant after unrolling
+    const half_t* bt = smem + (wave * 32 + lrow) * LDT + 8 * lh;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) bfr3[ks] = *reinterpret_cast<const half8*>(bt + 16 * ks);
-    }
-#pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
+    for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc3[ct][q] = 0.f;
-        if (ct + 1 < nct) {  // wave-uniform: request the next cout tile's fragments
-            const half_t* ar = p.w3 + (size_t)(32 * (ct + 1) + lrow) * p.K3 + 8 * lh;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) af3[(ct + 1) & 1][ks] = *reinterpret_cast<const half8*>(ar + 16 * ks);
-        }
-        if (ct < nct) {
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc3[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af3[ct & 1][ks], bfr3[ks], acc3[ct], 0, 0, 0);
+        if (ct < nct) {  // wave-uniform
+            const half_t* ar = p.w3 + (size_t)(32 * ct + lrow) * p.K3 + 8 * lh;
+#pragma unroll 4
+            for (int ks = 0; ks < ksteps; ++ks)
+                acc3[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(ar + 16 * ks), *reinterpret_cast<const half8*>(bt + 16 * ks),
+                                                                acc3[ct], 0, 0, 0);
         }
     }
     __syncthreads();  // every wave has read the tile: LDS becomes the transposed score tile [class][128 + 8]
@@ -1371,7 +1354,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
     const bool pvalid = oy0 + pty < p.H && ox0 + ptx < p.W;
     const int pix = (oy0 + pty) * p.W + ox0 + ptx;
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) {
+    for (int ct = 0; ct < 4; ++ct) {
         if (ct >= nct) break;  // wave-uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1413,8 +1396,9 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
 }
 
 bool dwpw_fused_supported(int C, int Cout) { return C > 0 && !(C & 31) && C <= DWPW_MAXC && Cout > 0 && !(Cout & 7); }
-// the class branch's tail on top: the unit's whole output in one cout tile of 128 channels (= the tail's K) and up to 96 classes
-bool dwpw_tail_supported(int C, int Cout, int nc) { return dwpw_fused_supported(C, Cout) && Cout == 128 && nc > 0 && nc <= 96; }
+// the class branch's tail on top: the unit's whole output (one cout tile of <= 128 channels, a multiple of 16 = the tail's K) and
+// up to 128 classes
+bool dwpw_tail_supported(int C, int Cout, int nc) { return dwpw_fused_supported(C, Cout) && Cout > 64 && Cout <= 128 && !(Cout & 15) && nc > 0 && nc <= 128; }
 
 int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s) {
     if (!dwpw_fused_supported(a.C, a.Cout)) BSY_FAIL(BSY_ERR_ARG, "dwpw: unsupported widths (C %d, Cout %d): C %% 32 == 0, C <= %d, Cout %% 8 == 0", a.C, a.Cout, DWPW_MAXC);

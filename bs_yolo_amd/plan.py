@@ -90,7 +90,7 @@ def c3k2_supported(cin: int, c: int, c2: int) -> bool:
 def dwpw_tail_supported(c: int, cout: int, nc: int) -> bool:
     """Widths for which the class branch's last 1x1 conv + sigmoid ride on its second DWConv+1x1 unit (mirror of
     conv_mfma.hip dwpw_tail_supported)."""
-    return dwpw_supported(c, cout) and cout == 128 and 0 < nc <= 96
+    return dwpw_supported(c, cout) and 64 < cout <= 128 and cout % 16 == 0 and 0 < nc <= 128
 
 
 def bneck_supported(c: int, ch: int) -> bool:

@@ -838,7 +838,7 @@ def test_engine_fused_decoder_matches_decode_kernel(dtype):
     pf, _ = fused.plan_for(2, 96, 160, dtype, dtype)
     pp, _ = plain.plan_for(2, 96, 160, dtype, dtype)
     assert not any(o["kind"] in (L.OP_DECODE, L.OP_RAW_NCHW) for o in pf.ops)
-    assert sum(1 for o in pf.ops if o["kind"] in (L.OP_CONV, L.OP_DWPW) and o.get("out_f32", 0) >= 2) == 6  # 3 box convs + 3 class tails
+    assert sum(1 for o in pf.ops if o["kind"] == L.OP_CONV and o.get("out_f32", 0) >= 2) == 6
     assert any(o["kind"] == L.OP_DECODE for o in pp.ops)
     yf, rf = fused(x)
     yp, rp = plain(x)
