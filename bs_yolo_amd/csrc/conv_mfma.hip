@@ -1350,9 +1350,9 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
     constexpr int LDP = TM + 8;
     const int hw = p.H * p.W;
     const int prow = wave * 32 + lrow;
-    const int pty = prow >> 4, ptx = prow & 15;
-    const bool pvalid = oy0 + pty < p.H && ox0 + ptx < p.W;
-    const int pix = (oy0 + pty) * p.W + ox0 + ptx;
+    const int ty = prow >> 4, tx = prow & 15;
+    const bool pvalid = oy0 + ty < p.H && ox0 + tx < p.W;
+    const int pix = (oy0 + ty) * p.W + ox0 + tx;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         if (ct >= nct) break;  // wave-uniform
