@@ -505,14 +505,14 @@ class Plan:
                 if fused and self.fuse_dwpw and self.fuse_tail and not t.up and dwpw_tail_supported(c3, c3, nc):
                     # the whole tail of the class branch in one launch: DWConv 3x3 + Conv 1x1 + the final 1x1 conv + sigmoid -> y
                     # (conv_mfma.hip dwpw_fused_kernel<2, true>); neither the unit's output nor the logits reach HBM
-                    un = f"{name}.cv3.{i}.1"
-                    kd = self._wrec(un + ".0", name=un + ".0", kind="dw", cout=c3, cin=1, k=3)
-                    kp = self._wrec(un + ".1", name=un + ".1", kind="conv", cout=c3, cin=c3, k=1, perm=None)
+                    nm = f"{name}.cv3.{i}.1"
+                    kd = self._wrec(nm + ".0", name=nm + ".0", kind="dw", cout=c3, cin=1, k=3)
+                    kp = self._wrec(nm + ".1", name=nm + ".1", kind="conv", cout=c3, cin=c3, k=1, perm=None)
                     kt = self._wrec(f"{name}.cv3.{i}.2", name=f"{name}.cv3.{i}.2", kind="plain", cout=nc, cin=c3, k=1, perm=None)
                     fl = 2 * self.B * t.H * t.W * c3 * (c3 + nc)
                     self.ops.append(dict(kind=L.OP_DWPW, H=t.H, W=t.W, OH=t.H, OW=t.W, src0=t,
                                          dst=T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc, 0, 0), ksize=3, stride=1, pad=1, act=1,
-                                         out_f32=2, wkey=kd, wkey2=kp, wkeys=[kt], mid_c=c3, name=un, lane=self._lane, nl=nc, nc=nc, nm=0,
+                                         out_f32=2, wkey=kd, wkey2=kp, wkeys=[kt], mid_c=c3, name=nm, lane=self._lane, nl=nc, nc=nc, nm=0,
                                          A=A, box=[T(L.BSY_EXT_BASE + self.EXT_RAW0 + i, 0, 0, 64 + nc, 0, 0)], cls=[], msk=[], level=i,
                                          lvl_h=[t.H, a0[i]], lvl_w=[t.W], lvl_stride=[strides[i]], out_dtype=self.out_dtype, mfma_flops=fl))
                     self.flops += fl + 2 * self.B * t.H * t.W * c3 * 9
