@@ -227,17 +227,8 @@ struct DwPwArgs {
     const float* bias;
     half_t* dst;
     int ldd, Cout, act;
-    // tail != 0: the class branch's final 1x1 conv (Cout -> nc, bias) + Detect's sigmoid fused on top; `dst` is unused, rows
-    // 4 + c of y (B, nrows, A) at anchors a0 + pixel are written (and the level's raw map when bound), as ConvArgs::epi == 2
-    int tail;
-    const void* w3;          // packed f16 [CoutPad][Kpad]
-    const float* b3;
-    int nc, A, a0, nrows, y_f32, raw_f32, rawC;
-    void* y;
-    void* raw;
 };
 bool dwpw_fused_supported(int C, int Cout);
-bool dwpw_tail_supported(int C, int Cout, int nc);
 int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s);
 
 struct DwArgs {

@@ -1132,22 +1132,14 @@ struct DwPwK {
     const float* bias;
     half_t* dst;
     int ldd, Cout, Kpad, act, tiles_x, tiles_y, ntn;
-    // TAIL (the class branch's last unit, head.py:49-57 + :147): a third layer -- the branch's final 1x1 conv (Cout -> nc, bias, no
-    // activation) -- and Detect's sigmoid run on the output tile while it is still in LDS; y rows 4 + c are written directly
-    const half_t* w3;   // packed [CoutPad][K3]
-    const float* b3;
-    int nc, K3, A, a0, nrows, y_f32, raw_f32, rawC;
-    void* y;
-    void* raw;
 };
 #define DWPW_MAXC 256
 // LDS: 2 patch buffers (chunk c + 1 lands while chunk c is processed), ONE weight stage (chunk c's 1x1 weights are issued
 // after the barrier that retires chunk c - 1's MFMAs and are only needed after the depthwise stage, which is longer than
 // their latency), the B-operand tile, and the depthwise weights / bias (dynamic: 10 * C floats) -> 46 KiB + 40 C bytes:
 // three workgroups per CU for C <= 128.
-template <int NT, bool TAIL = false>
+template <int NT>
 __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const DwPwK p) {
-    static_assert(!TAIL || NT == 2, "the tail needs the whole 1x1 output (<= 128 channels) in one workgroup");
     constexpr int TN = 64 * NT, TM = 128;
     constexpr int PIW = 3, NPI = 12, NPX = 10 * CP_PW;  // patch: 180 entries in 12 DMA wave-instructions
     constexpr int PBUF = NPI * 16 * 32, WST = TN * 32, PT = TM * 32;
@@ -1315,95 +1307,24 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
         }
     }
     __syncthreads();
-    if (!TAIL) {
-        constexpr int CPRW = TN / 8, ITER = TM * CPRW / 256;
+    constexpr int CPRW = TN / 8, ITER = TM * CPRW / 256;
 #pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            const int id = tid + 256 * i;
-            const int prow = id / CPRW, cc = (id % CPRW) * 8;
-            const int oy = oy0 + (prow >> 4), ox = ox0 + (prow & 15), cgl = n0 + cc;
-            if (oy >= p.H || ox >= p.W || cgl >= p.Cout) continue;
-            *reinterpret_cast<half8*>(p.dst + ((size_t)(n * p.H + oy) * p.W + ox) * p.ldd + cgl) =
-                *reinterpret_cast<const half8*>(smem + prow * LDT + cc);
-        }
-        return;
-    }
-    // ---- TAIL: logits[px][c] = sum_k tile[px][k] W3[c][k] + b3[c] over the tile parked above (K = Cout <= 128), wave = MFMA pixel
-    //      tile (32 pixels), cout tiles of 32 in turn with the A fragments straight from global memory (L2-resident, 16 KiB);
-    //      then sigmoid, transposed through LDS, 16-byte runs of 8 consecutive anchors into y (head.py:147) --------------------
-    const int nct = (p.nc + 31) >> 5, ksteps = p.Cout >> 4;  // Cout % 16 == 0 (launch check)
-    f32x16 acc3[4];  // nc <= 128 (launch check); every index below is a compile-time constant after unrolling
-    const half_t* bt = smem + (wave * 32 + lrow) * LDT + 8 * lh;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc3[ct][q] = 0.f;
-        if (ct < nct) {  // wave-uniform
-            const half_t* ar = p.w3 + (size_t)(32 * ct + lrow) * p.K3 + 8 * lh;
-#pragma unroll 4
-            for (int ks = 0; ks < ksteps; ++ks)
-                acc3[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(ar + 16 * ks), *reinterpret_cast<const half8*>(bt + 16 * ks),
-                                                                acc3[ct], 0, 0, 0);
-        }
-    }
-    __syncthreads();  // every wave has read the tile: LDS becomes the transposed score tile [class][128 + 8]
-    constexpr int LDP = TM + 8;
-    const int hw = p.H * p.W;
-    const int prow = wave * 32 + lrow;
-    const int ty = prow >> 4, tx = prow & 15;
-    const bool pvalid = oy0 + ty < p.H && ox0 + tx < p.W;
-    const int pix = (oy0 + ty) * p.W + ox0 + tx;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        if (ct >= nct) break;  // wave-uniform
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = 32 * ct + 8 * g + 4 * lh;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b3 + c0);  // bias is padded to a multiple of 128
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = c0 + e;
-                if (c >= p.nc) continue;
-                const float v = acc3[ct][4 * g + e] + bv[e];
-                const float sg = 1.0f / (1.0f + __expf(-v));
-                if (p.y_f32) {
-                    if (pvalid) reinterpret_cast<float*>(p.y)[((size_t)n * p.nrows + 4 + c) * p.A + p.a0 + pix] = sg;
-                } else {
-                    smem[c * LDP + prow] = (half_t)sg;
-                }
-                if (p.raw && pvalid) {  // the level's raw map (B, rawC, H, W), class logits at channels 64 ..
-                    const size_t ri = ((size_t)n * p.rawC + 64 + c) * hw + pix;
-                    if (p.raw_f32) reinterpret_cast<float*>(p.raw)[ri] = v; else reinterpret_cast<half_t*>(p.raw)[ri] = (half_t)v;
-                }
-            }
-        }
-    }
-    if (p.y_f32) return;  // wave-uniform: f32 scores were stored directly
-    __syncthreads();
-    half_t* y = reinterpret_cast<half_t*>(p.y);
-    for (int id = tid; id < p.nc * (TM / 8); id += 256) {
-        const int c = id / (TM / 8), g8 = (id - c * (TM / 8)) * 8;  // 8 pixels of one tile row: columns g8 % 16 .. + 7
-        const int r8 = g8 >> 4, x8 = g8 & 15;
-        const int oy = oy0 + r8, ox = ox0 + x8;
-        if (oy >= p.H || ox >= p.W) continue;
-        const size_t yi = ((size_t)n * p.nrows + 4 + c) * p.A + p.a0 + (size_t)oy * p.W + ox;
-        if (ox + 8 <= p.W && !(yi & 7)) {
-            *reinterpret_cast<half8*>(y + yi) = *reinterpret_cast<const half8*>(smem + c * LDP + g8);
-        } else {
-            for (int e = 0; e < 8 && ox + e < p.W; ++e) y[yi + e] = smem[c * LDP + g8 + e];
-        }
+    for (int i = 0; i < ITER; ++i) {
+        const int id = tid + 256 * i;
+        const int prow = id / CPRW, cc = (id % CPRW) * 8;
+        const int oy = oy0 + (prow >> 4), ox = ox0 + (prow & 15), cgl = n0 + cc;
+        if (oy >= p.H || ox >= p.W || cgl >= p.Cout) continue;
+        *reinterpret_cast<half8*>(p.dst + ((size_t)(n * p.H + oy) * p.W + ox) * p.ldd + cgl) =
+            *reinterpret_cast<const half8*>(smem + prow * LDT + cc);
     }
 }
 
 bool dwpw_fused_supported(int C, int Cout) { return C > 0 && !(C & 31) && C <= DWPW_MAXC && Cout > 0 && !(Cout & 7); }
-// the class branch's tail on top: the unit's whole output (one cout tile of <= 128 channels, a multiple of 16 = the tail's K) and
-// up to 128 classes
-bool dwpw_tail_supported(int C, int Cout, int nc) { return dwpw_fused_supported(C, Cout) && Cout > 64 && Cout <= 128 && !(Cout & 15) && nc > 0 && nc <= 128; }
 
 int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s) {
     if (!dwpw_fused_supported(a.C, a.Cout)) BSY_FAIL(BSY_ERR_ARG, "dwpw: unsupported widths (C %d, Cout %d): C %% 32 == 0, C <= %d, Cout %% 8 == 0", a.C, a.Cout, DWPW_MAXC);
-    if (!a.src || (!a.dst && !a.tail) || !a.dww || !a.dwb || !a.wgt || !a.bias) BSY_FAIL(BSY_ERR_ARG, "dwpw: null pointer");
-    if ((a.lds & 7) || a.lds < a.C || (!a.tail && ((a.ldd & 7) || a.ldd < a.Cout)) ||
+    if (!a.src || !a.dst || !a.dww || !a.dwb || !a.wgt || !a.bias) BSY_FAIL(BSY_ERR_ARG, "dwpw: null pointer");
+    if ((a.lds & 7) || (a.ldd & 7) || a.lds < a.C || a.ldd < a.Cout ||
         (((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.dww | (uintptr_t)a.dwb | (uintptr_t)a.wgt | (uintptr_t)a.bias) & 15))
         BSY_FAIL(BSY_ERR_ARG, "dwpw: misaligned pointer / leading dimension");
     if ((long long)a.B * a.H * a.W * a.lds >= (1LL << 31)) BSY_FAIL(BSY_ERR_ARG, "dwpw: source view exceeds 2^31 elements (split the batch)");
@@ -1419,18 +1340,6 @@ int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s) {
     const long long nblk = (long long)a.B * k.tiles_x * k.tiles_y * k.ntn;
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "dwpw: tile count out of range");
     const size_t dyn = (size_t)10 * a.C * sizeof(float);  // depthwise weights + bias
-    k.w3 = nullptr; k.b3 = nullptr; k.nc = k.K3 = k.A = k.a0 = k.nrows = k.y_f32 = k.raw_f32 = k.rawC = 0; k.y = nullptr; k.raw = nullptr;
-    if (a.tail) {
-        if (!dwpw_tail_supported(a.C, a.Cout, a.nc)) BSY_FAIL(BSY_ERR_ARG, "dwpw tail: unsupported widths (C %d, Cout %d, nc %d)", a.C, a.Cout, a.nc);
-        if (!a.w3 || !a.b3 || !a.y || (((uintptr_t)a.w3 | (uintptr_t)a.b3) & 15) || a.A <= 0 || a.a0 < 0 || a.a0 + a.H * a.W > a.A || a.nrows < 4 + a.nc ||
-            (a.raw && a.rawC < 64 + a.nc))
-            BSY_FAIL(BSY_ERR_ARG, "dwpw tail: bad decoder arguments");
-        k.w3 = (const half_t*)a.w3; k.b3 = a.b3; k.nc = a.nc; k.K3 = round_up(a.Cout, 32); k.A = a.A; k.a0 = a.a0; k.nrows = a.nrows;
-        k.y = a.y; k.y_f32 = a.y_f32; k.raw = a.raw; k.raw_f32 = a.raw_f32; k.rawC = a.rawC;
-        hipLaunchKernelGGL((dwpw_fused_kernel<2, true>), dim3((unsigned)nblk), dim3(256), dyn, s, k);
-        HIP_TRY(hipGetLastError());
-        return BSY_OK;
-    }
     if (wide) hipLaunchKernelGGL((dwpw_fused_kernel<2>), dim3((unsigned)nblk), dim3(256), dyn, s, k);
     else hipLaunchKernelGGL((dwpw_fused_kernel<1>), dim3((unsigned)nblk), dim3(256), dyn, s, k);
     HIP_TRY(hipGetLastError());

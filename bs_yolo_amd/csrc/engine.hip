@@ -414,19 +414,7 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             a.src = R.h(op.src0); a.lds = op.src0.ld; a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.src0.C;
             a.dww = (const float*)(wb + op.w_off); a.dwb = (const float*)(wb + op.b_off);
             a.wgt = (const void*)(wb + op.w2_off); a.bias = (const float*)(wb + op.b2_off);
-            a.act = op.act;
-            a.tail = op.out_f32 == 2;
-            if (a.tail) {  // class-branch tail fused: dst = the y view (external), mid_c = the unit's own output width, aux = tail conv
-                a.dst = nullptr; a.ldd = 0; a.Cout = op.mid_c;
-                a.w3 = wb + op.aux_off[0]; a.b3 = (const float*)(wb + op.aux_off[1]);
-                a.nc = op.nl; a.A = op.A; a.a0 = op.lvl_h[1]; a.nrows = op.dst.C; a.y = R.base(op.dst); a.y_f32 = op.out_dtype == BSY_F32;
-                const bsy_view& rv = op.box[0];
-                const bool bound = rv.buf >= BSY_EXT_BASE && rv.buf - BSY_EXT_BASE < R.n_ext && R.ext[rv.buf - BSY_EXT_BASE];
-                a.raw = bound ? R.base(rv) : nullptr; a.raw_f32 = a.y_f32; a.rawC = rv.C;
-            } else {
-                a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.Cout = op.dst.C;
-                a.w3 = nullptr; a.b3 = nullptr; a.nc = a.A = a.a0 = a.nrows = a.y_f32 = a.raw_f32 = a.rawC = 0; a.y = a.raw = nullptr;
-            }
+            a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.Cout = op.dst.C; a.act = op.act;
             if (!R.ok) return BSY_ERR_ARG;
             return launch_dwpw_fused(a, s);
         }
@@ -848,7 +836,6 @@ extern "C" int bsy_dwpw_fused(const void* x, int ldx, int B, int H, int W, int C
     DwPwArgs a;
     a.src = (const half_t*)x; a.lds = ldx; a.B = B; a.H = H; a.W = W; a.C = C; a.dww = dww; a.dwb = dwb; a.wgt = w; a.bias = b;
     a.dst = (half_t*)y; a.ldd = ldy; a.Cout = C2; a.act = act;
-    a.tail = 0; a.w3 = nullptr; a.b3 = nullptr; a.nc = a.A = a.a0 = a.nrows = a.y_f32 = a.raw_f32 = a.rawC = 0; a.y = a.raw = nullptr;
     return launch_dwpw_fused(a, (hipStream_t)stream);
 }
 

@@ -87,12 +87,6 @@ def c3k2_supported(cin: int, c: int, c2: int) -> bool:
     return (cin, c, c2) == (64, 32, 128)
 
 
-def dwpw_tail_supported(c: int, cout: int, nc: int) -> bool:
-    """Widths for which the class branch's last 1x1 conv + sigmoid ride on its second DWConv+1x1 unit (mirror of
-    conv_mfma.hip dwpw_tail_supported)."""
-    return dwpw_supported(c, cout) and 64 < cout <= 128 and cout % 16 == 0 and 0 < nc <= 128
-
-
 def bneck_supported(c: int, ch: int) -> bool:
     """Widths csrc/bneck_fused.hip accepts (mirror of bsy_bottleneck_fused_supported)."""
     return (c, ch) == (32, 16)
@@ -502,21 +496,6 @@ class Plan:
                 t = self.conv(f"{name}.cv3.{i}.1", t, c3, 3, 1)
             else:
                 t = self.dwpw(f"{name}.cv3.{i}.0", x, c3)
-                if fused and self.fuse_dwpw and self.fuse_tail and not t.up and dwpw_tail_supported(c3, c3, nc):
-                    # the whole tail of the class branch in one launch: DWConv 3x3 + Conv 1x1 + the final 1x1 conv + sigmoid -> y
-                    # (conv_mfma.hip dwpw_fused_kernel<2, true>); neither the unit's output nor the logits reach HBM
-                    nm = f"{name}.cv3.{i}.1"
-                    kd = self._wrec(nm + ".0", name=nm + ".0", kind="dw", cout=c3, cin=1, k=3)
-                    kp = self._wrec(nm + ".1", name=nm + ".1", kind="conv", cout=c3, cin=c3, k=1, perm=None)
-                    kt = self._wrec(f"{name}.cv3.{i}.2", name=f"{name}.cv3.{i}.2", kind="plain", cout=nc, cin=c3, k=1, perm=None)
-                    fl = 2 * self.B * t.H * t.W * c3 * (c3 + nc)
-                    self.ops.append(dict(kind=L.OP_DWPW, H=t.H, W=t.W, OH=t.H, OW=t.W, src0=t,
-                                         dst=T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc, 0, 0), ksize=3, stride=1, pad=1, act=1,
-                                         out_f32=2, wkey=kd, wkey2=kp, wkeys=[kt], mid_c=c3, name=nm, lane=self._lane, nl=nc, nc=nc, nm=0,
-                                         A=A, box=[T(L.BSY_EXT_BASE + self.EXT_RAW0 + i, 0, 0, 64 + nc, 0, 0)], cls=[], msk=[], level=i,
-                                         lvl_h=[t.H, a0[i]], lvl_w=[t.W], lvl_stride=[strides[i]], out_dtype=self.out_dtype, mfma_flops=fl))
-                    self.flops += fl + 2 * self.B * t.H * t.W * c3 * 9
-                    continue
                 t = self.dwpw(f"{name}.cv3.{i}.1", t, c3)
             if fused:
                 self._head_conv(f"{name}.cv3.{i}.2", t, nc, 2, i, a0[i], A, nc, strides[i])

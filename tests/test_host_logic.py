@@ -193,33 +193,16 @@ def test_c3k2_fusion_peephole():
         for o in fused:
             assert (o["src0"].C, o["mid_c"], o["dst"].C) == (64, 32, 128) and len(o["wkeys"]) == 4
             assert o["wkeys"] == [o["name"] + sfx for sfx in (".cv1", ".m.0.cv1", ".m.0.cv2", ".cv2")]
-            tails = sum(o["kind"] == L.OP_DWPW and o.get("out_f32") == 2 for o in b.ops)  # class-branch tails ride on fuse_tail too
-            assert len(a.ops) - len(b.ops) == 2 + tails  # cv1 conv + fused Bottleneck + cv2 conv -> one op
+            assert len(a.ops) - len(b.ops) == 2  # cv1 conv + fused Bottleneck + cv2 conv -> one op
             assert sum(b.buf_bytes) < sum(a.buf_bytes)  # no concat buffer
     assert L.OP_C3K2 == 18 and L.Op.aux_off.offset % 8 == 0
-
-
-def test_class_branch_tail_peephole():
-    """YOLO11s: the class branch's second DWConv+1x1 unit also runs the branch's final 1x1 conv and Detect's sigmoid (one OP_DWPW
-    launch with out_f32 = 2 per level); YOLO11n's 80-wide units (not a multiple of 32) keep the separate launches."""
-    a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_tail=False)
-    b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_tail=True)
-    t = [o for o in b.ops if o["kind"] == L.OP_DWPW and o.get("out_f32") == 2]
-    assert [o["name"] for o in t] == [f"model.23.cv3.{i}.1" for i in range(3)]
-    for i, o in enumerate(t):
-        assert o["wkeys"] == [f"model.23.cv3.{i}.2"] and o["mid_c"] == 128 and o["nl"] == 80 and o["dst"].buf == L.BSY_EXT_BASE + Plan.EXT_Y
-        assert o["lvl_h"][1] == [0, 6400, 8000][i] and o["A"] == 8400
-    assert not [o for o in b.ops if o["name"].endswith("cv3.0.2")]  # the separate last conv is gone
-    assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
-    n = Plan(stock_cfg("yolo11", "n"), 2, 640, 640)
-    assert not [o for o in n.ops if o["kind"] == L.OP_DWPW and o.get("out_f32") == 2]
 
 
 def test_dwpw_fusion_peephole():
     """YOLO11's class branch units nn.Sequential(DWConv, Conv 1x1) (head.py:49-57) become one OP_DWPW launch where the
     depthwise width is <= 256 (levels 0 and 1 of YOLO11s; the 512-wide level keeps two launches)."""
-    a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_dwpw=False, fuse_tail=False)
-    b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_dwpw=True, fuse_tail=False)
+    a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_dwpw=False)
+    b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_dwpw=True)
     assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
     fused = [o["name"] for o in b.ops if o["kind"] == L.OP_DWPW]
     assert fused == ["model.23.cv3.0.0", "model.23.cv3.0.1", "model.23.cv3.1.0", "model.23.cv3.1.1", "model.23.cv3.2.1"]
