@@ -189,10 +189,182 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
     }
 }
 
-bool bneck_fused_supported(int C, int CH) { return C == 32 && CH == 16; }
+// ---------------------------------------------------------------------------------------------------------------------
+// The 64 -> 32 -> 64 Bottleneck (YOLO11s model.4 / model.16 at 80 x 80; round 2).  Two launches of the patch kernel ran these
+// thin layers at 350-430 TFLOP/s (a 64-wide cout tile is half empty for the 32-channel hidden map, and the hidden map
+// round-trips through HBM): 0.078 ms per Bottleneck.  Same scheme as above with both weight matrices in LDS (conv 1's A
+// fragments no longer fit registers: 36 K-steps), 8 waves, one workgroup per CU (143 KiB of LDS):
+//   conv 1: 6 MFMA pixel tiles of the hidden patch on waves 0-5, 36 K-steps each;
+//   conv 2: 4 pixel tiles x 2 cout tiles on the 8 waves, 18 K-steps each, + shortcut from the input patch.
+// Lane-constant address arithmetic is hoisted out of the tile loop (c3k2_fused.hip).  K orders and epilogue arithmetic equal
+// conv_mfma.hip's tap-major implicit GEMM: bit-identical to the two-launch path through that kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C, int CH>
+__global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
+    constexpr int XS = C + 8, MS = CH + 8, LDO = C + 8;
+    constexpr int KSA = 9 * C / 16, KSB = 9 * CH / 16;
+    constexpr int XCH = C / 8;
+    constexpr int NITEM = BN_NX * XCH, NLOAD = (NITEM + 511) / 512;
+    constexpr int W1S = 9 * C + 8, W2S = 9 * CH + 8;  // padded weight rows (halves): conflict-free A reads
+    constexpr int SX = BN_NX * XS, SM = BN_NM * MS, SO = BN_TH * BN_TW * LDO;
+    static_assert(C == 64 && CH == 32, "instantiated for the YOLO11s C3k2 bottleneck at 1/8 resolution");
+    __shared__ __attribute__((aligned(16))) half_t lds[SX + SM + SO + CH * W1S + C * W2S + 2 * (C + CH)];
+    half_t* sx = lds;
+    half_t* smid = lds + SX;
+    half_t* sout = smid + SM;
+    half_t* sw1 = sout + SO;
+    half_t* sw2 = sw1 + CH * W1S;
+    float* sb1 = reinterpret_cast<float*>(sw2 + C * W2S);
+    float* sb2 = sb1 + CH;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    if (tid < CH) sb1[tid] = p.b1[tid];
+    if (tid < C) sb2[tid] = p.b2[tid];
+    for (int i = tid; i < CH * (9 * C / 8); i += 512) {
+        const int row = i / (9 * C / 8), ch = i - row * (9 * C / 8);
+        *reinterpret_cast<half8*>(sw1 + row * W1S + ch * 8) = *reinterpret_cast<const half8*>(p.w1 + (size_t)row * p.Kpad1 + ch * 8);
+    }
+    for (int i = tid; i < C * (9 * CH / 8); i += 512) {
+        const int row = i / (9 * CH / 8), ch = i - row * (9 * CH / 8);
+        *reinterpret_cast<half8*>(sw2 + row * W2S + ch * 8) = *reinterpret_cast<const half8*>(p.w2 + (size_t)row * p.Kpad2 + ch * 8);
+    }
+
+    // tile-independent lane tables
+    int it_off[NLOAD], it_r[NLOAD], it_c[NLOAD];
+    unsigned it_rel[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int idx = tid + 512 * i;
+        const int e = idx / XCH, ch = idx - e * XCH;
+        const int r = e / BN_XC, c = e - r * BN_XC;
+        it_r[i] = idx < NITEM ? r : 0x40000000;  // items past the patch: never in bounds
+        it_c[i] = c;
+        it_off[i] = e * XS + ch * 8;
+        it_rel[i] = (unsigned)((r * p.W + c) * p.lds + ch * 8);
+    }
+    constexpr int CPRW = C / 8, NST = BN_TH * BN_TW * CPRW / 512;
+    int st_y[NST], st_x[NST], st_off[NST];
+    unsigned st_rel[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int id = tid + 512 * j;
+        const int pr = id / CPRW, cc = (id % CPRW) * 8;
+        st_y[j] = pr / BN_TW;
+        st_x[j] = pr % BN_TW;
+        st_off[j] = pr * LDO + cc;
+        st_rel[j] = (unsigned)((st_y[j] * p.W + st_x[j]) * p.ldd + cc);
+    }
+    // conv 1: hidden pixel of this lane (waves 0-5); conv 2: output pixel tile wave & 3, cout tile wave >> 2
+    const int mm1 = wave * 32 + lrow, mc1 = mm1 < BN_NM ? mm1 : BN_NM - 1, r1 = mc1 / BN_MC, c1 = mc1 - r1 * BN_MC;
+    const half_t* xb = sx + (r1 * BN_XC + c1) * XS + 8 * lh;
+    const half_t* a1base = sw1 + lrow * W1S + 8 * lh;
+    const int pt = wave & 3, ct = wave >> 2;
+    const int ty2 = 2 * pt + (lrow >> 4), tx2 = lrow & 15;
+    const half_t* b2base = smid + (ty2 * BN_MC + tx2) * MS + 8 * lh;
+    const half_t* a2base = sw2 + (32 * ct + lrow) * W2S + 8 * lh;
+    const half_t* rbase = sx + ((ty2 + 2) * BN_XC + tx2 + 2) * XS + 32 * ct + 4 * lh;  // shortcut: the pixel's own input entry
+    half_t* obase = sout + (pt * 32 + lrow) * LDO + 32 * ct + 4 * lh;
+
+    auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
+        const int r = (int)__umulhi((unsigned)tile, p.magic_x);
+        const int tx = tile - r * p.tiles_x;
+        n = (int)__umulhi((unsigned)r, p.magic_y);
+        const int ty = r - n * p.tiles_y;
+        oy0 = ty * BN_TH;
+        ox0 = tx * BN_TW;
+    };
+    half8 pre[NLOAD];
+    int nn = 0, noy0 = 0, nox0 = 0;
+    auto fetch = [&](int tile) {
+        tile_origin(tile, nn, noy0, nox0);
+        const half_t* tb = p.src + ((long long)(nn * p.H + noy0 - 2) * p.W + (nox0 - 2)) * p.lds;  // patch origin (a base only)
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            pre[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)(noy0 - 2 + it_r[i]) < (unsigned)p.H && (unsigned)(nox0 - 2 + it_c[i]) < (unsigned)p.W)
+                pre[i] = *reinterpret_cast<const half8*>(tb + it_rel[i]);
+        }
+    };
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the weight loads here, not inside the tile loop
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) fetch(tile);
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        const int n = nn, oy0 = noy0, ox0 = nox0;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i)
+            if (tid + 512 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
+        half_t* ob = p.dst + ((long long)(n * p.H + oy0) * p.W + ox0) * p.ldd;
+        __syncthreads();  // input patch visible (first iteration: the weights too); the previous tile's output has been read
+        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+
+        // ---- conv 1: 180 hidden pixels = 6 MFMA pixel tiles on waves 0-5 -----------------------------------------------------
+        if (wave < BN_NMT) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSA; ++ks) {
+                const int k0 = 16 * ks, tap = k0 / C, ch0 = (k0 % C) / 8;  // compile-time; lane half 1 = next chunk
+                const half8 bf = *reinterpret_cast<const half8*>(xb + ((tap / 3) * BN_XC + tap % 3) * XS + ch0 * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(a1base + 16 * ks), bf, acc, 0, 0, 0);
+            }
+            const unsigned keep = ((unsigned)(oy0 - 1 + r1) < (unsigned)p.H && (unsigned)(ox0 - 1 + c1) < (unsigned)p.W) ? 0xffffffffu : 0u;
+            if (mm1 < BN_NM) {
+#pragma unroll
+                for (int g = 0; g < CH / 8; ++g) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + 8 * g + 4 * lh);
+                    union { half4 h; unsigned u[2]; } o;
+                    f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                    if (p.act) t = silu4_f(t);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
+                    o.u[0] &= keep;  // outside the map: conv 2's zero padding
+                    o.u[1] &= keep;
+                    *reinterpret_cast<half4*>(smid + mm1 * MS + 8 * g + 4 * lh) = o.h;
+                }
+            }
+        }
+        __syncthreads();  // hidden patch complete
+
+        // ---- conv 2 + shortcut: MFMA pixel tile pt (2 rows x 16), cout tile ct (32 channels) per wave ----------------------------
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const int k0 = 16 * ks, tap = k0 / CH, ch0 = (k0 % CH) / 8;
+                const half8 bf = *reinterpret_cast<const half8*>(b2base + ((tap / 3) * BN_MC + tap % 3) * MS + ch0 * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(a2base + 16 * ks), bf, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sb2 + 32 * ct + 8 * g + 4 * lh);
+                const half4 rv = *reinterpret_cast<const half4*>(rbase + 8 * g);
+                half4 o;
+                f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                if (p.act) t = silu4_f(t);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)t[q] + (float)rv[q]);
+                *reinterpret_cast<half4*>(obase + 8 * g) = o;
+            }
+        }
+        __syncthreads();  // output tile complete
+#pragma unroll
+        for (int j = 0; j < NST; ++j)
+            if (oy0 + st_y[j] < p.H && ox0 + st_x[j] < p.W)
+                *reinterpret_cast<half8*>(ob + st_rel[j]) = *reinterpret_cast<const half8*>(sout + st_off[j]);
+    }
+}
+
+bool bneck_fused_supported(int C, int CH) { return (C == 32 && CH == 16) || (C == 64 && CH == 32); }
 
 int launch_bneck_fused(const BneckArgs& a, hipStream_t s) {
-    if (!bneck_fused_supported(a.C, a.CH)) BSY_FAIL(BSY_ERR_ARG, "bottleneck: unsupported widths (C %d, hidden %d): need (32, 16)", a.C, a.CH);
+    if (!bneck_fused_supported(a.C, a.CH)) BSY_FAIL(BSY_ERR_ARG, "bottleneck: unsupported widths (C %d, hidden %d): need (32, 16) or (64, 32)", a.C, a.CH);
     if (a.B <= 0 || a.H <= 0 || a.W <= 0) BSY_FAIL(BSY_ERR_ARG, "bottleneck: bad extent");
     if (((uintptr_t)a.src & 15) || ((uintptr_t)a.dst & 15) || (a.lds & 7) || (a.ldd & 7) || a.lds < a.C || a.ldd < a.C ||
         ((uintptr_t)a.w1 & 15) || ((uintptr_t)a.w2 & 15) || ((uintptr_t)a.b1 & 15) || ((uintptr_t)a.b2 & 15) ||
@@ -209,6 +381,12 @@ int launch_bneck_fused(const BneckArgs& a, hipStream_t s) {
     k.ntiles = (int)nt;
     k.magic_x = (unsigned)(((1ULL << 32) + k.tiles_x - 1) / k.tiles_x);
     k.magic_y = (unsigned)(((1ULL << 32) + k.tiles_y - 1) / k.tiles_y);
+    if (a.C == 64) {
+        const int grid = k.ntiles < 256 ? k.ntiles : 256;  // one 512-thread workgroup (143 KiB of LDS) per CU
+        hipLaunchKernelGGL((bneck_fused_wide_kernel<64, 32>), dim3(grid), dim3(512), 0, s, k);
+        HIP_TRY(hipGetLastError());
+        return BSY_OK;
+    }
     const int grid = k.ntiles < 768 ? k.ntiles : 768;  // 3 workgroups per CU
     hipLaunchKernelGGL((bneck_fused_kernel<32, 16>), dim3(grid), dim3(256), 0, s, k);
     HIP_TRY(hipGetLastError());

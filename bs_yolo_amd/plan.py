@@ -89,7 +89,7 @@ def c3k2_supported(cin: int, c: int, c2: int) -> bool:
 
 def bneck_supported(c: int, ch: int) -> bool:
     """Widths csrc/bneck_fused.hip accepts (mirror of bsy_bottleneck_fused_supported)."""
-    return (c, ch) == (32, 16)
+    return (c, ch) in ((32, 16), (64, 32))
 
 
 class Plan:

@@ -228,14 +228,17 @@ def test_stem_fused_rejects_unsupported():
         O.stem_fused(img, torch.zeros(32, 3, 3, 3), torch.zeros(32), torch.zeros(64, 32, 3, 3), torch.zeros(64))
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 40, 24), (3, 9, 13), (70, 8, 16), (1, 3, 5)])
-def test_bottleneck_fused_matches_unfused_and_oracle(shape):
-    """Bottleneck (block.py:3405-3419, k = (3,3), shortcut) as one launch (csrc/bneck_fused.hip): bit-identical to two
-    bsy_conv2d launches (the second with the residual) and equal to the fp32 reference with the hidden map rounded to
-    fp16.  Input and output are channel slices of one wider buffer, as inside C3k2's concat buffer; shapes cover
-    ragged tiles, maps smaller than one tile and more tiles than persistent workgroups."""
+@pytest.mark.parametrize("widths", [(32, 16), (64, 32)])
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 40, 24), (3, 9, 13), (70, 8, 16), (1, 3, 5), (300, 16, 16)])
+def test_bottleneck_fused_matches_unfused_and_oracle(shape, widths, monkeypatch):
+    """Bottleneck (block.py:3405-3419, k = (3,3), shortcut) as one launch (csrc/bneck_fused.hip; 32/16: YOLO11s model.2,
+    64/32: model.4 / model.16): bit-identical to two bsy_conv2d launches through the implicit-GEMM kernel (tap-major K order;
+    the second with the residual) and equal to the fp32 reference with the hidden map rounded to fp16.  Input and output are
+    channel slices of one wider buffer, as inside C3k2's concat buffer; shapes cover ragged tiles, maps smaller than one tile
+    and more tiles than persistent workgroups."""
     B, H, W = shape
-    c, ch, ld = 32, 16, 96
+    c, ch = widths
+    ld = 3 * c
     g = torch.Generator().manual_seed(21)
     buf = h16(torch.randn(B, H, W, ld, generator=g))
     w1 = h16(torch.randn(ch, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5)
@@ -243,19 +246,29 @@ def test_bottleneck_fused_matches_unfused_and_oracle(shape):
     w2 = h16(torch.randn(c, ch, 3, 3, generator=g) * (2.0 / (9 * ch)) ** 0.5)
     b2 = torch.randn(c, generator=g) * 0.2
     dbuf = buf.half().to(DEV)
-    x = dbuf[..., 32:64]
-    O.bottleneck_fused(x, w1, b1, w2, b2, out=dbuf[..., 64:96])
+    x = dbuf[..., c:2 * c]
+    O.bottleneck_fused(x, w1, b1, w2, b2, out=dbuf[..., 2 * c:])
     w1p, b1p = O.pack_conv_weight(w1, b1, DEV)
     w2p, b2p = O.pack_conv_weight(w2, b2, DEV)
     xc = x.contiguous()
+    monkeypatch.setenv("BSY_CONV_CFG", str((3 << 4) | 1))  # 128 x 64 implicit-GEMM tile: the tap-major K order the fused kernels share
     mid = O.conv2d_nhwc(xc, w1p, b1p, ch, 3, 1, True)
     two = O.conv2d_nhwc(mid, w2p, b2p, c, 3, 1, True, res=xc)
+    monkeypatch.delenv("BSY_CONV_CFG")
     torch.cuda.synchronize()
-    assert torch.equal(dbuf[..., 64:96], two)
-    assert torch.equal(dbuf[..., :64].cpu(), buf[..., :64].half())  # the other slices are untouched
-    xr = nchw(buf[..., 32:64])
+    assert torch.equal(dbuf[..., 2 * c:], two)
+    assert torch.equal(dbuf[..., :2 * c].cpu(), buf[..., :2 * c].half())  # the other slices are untouched
+    xr = nchw(buf[..., c:2 * c])
     ref = xr + F.silu(F.conv2d(h16(F.silu(F.conv2d(xr, w1, b1, 1, 1))), w2, b2, 1, 1))
     np.testing.assert_allclose(nchw(two.float().cpu()).numpy(), ref.numpy(), rtol=4e-3, atol=4e-3)
+
+
+def test_bottleneck_fused_rejects_unsupported():
+    assert L.lib.bsy_bottleneck_fused_supported(32, 16) == 1 and L.lib.bsy_bottleneck_fused_supported(64, 32) == 1
+    assert L.lib.bsy_bottleneck_fused_supported(64, 64) == 0 and L.lib.bsy_bottleneck_fused_supported(128, 64) == 0
+    x = torch.zeros(1, 8, 8, 128, dtype=torch.float16, device=DEV)
+    with pytest.raises(L.BsyError):
+        O.bottleneck_fused(x, torch.zeros(64, 128, 3, 3), torch.zeros(64), torch.zeros(128, 64, 3, 3), torch.zeros(128))
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 40, 24), (3, 9, 13), (300, 8, 16), (1, 3, 5), (2, 33, 47)])
@@ -320,13 +333,6 @@ def test_engine_c3k2_fusion_is_bit_identical():
         assert torch.equal(yf, yp) and all(torch.equal(a, b) for a, b in zip(rf, rp))
         fused.close()
         plain.close()
-
-
-def test_bottleneck_fused_rejects_unsupported():
-    assert L.lib.bsy_bottleneck_fused_supported(32, 16) == 1 and L.lib.bsy_bottleneck_fused_supported(64, 32) == 0
-    x = torch.zeros(1, 8, 8, 64, device=DEV).half()
-    with pytest.raises(L.BsyError):
-        O.bottleneck_fused(x, torch.zeros(32, 64, 3, 3), torch.zeros(32), torch.zeros(64, 32, 3, 3), torch.zeros(64))
 
 
 @pytest.mark.parametrize("kh,kw,stride,act", [(5, 5, 1, True), (7, 7, 1, True), (3, 3, 2, False), (1, 21, 1, False),
@@ -747,13 +753,15 @@ def test_engine_batch_independence_and_determinism():
 
 
 @pytest.mark.parametrize("scale", ["n", "s"])
-def test_engine_stem_fusion_is_bit_identical(scale):
+def test_engine_stem_fusion_is_bit_identical(scale, monkeypatch):
     """The OP_STEM / OP_BNECK / OP_C3K2 / OP_DWPW plan (fused launches, merged C3k branch convs) returns exactly what the plan of
     plain convs returns."""
     m = R.Model("yolo11", scale, 80, "detect")
     P = R.synth_params(m, 0)
     cfg = stock_cfg("yolo11", scale)
-    # autotune off: the tuner may pick kernels with different (equally valid) summation orders per plan
+    # autotune off: the tuner may pick kernels with different (equally valid) summation orders per plan; no patch kernel
+    # (chunk-major K order): the fused Bottleneck / C3k2 kernels sum tap-major like the implicit-GEMM kernel
+    monkeypatch.setenv("BSY_NO_PATCH", "1")
     fused = YoloEngine(cfg, P, fuse_stem=True, fuse_bneck=True, fuse_dwpw=True, autotune=False)
     plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False, fuse_tail=False, autotune=False)
     x = torch.rand(2, 3, 160, 96, generator=torch.Generator().manual_seed(3)).half().to(DEV)

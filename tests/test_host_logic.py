@@ -113,21 +113,22 @@ def test_stem_fusion_peephole():
 
 
 def test_bottleneck_fusion_peephole():
-    """C3k2's thin Bottleneck (32 -> 16 -> 32 with shortcut: model.2.m.0 of YOLO11s) becomes one OP_BNECK launch;
-    other widths keep two convs.  FLOP accounting and parameter records are unchanged."""
+    """C3k2's thin Bottlenecks with shortcut (32 -> 16 -> 32: model.2.m.0 of YOLO11s; 64 -> 32 -> 64: model.4.m.0 / model.16.m.0)
+    become one OP_BNECK launch each; other widths keep two convs.  FLOP accounting and parameter records are unchanged."""
     a = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_tail=False)
     b = Plan(stock_cfg("yolo11", "s"), 2, 640, 640, fuse_stem=False, fuse_bneck=True, fuse_tail=False)
     assert a.flops == b.flops and list(a.wrecs) == list(b.wrecs)
     fused = [o for o in b.ops if o["kind"] == L.OP_BNECK]
-    assert [o["name"] for o in fused] == ["model.2.m.0"] and len(b.ops) == len(a.ops) - 1
+    assert [o["name"] for o in fused] == ["model.2.m.0", "model.4.m.0", "model.16.m.0"] and len(b.ops) == len(a.ops) - 3
     o = fused[0]
     assert (o["src0"].C, o["mid_c"], o["dst"].C) == (32, 16, 32) and o["src0"].buf == o["dst"].buf  # slices of the concat buffer
     assert o["wkey"] == "model.2.m.0.cv1" and o["wkey2"] == "model.2.m.0.cv2" and L.OP_BNECK == 9
+    assert [(o["src0"].C, o["mid_c"]) for o in fused[1:]] == [(64, 32), (64, 32)]
     for r in ("cv1", "cv2"):
         ra, rb = a.wrecs[f"model.2.m.0.{r}"], b.wrecs[f"model.2.m.0.{r}"]
         assert (ra.kind, ra.cout, ra.cin, ra.k) == (rb.kind, rb.cout, rb.cin, rb.k)
     n = Plan(stock_cfg("yolo11", "n"), 1, 64, 64, fuse_bneck=True, fuse_tail=False)  # same widths one level down
-    assert [o["name"] for o in n.ops if o["kind"] == L.OP_BNECK] == ["model.4.m.0", "model.16.m.0"]
+    assert [o["name"] for o in n.ops if o["kind"] == L.OP_BNECK] == ["model.4.m.0", "model.13.m.0", "model.16.m.0", "model.19.m.0"]
     m = Plan(stock_cfg("yolo11", "m"), 1, 64, 64, fuse_bneck=True)  # C3k blocks, e = 1.0: not fused
     assert not any(o["kind"] == L.OP_BNECK for o in m.ops)
 
