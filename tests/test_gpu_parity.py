@@ -251,7 +251,7 @@ def test_bottleneck_fused_matches_unfused_and_oracle(shape, widths, monkeypatch)
     w1p, b1p = O.pack_conv_weight(w1, b1, DEV)
     w2p, b2p = O.pack_conv_weight(w2, b2, DEV)
     xc = x.contiguous()
-    monkeypatch.setenv("BSY_CONV_CFG", str((3 << 4) | 1))  # 128 x 64 implicit-GEMM tile: the tap-major K order the fused kernels share
+    monkeypatch.setenv("BSY_CONV_CFG", str(3 << 4))  # 128 x 64 implicit-GEMM tile, generic variant (any Cin % 8 == 0): the tap-major K order the fused kernels share
     mid = O.conv2d_nhwc(xc, w1p, b1p, ch, 3, 1, True)
     two = O.conv2d_nhwc(mid, w2p, b2p, c, 3, 1, True, res=xc)
     monkeypatch.delenv("BSY_CONV_CFG")
