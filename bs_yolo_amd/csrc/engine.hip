@@ -645,22 +645,29 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
         if (rc != BSY_OK) break;
         int cand[BSY_CONV_MAX_CFG];
         const int nc = conv_candidates(a, cand, BSY_CONV_MAX_CFG);
-        float best = 1e30f;
-        int best_cfg = cand[0];
-        for (int c = 0; c < nc && rc == BSY_OK; ++c) {
-            a.cfg = cand[c];
-            rc = launch_conv(a, s);  // warm-up
-            if (rc != BSY_OK) break;
-            for (int trial = 0; trial < 3 && rc == BSY_OK; ++trial) {  // best of three timed bursts of five launches: one burst is
-                if (hipEventRecord(e0, s) != hipSuccess) { rc = BSY_ERR_HIP; break; }  // noisy (r02: near-ties went to the slower kernel)
+        // Candidates are timed ROUND-ROBIN (three rounds; per round one warm-up + a burst of five launches each) and ranked by
+        // their best burst: clock ramps and neighbours' activity drift over a sweep, and timing every candidate in every phase
+        // of it keeps near-ties from going to whichever kernel happened to run in a quiet moment (r02: the same layer flipped
+        // between a 0.045 ms and a 0.056 ms configuration from box to box).
+        float best_of[BSY_CONV_MAX_CFG];
+        for (int c = 0; c < nc; ++c) best_of[c] = 1e30f;
+        for (int round = 0; round < 3 && rc == BSY_OK; ++round)
+            for (int c = 0; c < nc && rc == BSY_OK; ++c) {
+                a.cfg = cand[c];
+                rc = launch_conv(a, s);  // warm-up
+                if (rc != BSY_OK) break;
+                if (hipEventRecord(e0, s) != hipSuccess) { rc = BSY_ERR_HIP; break; }
                 for (int r = 0; r < 5 && rc == BSY_OK; ++r) rc = launch_conv(a, s);
                 if (rc != BSY_OK) break;
                 float ms = 0.f;
                 if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
                     hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = BSY_ERR_HIP; bsy_set_error("plan_autotune: event timing failed"); break; }
-                if (ms < best) { best = ms; best_cfg = cand[c]; }
+                if (ms < best_of[c]) best_of[c] = ms;
             }
-        }
+        float best = 1e30f;
+        int best_cfg = cand[0];
+        for (int c = 0; c < nc; ++c)
+            if (best_of[c] < best) { best = best_of[c]; best_cfg = cand[c]; }
         if (rc != BSY_OK) break;
         op.tuned_cfg = best_cfg + 1;
         a.cfg = best_cfg;
