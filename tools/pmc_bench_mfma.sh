@@ -9,11 +9,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_bench_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "rc=$?"
 python3 - $R ${1:-68} <<'PY' | tee $R/gpurun_out/mfma_util.txt
-import csv, glob, sys
+import csv, glob, os, sys
 R, NCONV = sys.argv[1], int(sys.argv[2])
-f = glob.glob(f"{R}/gpurun_out/pmc_bench_mfma/*/*counter_collection.csv")[0]
+f = sorted(glob.glob(f"{R}/gpurun_out/pmc_bench_mfma/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))
-CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")
+CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")
 disp = {}
 for r in rows:
     d = disp.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "t": int(r["Start_Timestamp"]), "dur": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
