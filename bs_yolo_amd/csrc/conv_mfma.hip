@@ -53,8 +53,10 @@ struct ConvK {
     void* y;
     void* raw;
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
-    int dbg;  // ablation switches for profiling (BSY_CONV_DBG; results are WRONG under them): 1 = no DMA, 4 = no epilogue,
-              // 64 = taps innermost in the K loop (the traffic experiment of DESIGN.md section 5)
+    int dbg;  // ablation switches for profiling (BSY_CONV_DBG; results are WRONG under them): 1 = no DMA, 4 = no epilogue
+    int korder;  // 0 = tap-major K walk (taps outer, channels inner: the packed order), 1 = chunk-major (BK channels of all
+                 // ntaps taps, then the next BK channels): a stride-2 3x3 tile then re-reads its input lines within
+                 // ntaps K-steps -- from the XCD's L2 -- instead of once per tap, Cin / BK K-steps apart (variant bit 4)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int bsy_zero_page[16];  // zero-initialised; source of padded taps
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
             }
 #pragma unroll
             for (int j = 0; j < WIW; ++j)
-                dma16_buf(rsw, 2u * woff[j], (unsigned)kt * (2u * BK), sW + (wave * WIW + j) * RPI * BK);
+                dma16_buf(rsw, 2u * woff[j], 2u * (unsigned)(s_tap * Cin + s_cb), sW + (wave * WIW + j) * RPI * BK);
         } else {
             const bool kvalid = tap < p.ntaps;
             const int kh = (KS == 1) ? 0 : tap / KS;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
 #define BSY_ADVANCE_K()                                                                          \
     do {                                                                                         \
         if (ALIGNED) {                                                                           \
-            if (p.dbg & 64) { /* experiment (timing only, wrong numerics): taps innermost */     \
+            if (p.korder) { /* chunk-major: all taps of BK channels, then the next BK channels */ \
                 if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += BK; }                               \
             } else {                                                                             \
                 s_cb += BK;                                                                      \
@@ -1374,10 +1376,13 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 //            10 = 8x16 px x 128 couts (2-stage weight ring), 11 = 8x16 px x 64 couts (variant 1: 3 stages, 2: 2 stages):
 //            patch-based 3x3 stride-1 kernel; 12 / 13 = the same with 6x20-pixel tiles (maps whose width is a multiple of 20)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
-//            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages
+//            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages; + 4 = the same with the chunk-major K walk
+//            (ConvK::korder; 3x3 layers, implicit-GEMM tiles: sums in another order -> equal to fp32 rounding, not bit for bit)
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
-    const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 15;
-    if (cfg < 0 || tile > 13 || var > 3) return false;
+    const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 3, korder = (cfg >> 2) & 3;
+    if (cfg < 0 || tile > 13 || korder > 1) return false;
+    // variant bit 4: chunk-major K walk -- implicit-GEMM tiles of aligned 3x3 layers only (a 1x1 layer has one tap)
+    if (korder && (tile >= 8 || var < 1 || a.ksize != 3)) return false;
     if (a.epi && tile >= 8) return false;           // fused decoder: implicit-GEMM kernel only
     if (a.epi == 3 && tile != 1) return false;      // DFL needs all 64 box couts in one wave: the 256 x 64 tile (4 x 1 waves, NT 2)
     if (tile >= 12) {  // 6x20-pixel patch tiles
@@ -1424,8 +1429,9 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
     // 6x20 tiles where they need fewer tiles than 8x16 ones (20 x 20 maps: 4 instead of 6 per image)
     const bool t20 = ceil_div(a.W, 20) * ceil_div(a.H, 6) < ceil_div(a.W, 16) * ceil_div(a.H, 8);
     if (!a.epi && a.ksize == 3 && a.stride == 1 && a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) add(t20 ? 13 : 11, 2);  // patch kernel
-    if (!a.epi && !(a.Cout & 255) && aligned64 && M >= 16384) add(7, 3);  // 256 x 256, 64-deep K-steps
-    add(tile, aligned64 ? 3 : 1);
+    const int km = (a.ksize == 3 && a.stride == 2 && !getenv("BSY_NO_KORDER")) ? 4 : 0;  // stride-2 3x3 layers walk K chunk-major (see ConvK::korder)
+    if (!a.epi && !(a.Cout & 255) && aligned64 && M >= 16384) add(7, 3 | km);  // 256 x 256, 64-deep K-steps
+    add(tile, (aligned64 ? 3 : 1) | km);
     static const int tn[10] = {32, 64, 128, 64, 128, 128, 64, 256, 128, 64};
     for (int t = 0; t < 10; ++t) {
         if (tn[t] >= 2 * round_up(a.Cout, 32)) continue;      // more than half of the cout tile would be padding
@@ -1434,6 +1440,8 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (t == 7 && M < 16384) continue;
         if (t >= 8 && (M < 65536 || getenv("BSY_NO_PERSIST"))) continue;                      // persistent tiles need several tiles per workgroup
         for (int v = 1; v <= 3; ++v) add(t, v);
+        if (km && t < 8)  // chunk-major K walk: the taps' re-reads of a stride-2 layer stay in L2
+            for (int v = 1; v <= 3; ++v) add(t, v | 4);
     }
     if (a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) {  // 3x3 s1 patch kernel
         add(10, 1); add(11, 1); add(11, 2);
@@ -1495,7 +1503,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         conv_candidates(a, list, BSY_CONV_MAX_CFG);
         cfg = list[0];
     }
-    const int tile = cfg >> 4, var = cfg & 15;
+    const int tile = cfg >> 4, var = cfg & 3;
+    k.korder = (cfg >> 2) & 1;
     // tile: 0 = 256x32, 1 = 256x64, 2 = 128x128, 3 = 128x64, 4 = 256x128 (8 waves), 5 = 64x128, 6 = 64x64
     // var : 0 = generic BK32 S3, 1 = aligned BK32 S3, 2 = aligned BK32 S2, 3 = aligned BK64 S2
 #define BSY_VAR(KS_, WM_, WN_, MT_, NT_)                                                  \

@@ -669,6 +669,11 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
         for (int c = 0; c < nc; ++c)
             if (best_of[c] < best) { best = best_of[c]; best_cfg = cand[c]; }
         if (rc != BSY_OK) break;
+        // near-tie between the two K walks of one tile: take the chunk-major one (variant bit 4) -- a stride-2 3x3 layer then
+        // fetches its input about once instead of 2.25 times, whatever the stopwatch says about 2 %
+        if (!(best_cfg & 4))
+            for (int c = 0; c < nc; ++c)
+                if (cand[c] == (best_cfg | 4) && best_of[c] <= 1.02f * best) { best_cfg = cand[c]; break; }
         op.tuned_cfg = best_cfg + 1;
         a.cfg = best_cfg;
         rc = launch_conv(a, s);

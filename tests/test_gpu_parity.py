@@ -132,6 +132,41 @@ def test_conv_patch_kernel_matches_oracle(case, monkeypatch):
     assert d.max().item() <= 2e-3 * max(1.0, base.float().abs().max().item()) and (d > 0).float().mean().item() < 0.05
 
 
+KORDER_CASES = [
+    # B, H, W, cin, cout, stride, cfg     cfg = tile << 4 | variant; variant + 4 = chunk-major K walk (3x3 layers, implicit-GEMM tiles)
+    (2, 40, 40, 128, 128, 2, 0x25),       # model.3's shape class: 128 x 128 tile, BK 32 / 3 stages
+    (1, 33, 31, 64, 256, 2, 0x77),        # 256 x 256 tile, BK 64; odd extents
+    (2, 20, 20, 256, 256, 2, 0x27),       # BK 64, 4 chunks x 9 taps
+    (3, 17, 23, 32, 48, 2, 0x16),         # one chunk: both walks visit the same K-steps; ragged cout, 2 stages
+    (2, 24, 24, 96, 64, 1, 0x35),         # stride 1 is valid too (the tuner only offers it for stride 2)
+]
+
+
+@pytest.mark.parametrize("case", KORDER_CASES)
+def test_conv_chunk_major_k_walk_matches_oracle(case, monkeypatch):
+    """Variant bit 4 of the implicit-GEMM configurations (conv_mfma.hip, ConvK::korder): all nine taps of a BK-channel chunk,
+    then the next chunk -- another summation order, so equal to the tap-major walk to fp32 rounding (<= 1 fp16 ulp)."""
+    B, H, W, cin, cout, s, cfg = case
+    g = torch.Generator().manual_seed(cfg * 1000 + cin)
+    x = h16(torch.randn(B, cin, H, W, generator=g))
+    w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.5
+    y = F.silu(F.conv2d(x, w, b, s, 1))
+    wp, bp = O.pack_conv_weight(w, b, DEV)
+    xd = nhwc(x).half().to(DEV)
+    monkeypatch.setenv("BSY_CONV_CFG", str(cfg & ~4))
+    base = O.conv2d_nhwc(xd, wp, bp, cout, 3, s, True)
+    monkeypatch.setenv("BSY_CONV_CFG", str(cfg))
+    out = O.conv2d_nhwc(xd, wp, bp, cout, 3, s, True)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("BSY_CONV_CFG")
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), y.numpy(), rtol=2e-3, atol=2e-3)
+    d = (out.float() - base.float()).abs()
+    assert d.max().item() <= 2e-3 * max(1.0, base.float().abs().max().item()) and (d > 0).float().mean().item() < 0.05
+    if cin <= 32:
+        assert torch.equal(out, base)  # a single chunk: identical K-steps in identical order
+
+
 def test_conv_two_sources_and_upsample():
     """Virtual Concat + virtual nn.Upsample: cv1(cat(upsample(a), b)) (yolo11 head layers 11-13)."""
     g = torch.Generator().manual_seed(3)
@@ -514,7 +549,10 @@ def test_engine_matches_reference_golden(tag, dtype):
         assert es.max() < k * 1e-2 and q(es) < k * 5e-3 and es.mean() < k * 1e-4, (es.max(), q(es), es.mean())
         assert eb.max() < k * 1.0 and q(eb) < k * 0.8 and eb.mean() < k * 0.05, (eb.max(), q(eb), eb.mean())
         qs, qb = np.abs(y[:, 4:4 + nc] - yq[:, 4:4 + nc]), np.abs(y[:, :4] - yq[:, :4])
-        assert qs.max() < k * 1e-2 and q(qs) < k * 5e-3 and qs.mean() < k * 5e-5, (qs.max(), q(qs), qs.mean())
+        # mean vs the fp16-emulating oracle: 1e-4 like the bound above -- on the 126-anchor BS-YOLO11s case the statistic moved from
+        # 1.4e-4 to 1.7e-4 when the stride-2 convs changed their fp32 summation ORDER (chunk-major K walk): it measures how these
+        # random weights amplify 1-ulp flips, not a kernel's accuracy (the per-layer tests do that)
+        assert qs.max() < k * 1e-2 and q(qs) < k * 5e-3 and qs.mean() < k * 1e-4, (qs.max(), q(qs), qs.mean())
         assert qb.max() < k * 1.0 and q(qb) < k * 0.8 and qb.mean() < k * 0.03, (qb.max(), q(qb), qb.mean())
         if y.shape[1] > 4 + nc:  # mask coefficients (raw conv outputs, O(1..10) magnitude)
             em = np.abs(y[:, 4 + nc:] - yref[:, 4 + nc:])
