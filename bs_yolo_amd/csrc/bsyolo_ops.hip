@@ -652,8 +652,16 @@ __global__ __launch_bounds__(256) void ela_apply_kernel(const half_t* __restrict
 size_t ela_scratch_floats(int H, int W, int C) { return (size_t)(2 * (H + W) + 2) * C; }
 
 // means in the scratch -> gates in the scratch (f32 only: shared by the fp16 path and the fp32 correctness mode, ref32.hip)
+// GroupNorm(max(1, C // 16), C) (ELA.py:70): channels per group -- 16 when C is a multiple of 16, otherwise C / (C // 16)
+// (C = 40: 2 groups of 20; C = 24: one group of 24); 0 when the group count does not divide C (the reference's constructor raises)
+static int ela_group_size(int C) {
+    const int groups = C >= 16 ? C / 16 : 1;
+    return C % groups ? 0 : C / groups;
+}
+
 int launch_ela_gate(const ElaArgs& a, hipStream_t s) {
-    const int gsz = a.C >= 16 ? 16 : a.C;
+    const int gsz = ela_group_size(a.C);
+    if (gsz <= 0 || gsz > 256) BSY_FAIL(BSY_ERR_ARG, "ela: %d channels do not split into %d GroupNorm groups", a.C, a.C / 16);
     const int Lmax = a.H > a.W ? a.H : a.W;
     const size_t lds = ((size_t)Lmax * gsz + 512) * sizeof(float);
     if (lds > 64 * 1024) BSY_FAIL(BSY_ERR_ARG, "ela: map side %d too long for the gate kernel", Lmax);
@@ -665,11 +673,11 @@ int launch_ela_gate(const ElaArgs& a, hipStream_t s) {
 
 int launch_ela(const ElaArgs& a, hipStream_t s) {
     if (!a.src || !a.dst || !a.scratch || !a.wsp || !a.wch || !a.gnw || !a.gnb) BSY_FAIL(BSY_ERR_ARG, "ela: null pointer");
-    if ((a.C & 15) || (a.lds & 7) || (a.ldd & 7) || (((uintptr_t)a.src | (uintptr_t)a.dst) & 15) || a.k < 1 || !(a.k & 1) || a.k > 15 ||
+    if ((a.C & 7) || (a.lds & 7) || (a.ldd & 7) || (((uintptr_t)a.src | (uintptr_t)a.dst) & 15) || a.k < 1 || !(a.k & 1) || a.k > 15 ||
         a.B <= 0 || a.H <= 0 || a.W <= 0)
-        BSY_FAIL(BSY_ERR_ARG, "ela: bad layout (C must be a multiple of 16, odd kernel <= 15)");
-    const int gsz = a.C >= 16 ? 16 : a.C;  // GroupNorm(max(1, C // 16), C)
-    const int groups = a.C / gsz;
+        BSY_FAIL(BSY_ERR_ARG, "ela: bad layout (C must be a multiple of 8, odd kernel <= 15)");
+    const int gsz = ela_group_size(a.C);
+    if (gsz <= 0) BSY_FAIL(BSY_ERR_ARG, "ela: %d channels do not split into %d GroupNorm groups", a.C, a.C / 16);
     const size_t per_img = ela_scratch_floats(a.H, a.W, a.C);
     const int Lmax = a.H > a.W ? a.H : a.W;
     const size_t lds = ((size_t)Lmax * gsz + 512) * sizeof(float);

@@ -325,7 +325,7 @@ int launch_mul32(const float* x, int ldx, const float* y, int ldy, long long npi
 }
 
 int launch_ela32(const ElaArgs& a, const float* src, float* dst, hipStream_t s) {
-    if (!src || !dst || !a.scratch || !a.wsp || !a.wch || !a.gnw || !a.gnb || (a.C & 15) || a.k < 1 || !(a.k & 1) || a.k > 15)
+    if (!src || !dst || !a.scratch || !a.wsp || !a.wch || !a.gnw || !a.gnb || (a.C & 7) || a.k < 1 || !(a.k & 1) || a.k > 15)
         BSY_FAIL(BSY_ERR_ARG, "ela32: bad argument");
     const size_t per_img = ela_scratch_floats(a.H, a.W, a.C);
     const int Lmax = a.H > a.W ? a.H : a.W;

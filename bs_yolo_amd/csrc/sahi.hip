@@ -19,6 +19,11 @@
 //                            inside the chunk by the same parallel fixed point as nms_greedy_kernel.
 //     4. sahi_merge_kernel   one wavefront per kept box walks its members in score order and applies has_match
 //                            (float64, metric > thr against the GROWING box) + box union / max score.
+//     3'. sahi_nmm_kernel   (postprocess NMM) sahi's non-greedy `nmm` assignment: the predictions of a class take turns in score
+//                            order (one workgroup, one barrier per turn); a turn tests the prediction against every other
+//                            box of the class in parallel and hands its unassigned matches to its keeper (itself if it has
+//                            none).  Members remember the turn that assigned them: the merge walks them in (turn, ascending
+//                            score) order -- the order sahi's lists are appended in.
 // No host synchronisation anywhere; `out_count` stays on the device.
 #include "common.h"
 
@@ -118,6 +123,10 @@ struct SahiK {
     int32_t* kcls;         // [cap]
     int32_t* kpos;         // [cap]  kept slot -> sorted position
     int32_t* klast;        // [cap]  kept slot -> last sorted position that belongs to it
+    int32_t* assigned;     // [cap]  NMM: sorted position -> sorted position of its keeper (-1: none yet); aliases kbox
+    int32_t* turn;         // [cap]  NMM: the turn (sorted position of the prediction being processed) that assigned it
+    int32_t* iskeep;       // [cap]  NMM: 1 = a key of keep_to_merge_list
+    int32_t* mcls;         // [cap]  NMM: class used for matching (0 when class-agnostic)
     int32_t* n_cand;       // [0] candidates, [1] kept
     float* out;            // (max_out, 6)
     int32_t* out_count;
@@ -333,6 +342,95 @@ __global__ __launch_bounds__(256) void sahi_greedy_kernel(const SahiK p) {
     }
 }
 
+// sahi's non-greedy nmm (sahi/postprocess/combine.py `nmm`, restated in oracle/sahi_ref.py nmm()).  One workgroup: the
+// assignment is a chain over the predictions in score order; every turn is parallel over the other boxes of the class.
+__global__ __launch_bounds__(1024) void sahi_nmm_kernel(const SahiK p) {
+    __shared__ int sh_end, sh_cnt[16], sh_base;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.n_cand[0];
+    for (int i = tid; i < n; i += nt) {
+        const u64 k = p.keys[i];
+        const int f = (int)(0xFFFFu - (unsigned)(k & 0xFFFFull));
+        const float* fb = p.fbox + (size_t)f * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p.sbox[(size_t)i * 4 + e] = fb[e];
+        p.sscore[i] = __uint_as_float((unsigned)(k >> 16));
+        const int cls = (int)p.det[(size_t)f * p.row + 5];
+        p.scls[i] = cls;
+        p.mcls[i] = p.agnostic ? 0 : cls;
+        p.assigned[i] = -1;
+        p.turn[i] = 0;
+        p.iskeep[i] = 0;
+    }
+    __syncthreads();
+    int seg_s = 0, seg_e = 0;
+    for (int i = 0; i < n; ++i) {
+        if (i == seg_e) {  // uniform: next class segment [i, first position of another class)
+            if (tid == 0) sh_end = n;
+            __syncthreads();
+            const int c = p.mcls[i];
+            for (int j = i + 1 + tid; j < n; j += nt)
+                if (p.mcls[j] != c) { atomicMin(&sh_end, j); break; }  // classes ascend: a thread's first mismatch is its lowest
+            __syncthreads();
+            seg_s = i;
+            seg_e = sh_end;
+            __syncthreads();
+        }
+        const int a_i = p.assigned[i];
+        const bool first = a_i < 0;  // "pred_ind not in merge_to_keep": it becomes a keeper
+        const int keep = first ? i : a_i;
+        if (first && tid == 0) p.iskeep[i] = 1;
+        float pb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pb[e] = p.sbox[(size_t)i * 4 + e];
+        const float pa = (pb[2] - pb[0]) * (pb[3] - pb[1]);
+        for (int j = seg_s + tid; j < seg_e; j += nt) {
+            if (j == i || p.assigned[j] >= 0 || (!first && p.iskeep[j])) continue;
+            float cb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cb[e] = p.sbox[(size_t)j * 4 + e];
+            const float ca = (cb[2] - cb[0]) * (cb[3] - cb[1]);
+            if (nmm_matched(pb, pa, cb, ca, p.metric, p.thr)) { p.assigned[j] = keep; p.turn[j] = i; }
+        }
+        __syncthreads();  // position i + 1 reads what this turn assigned
+    }
+    // kept slots in position order (class ascending, score descending): chunked prefix count of iskeep
+    if (tid == 0) sh_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += nt) {
+        const int i = c0 + tid;
+        const bool kp = i < n && p.iskeep[i];
+        const u64 b = __ballot(kp);
+        if (lane == 0) sh_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int before = sh_base;
+        for (int w = 0; w < wave; ++w) before += sh_cnt[w];
+        if (kp) {
+            const int slot = before + __popcll(b & ((1ull << lane) - 1ull));
+            p.keeper[i] = slot;
+            p.kpos[slot] = i;
+            p.klast[slot] = i;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = sh_base;
+            for (int w = 0; w < nt / 64; ++w) t += sh_cnt[w];
+            sh_base = t;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += nt)
+        if (!p.iskeep[i]) {
+            const int slot = p.keeper[p.assigned[i]];  // every non-keeper was assigned (its own turn would have made it a keeper)
+            p.keeper[i] = slot;
+            atomicMax(p.klast + slot, i);
+        }
+    if (tid == 0) {
+        p.n_cand[1] = sh_base;
+        *p.out_count = sh_base < p.max_out ? sh_base : p.max_out;
+    }
+}
+
 // has_match: float64 metric of the growing merged box against a member, "> thr".
 __device__ __forceinline__ bool has_match64(const double* a, const double* b, int metric, double thr) {
     const double a1 = (a[2] - a[0]) * (a[3] - a[1]), a2 = (b[2] - b[0]) * (b[3] - b[1]);
@@ -354,7 +452,38 @@ __global__ __launch_bounds__(256) void sahi_merge_kernel(const SahiK p) {
         for (int e = 0; e < 4; ++e) cur[e] = (double)p.sbox[(size_t)pos0 * 4 + e];
         float score = p.sscore[pos0];
         int cls = p.scls[pos0];
-        if (p.do_merge) {
+        if (p.do_merge == 2) {  // NMM: members in (turn, ascending score = descending position) order
+            const int last = p.klast[k];
+            bool have_prev = false;
+            u64 prev = 0ull;
+            for (;;) {
+                u64 best = ~0ull;
+                for (int pos = pos0 + 1 + lane; pos <= last; pos += 64) {
+                    if (p.keeper[pos] != k) continue;
+                    const u64 key = ((u64)(unsigned)p.turn[pos] << 32) | (u64)(0xFFFFFFFFu - (unsigned)pos);
+                    if ((!have_prev || key > prev) && key < best) best = key;
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const u64 o = ((u64)(unsigned)__shfl_xor((int)(best >> 32), d) << 32) | (u64)(unsigned)__shfl_xor((int)(best & 0xFFFFFFFFull), d);
+                    if (o < best) best = o;
+                }
+                if (best == ~0ull) break;  // wave-uniform
+                prev = best;
+                have_prev = true;
+                const int q = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+                double cb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cb[e] = (double)p.sbox[(size_t)q * 4 + e];
+                if (has_match64(cur, cb, p.metric, (double)p.thr)) {
+                    const float cs = p.sscore[q];
+                    if (!(score > cs)) cls = p.scls[q];
+                    score = fmaxf(score, cs);
+                    cur[0] = fmin(cur[0], cb[0]); cur[1] = fmin(cur[1], cb[1]);
+                    cur[2] = fmax(cur[2], cb[2]); cur[3] = fmax(cur[3], cb[3]);
+                }
+            }
+        } else if (p.do_merge) {
             const int last = p.klast[k];
             for (int base = pos0 + 1; base <= last; base += 64) {
                 const int pos = base + lane;
@@ -401,7 +530,7 @@ extern "C" int bsy_sahi_merge(const float* det, const int32_t* counts, const flo
                               float full_h, float* out, int32_t* out_count, int max_out, void* workspace,
                               size_t workspace_bytes, bsy_stream stream) {
     if (!det || !counts || !shift || !out || !out_count || T <= 0 || max_det <= 0 || row < 6 || max_out <= 0 ||
-        (match_metric != 0 && match_metric != 1))
+        (match_metric != 0 && match_metric != 1) || do_merge < 0 || do_merge > 2)
         BSY_FAIL(BSY_ERR_ARG, "bsy_sahi_merge: bad argument");
     if ((long long)T * max_det > 65536) BSY_FAIL(BSY_ERR_ARG, "bsy_sahi_merge: more than 65536 detection slots");
     if (!workspace || workspace_bytes < bsy_sahi_merge_workspace_bytes(T, max_det))
@@ -419,7 +548,9 @@ extern "C" int bsy_sahi_merge(const float* det, const int32_t* counts, const flo
     p.keys = (u64*)w; w += cap * 8;
     p.fbox = (float*)w; w += cap * 16;
     p.sbox = (float*)w; w += cap * 16;
-    p.kbox = (float*)w; w += cap * 16;
+    p.kbox = (float*)w;  // the NMM assignment keeps no box copies: its four per-position arrays live here
+    p.assigned = (int32_t*)w; p.turn = p.assigned + cap; p.iskeep = p.turn + cap; p.mcls = p.iskeep + cap;
+    w += cap * 16;
     p.sscore = (float*)w; w += cap * 4;
     p.karea = (float*)w; w += cap * 4;
     p.scls = (int32_t*)w; w += cap * 4;
@@ -432,7 +563,8 @@ extern "C" int bsy_sahi_merge(const float* det, const int32_t* counts, const flo
     const int slots = T * max_det;
     hipLaunchKernelGGL(sahi_gather_kernel, dim3((slots + 255) / 256), dim3(256), 0, s, p);
     hipLaunchKernelGGL(sahi_sort_kernel, dim3(1), dim3(1024), 0, s, p);
-    hipLaunchKernelGGL(sahi_greedy_kernel, dim3(1), dim3(256), 0, s, p);
+    if (do_merge == 2) hipLaunchKernelGGL(sahi_nmm_kernel, dim3(1), dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL(sahi_greedy_kernel, dim3(1), dim3(256), 0, s, p);
     hipLaunchKernelGGL(sahi_merge_kernel, dim3(256), dim3(256), 0, s, p);
     HIP_TRY(hipGetLastError());
     return BSY_OK;

@@ -384,8 +384,8 @@ class Plan:
     def ela(self, name: str, x: T) -> T:
         """nn/Addmodules/ELA.py:33-101."""
         assert not x.up
-        if x.C % 16:
-            raise NotImplementedError(f"ELA on {x.C} channels: must be a multiple of 16 (GroupNorm groups of 16)")
+        if x.C % 8 or x.C % max(1, x.C // 16):  # GroupNorm(max(1, C // 16), C): the reference's constructor needs the second
+            raise NotImplementedError(f"ELA on {x.C} channels: must be a multiple of 8 that splits into {x.C // 16} groups")
         k = int(abs((math.log(x.C, 2) + 1) / 2))
         k = k if k % 2 else k + 1
         key = self._wrec(name, name=name, kind="ela", cout=x.C, cin=1, k=k)

@@ -7,7 +7,8 @@ Names and argument meaning below follow sahi 0.11.x so those two scripts read th
 
   * ``get_slice_bboxes``       sahi.slicing.get_slice_bboxes (host integer arithmetic, explicit slice size)
   * ``slice_image``            sahi.slicing.slice_image + the predictor's preprocess of every crop -> one HIP kernel
-  * ``postprocess``            sahi.postprocess.combine.GreedyNMMPostprocess / NMSPostprocess -> four HIP kernels
+  * ``postprocess``            sahi.postprocess.combine.GreedyNMMPostprocess / NMMPostprocess / NMSPostprocess (LSNMS runs as NMS)
+                               -> four HIP kernels
   * ``get_sliced_prediction``  sahi.predict.get_sliced_prediction: slice -> forward + NMS per tile batch ->
                                (optional full-image prediction) -> cross-tile merge.  With torch.distributed
                                initialised the tiles are sharded over the ranks (parallel.shard_bounds), the fixed-size
@@ -29,6 +30,9 @@ from .nms import _workspace, nms_batched, scale_boxes_batched
 from .parallel import gather_detections, shard_bounds
 
 METRICS = {"IOU": 0, "IOS": 1}
+# sahi.predict POSTPROCESS_NAME_TO_CLASS -> bsy_sahi_merge's do_merge.  LSNMS (the `lsnms` package: an R-tree accelerated NMS,
+# IOU only) keeps what NMS keeps, so it runs the NMS kernels.
+_POSTPROCESS = {"NMS": 0, "LSNMS": 0, "GREEDYNMM": 1, "NMM": 2}
 
 
 def get_slice_bboxes(image_height: int, image_width: int, slice_height: int, slice_width: int,
@@ -97,8 +101,10 @@ def postprocess(det: torch.Tensor, counts: torch.Tensor, shifts, postprocess_typ
     tile origins (x0, y0) -> (out (max_out, 6) fp32, out_count () int32), both on the device, no host sync."""
     if not det.is_cuda:
         raise RuntimeError("bs_yolo_amd.sahi needs GPU tensors (no CPU fallback)")
-    if postprocess_type not in ("GREEDYNMM", "NMS"):
-        raise NotImplementedError(f"postprocess_type {postprocess_type!r} (sahi's NMM / LSNMS are not restated)")
+    if postprocess_type not in _POSTPROCESS:
+        raise ValueError(f"postprocess_type {postprocess_type!r}: one of {sorted(_POSTPROCESS)}")
+    if postprocess_type == "LSNMS" and match_metric != "IOU":
+        raise NotImplementedError("LSNMS: IOU only (as in sahi)")
     if match_metric not in METRICS:
         raise ValueError(f"match_metric {match_metric!r}")
     det = det.contiguous().float()
@@ -115,7 +121,7 @@ def postprocess(det: torch.Tensor, counts: torch.Tensor, shifts, postprocess_typ
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     L.check(L.lib.bsy_sahi_merge(C.c_void_p(det.data_ptr()), C.c_void_p(counts.data_ptr()), C.c_void_p(sh.data_ptr()), T,
                                  max_det, row, METRICS[match_metric], float(match_threshold), int(bool(class_agnostic)),
-                                 int(postprocess_type == "GREEDYNMM"), fw, fh, C.c_void_p(out.data_ptr()),
+                                 _POSTPROCESS[postprocess_type], fw, fh, C.c_void_p(out.data_ptr()),
                                  C.c_void_p(n.data_ptr()), max_out, C.c_void_p(ws.data_ptr()), ws.numel(), stream))
     return out, n
 

@@ -342,8 +342,10 @@ int bsy_ap_per_class(const uint8_t* tp, const float* conf, const float* pred_cls
  *   layout bsy_nms writes;  shift (T, 2) f32 DEVICE = tile origin (x0, y0);  boxes are clamped to >= 0 and to
  *   (full_w, full_h) when those are > 0, dropped unless x1 < x2 and y1 < y2, then shifted.
  *   match_metric 0 = IOU, 1 = IOS; a lower-scored box joins the first kept box (score order, same class unless
- *   class_agnostic) with metric >= match_threshold; do_merge != 0 (GREEDYNMM) folds members whose metric against the
- *   growing merged box is > match_threshold into it (box union, max score), do_merge == 0 (NMS) only drops them.
+ *   class_agnostic) with metric >= match_threshold; do_merge == 1 (GREEDYNMM) folds members whose metric against the
+ *   growing merged box is > match_threshold into it (box union, max score), do_merge == 0 (NMS / LSNMS) only drops them;
+ *   do_merge == 2 (NMM) assigns members the non-greedy way instead -- every box, in score order, hands the unassigned
+ *   boxes it matches to its own keeper -- and folds them in the order they were assigned.
  *   out (max_out, 6) f32 in class-ascending (unless agnostic), score-descending keep order; out_count DEVICE int32 =
  *   min(kept, max_out).  T * max_det <= 65536.  No host synchronisation.
  * --------------------------------------------------------------------------------------------------------- */

@@ -21,6 +21,12 @@ the published algorithm of sahi 0.11.x from its documentation:
                                 `calculate_box_union`, `get_merged_score` (max), `get_merged_category` (the
                                 higher score's; the candidate's on a tie)
   * nms                      -- sahi/postprocess/combine.py `nms` / `batched_nms` (same keep set, no merging)
+  * nmm                      -- sahi/postprocess/combine.py `nmm` / `batched_nmm` + `NMMPostprocess.__call__` (the non-greedy
+                                merge: every prediction, in score order, hands the boxes it matches to ITS keeper, so a
+                                keeper also collects boxes it does not overlap itself; merging as above, in list order)
+  * LSNMS                    -- `LSNMSPostprocess` calls the `lsnms` package (an R-tree accelerated non-maximum suppression,
+                                IOU only, sahi marks it experimental): same keep set as `nms` with the IOU metric, which is
+                                what postprocess() runs for it; like sahi it refuses the IOS metric
 sahi's defaults (predict(): postprocess_type GREEDYNMM, match metric IOS, threshold 0.5, class_agnostic False) are
 the defaults here.  Score ties: sahi's `scores.argsort()` is unstable; here ties go to the lower flat index
 (tile-major, row-minor), which is what both this file and the HIP path implement.
@@ -116,6 +122,38 @@ def greedy_nmm(boxes, metric="IOS", threshold=0.5):
     return keep_to_merge
 
 
+def nmm(boxes, metric="IOS", threshold=0.5):
+    """boxes (n, 6) f32 -> {keep_index: [merge candidates in the order sahi's loop appends them]}, keeps in descending score
+    order.  Prediction i (descending score; ties by lower index) matches every OTHER box whose metric is not < threshold;
+    if i has no keeper it becomes one and takes its unassigned matches, otherwise its keeper takes those of them that are
+    neither keepers nor assigned.  Within one step the matches are appended in ascending score order (sahi flips the
+    descending list)."""
+    n = boxes.shape[0]
+    order = sorted(range(n), key=lambda i: (-float(boxes[i, 4]), i))
+    keep_to_merge, merge_to_keep = {}, {}
+    for pred in order:
+        others = [o for o in order if o != pred]
+        if not others:
+            if pred not in merge_to_keep:
+                keep_to_merge[pred] = []
+            break
+        v = _metric32(boxes[pred], boxes[others], metric)
+        matched = [o for o, u in zip(others, v < f32(threshold)) if not u][::-1]
+        if pred not in merge_to_keep:
+            keep_to_merge[pred] = []
+            for m in matched:
+                if m not in merge_to_keep:
+                    keep_to_merge[pred].append(m)
+                    merge_to_keep[m] = pred
+        else:
+            keep = merge_to_keep[pred]
+            for m in matched:
+                if m not in keep_to_merge and m not in merge_to_keep:
+                    keep_to_merge[keep].append(m)
+                    merge_to_keep[m] = keep
+    return keep_to_merge
+
+
 def _metric64(b1, b2, metric):
     """has_match's float64 metric (numpy on Python floats)."""
     b1 = np.asarray(b1[:4], dtype=np.float64); b2 = np.asarray(b2[:4], dtype=np.float64)
@@ -133,6 +171,12 @@ def postprocess(boxes, postprocess_type="GREEDYNMM", metric="IOS", threshold=0.5
     """boxes (N, 6) f32 full-image detections -> (K, 6) f32.  Order: class ascending (unless class_agnostic), score
     descending inside -- the iteration order of sahi's keep_to_merge_list."""
     boxes = np.asarray(boxes, dtype=f32).reshape(-1, 6)
+    if postprocess_type not in ("GREEDYNMM", "NMM", "NMS", "LSNMS"):
+        raise ValueError(postprocess_type)
+    if postprocess_type == "LSNMS":
+        if metric != "IOU":
+            raise NotImplementedError("LSNMS: IOU only (as in sahi)")
+        postprocess_type = "NMS"
     groups = [np.arange(boxes.shape[0])] if class_agnostic else \
         [np.nonzero(boxes[:, 5] == c)[0] for c in np.unique(boxes[:, 5])]
     out = []
@@ -140,9 +184,10 @@ def postprocess(boxes, postprocess_type="GREEDYNMM", metric="IOS", threshold=0.5
         if g.size == 0:
             continue
         sub = boxes[g]
-        for keep, cands in greedy_nmm(sub, metric, threshold).items():
+        assign = nmm if postprocess_type == "NMM" else greedy_nmm
+        for keep, cands in assign(sub, metric, threshold).items():
             cur = [float(v) for v in sub[keep]]
-            if postprocess_type == "GREEDYNMM":
+            if postprocess_type in ("GREEDYNMM", "NMM"):
                 for c in cands:
                     cand = [float(v) for v in sub[c]]
                     if _metric64(cur, cand, metric) > threshold:

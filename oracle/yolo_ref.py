@@ -682,7 +682,7 @@ class Model:
             chans.append(c2)
         hf = HEAD_FROM[family]
         hch = [chans[x] for x in hf]
-        self.strides = [8.0, 16.0, 32.0]  # tasks.py:333-344 stride probe result for these graphs
+        self.strides = self._probe_strides(hf)
         hname = f"model.{len(self.layers)}"
         if task == "detect":
             head = Detect(hname, nc, hch, legacy, self.strides)
@@ -693,6 +693,22 @@ class Model:
         self.head = head
         self.save = sorted({x % len(self.layers) for f, _ in self.layers for x in ([f] if isinstance(f, int) else f)
                             if x != -1})
+
+    def _probe_strides(self, hf, s=256):
+        """tasks.py:333-344: the reference sends a 256 x 256 zero image through the graph and sets stride = 256 / height of every
+        Detect input.  Heights follow from the layers' conv arithmetic alone (8, 16, 32 for the stock graphs)."""
+        hs: List[int] = []
+        for f, m in self.layers:
+            h_in = s if not hs else hs[f if isinstance(f, int) else f[0]]
+            conv = m.cv2 if isinstance(m, SCDown) else m  # SCDown: its depthwise conv carries the stride
+            if m == "up":
+                h = 2 * h_in
+            elif isinstance(conv, Conv):
+                h = (h_in + 2 * conv.p - conv.k) // conv.s + 1
+            else:
+                h = h_in
+            hs.append(h)
+        return [float(s) / hs[x] for x in hf]
 
     def param_specs(self) -> List[Tuple[str, Tuple[int, ...]]]:
         out = []

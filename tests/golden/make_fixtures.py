@@ -275,6 +275,9 @@ def bsyolo_module_fixtures():
     add("msca", RefMSCA(32), rnd(2, 32, 9, 12), ["MSCAAttention", 32])
     add("ela64", RefELA(64), rnd(2, 64, 8, 6), ["ELA", 64])
     add("ela256", RefELA(256), rnd(1, 256, 5, 7), ["ELA", 256])
+    # widths that are not multiples of 16 (round 2): GroupNorm(max(1, c // 16), c) -> 2 groups of 20, 1 group of 24
+    add("ela40", RefELA(40), rnd(2, 40, 7, 9), ["ELA", 40])
+    add("ela24", RefELA(24), rnd(1, 24, 6, 5), ["ELA", 24])
     out["cases"] = json.dumps(cases)
     np.savez_compressed(HERE / "modules_bsyolo.npz", **out)
     print("wrote bsyolo modules", len(cases), "cases")
@@ -520,6 +523,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ap":  # only the ap_per_class vectors
         ap_fixtures()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bsyolo_modules":  # only the BS-YOLO module vectors (cases are appended: earlier ones keep their values)
+        bsyolo_module_fixtures()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bsyolo":  # only the BS-YOLO graph vectors (added after the stock set)
         graph_fixture("bsyolo11n_detect", "bsyolo11", "n", "detect", [(2, 64, 64), (1, 96, 160)], nc=12, keep_layers=True)

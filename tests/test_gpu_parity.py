@@ -387,7 +387,7 @@ def test_dwconv_generic_matches_oracle(kh, kw, stride, act):
     np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("tag", ["ela64", "ela256"])
+@pytest.mark.parametrize("tag", ["ela64", "ela256", "ela40", "ela24"])  # 40 / 24: GroupNorm groups of 20 / 24 channels
 def test_ela_matches_reference_golden(tag):
     """ELA (nn/Addmodules/ELA.py:33-101) through bsy_ela against the fork's own module output (modules_bsyolo.npz)."""
     z = np.load(GOLDEN / "modules_bsyolo.npz", allow_pickle=False)
@@ -1449,6 +1449,39 @@ def test_engine_top_level_dwconv_layers_match_oracle():
         d = (y16.float().cpu() - yref).abs()
         assert float(d[:, 4:].max()) < 1e-2 and float(d[:, :4].max()) < 1.0, (float(d[:, 4:].max()), float(d[:, :4].max()))
         assert sum(o["kind"] == L.OP_DWCONV_G for o in e16.plan_for(2, 96, 128, torch.float16, torch.float16)[0].ops) == 2
+        e16.close()
+        e32.close()
+    finally:
+        for d_ in (R.GRAPHS, R.SCALES, R.HEAD_FROM):
+            d_.pop(fam, None)
+
+
+def test_engine_ela_on_widths_that_are_not_multiples_of_16():
+    """`ELA` (nn/Addmodules/ELA.py:33-101) on 24 and 40 channels -- GroupNorm(max(1, c // 16), c) = one group of 24, two of 20 -- in a
+    graph of its own through the engine, both precisions, against the oracle (pinned for these widths by modules_bsyolo.npz)."""
+    fam = "t_ela"
+    R.GRAPHS[fam] = [(-1, 1, "Conv", (24, 3, 2)), (-1, 1, "ELA", (24,)), (-1, 1, "Conv", (40, 3, 2)), (-1, 1, "ELA", (40,)),
+                     (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "Conv", (64, 3, 2))]
+    R.SCALES[fam] = {"n": (1.0, 1.0, 1024)}
+    R.HEAD_FROM[fam] = (3, 4, 5)
+    cfg = {"nc": 12, "scale": "n", "scales": {"n": [1.0, 1.0, 1024]},
+           "backbone": [[-1, 1, "Conv", [24, 3, 2]], [-1, 1, "ELA", [24]], [-1, 1, "Conv", [40, 3, 2]], [-1, 1, "ELA", [40]],
+                        [-1, 1, "Conv", [64, 3, 2]], [-1, 1, "Conv", [64, 3, 2]]],
+           "head": [[[3, 4, 5], 1, "Detect", ["nc"]]]}
+    try:
+        m = R.Model(fam, "n", 12, "detect")
+        P = R.synth_params(m, 5)
+        x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(5))
+        with torch.inference_mode():
+            yref, rref = m.forward(P, x)
+        e32 = YoloEngine(cfg, P, precision="fp32")
+        y32, r32 = e32(x.to(DEV))
+        assert float((y32.cpu()[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3 and float((y32.cpu()[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 128
+        e16 = YoloEngine(cfg, P)
+        y16, _ = e16(x.half().to(DEV))
+        d = (y16.float().cpu() - yref).abs()
+        assert float(d[:, 4:].max()) < 1e-2 and float(d[:, :4].max()) < 1.0, (float(d[:, 4:].max()), float(d[:, :4].max()))
+        assert sum(o["kind"] == L.OP_ELA for o in e16.plan_for(2, 96, 128, torch.float16, torch.float16)[0].ops) == 2
         e16.close()
         e32.close()
     finally:

@@ -80,6 +80,34 @@ def test_greedy_nmm_known_answers():
     assert S.postprocess(np.zeros((0, 6), np.float32)).shape == (0, 6)
 
 
+def test_nmm_known_answers():
+    """sahi's non-greedy `nmm`: a chain A-B-C (A~B, B~C, A and C apart).  GREEDYNMM: A takes B, C stays a detection.  NMM: B, already
+    A's member, hands C to A as well -- and C is folded because the GROWN box A u B matches it."""
+    A = [0, 0, 100, 100, .9, 0]; B = [60, 0, 160, 100, .8, 0]; C = [120, 0, 220, 100, .7, 0]; D = [500, 500, 600, 600, .6, 0]
+    boxes = np.array([C, A, D, B], np.float32)   # IOS(A,B) = IOS(B,C) = .4, IOS(A,C) = 0
+    assert S.nmm(boxes, "IOS", 0.3) == {1: [3, 0], 2: []}           # keeps A (index 1) and D; A's list: B (own turn), then C (B's turn)
+    assert S.greedy_nmm(boxes, "IOS", 0.3) == {1: [3], 0: [], 2: []}
+    out = S.postprocess(boxes, "NMM", "IOS", 0.3)
+    np.testing.assert_allclose(out, np.array([[0, 0, 220, 100, .9, 0], D], np.float32))   # A u B = [0, 160]: IOS with C = .4 > .3
+    out = S.postprocess(boxes, "GREEDYNMM", "IOS", 0.3)
+    np.testing.assert_allclose(out, np.array([[0, 0, 160, 100, .9, 0], C, D], np.float32))
+    # a member that the grown box does not match is dropped, not re-emitted (as in sahi): E touches only B's far end
+    E = [150, 0, 400, 100, .5, 0]                # IOS(B, E) = 10 / 100 = .1, IOS(A u B, E) = 10 / 160 = .0625
+    out = S.postprocess(np.array([A, B, E], np.float32), "NMM", "IOS", 0.08)
+    np.testing.assert_allclose(out, np.array([[0, 0, 160, 100, .9, 0]], np.float32))
+    # within one turn the matches are appended in ASCENDING score order (sahi flips the descending list)
+    G = [10, 0, 110, 100, .5, 0]; H = [5, 0, 105, 100, .6, 0]
+    assert S.nmm(np.array([A, G, H], np.float32), "IOS", 0.5) == {0: [1, 2]}
+    # a keeper is never handed to another keeper: K2 matches member M of K1 but not K1
+    K1 = [0, 0, 100, 100, .9, 0]; K2 = [150, 0, 250, 100, .85, 0]; M = [80, 0, 180, 100, .5, 0]   # IOS(K1,M) = .2, IOS(K2,M) = .3
+    assert S.nmm(np.array([K1, K2, M], np.float32), "IOS", 0.15) == {0: [2], 1: []}
+    # NMM without overlaps is the identity in score order; LSNMS = NMS with IOU, and refuses IOS like sahi
+    np.testing.assert_allclose(S.postprocess(np.array([D, A], np.float32), "NMM"), np.array([A, D], np.float32))
+    np.testing.assert_allclose(S.postprocess(boxes, "LSNMS", "IOU", 0.2), S.postprocess(boxes, "NMS", "IOU", 0.2))
+    with pytest.raises(NotImplementedError):
+        S.postprocess(boxes, "LSNMS", "IOS", 0.5)
+
+
 def test_tile_detections_clamp_shift_and_drop():
     det = np.zeros((2, 3, 6), np.float32)
     det[0, 0] = [-5, 10, 50, 60, .9, 1]       # negative clamped to 0
@@ -172,6 +200,9 @@ def _merge_both(det, counts, shifts, full, **kw):
     dict(postprocess_type="NMS", match_metric="IOU", match_threshold=0.5),
     dict(match_threshold=0.9),
     dict(match_metric="IOU", match_threshold=0.05, class_agnostic=True),
+    dict(postprocess_type="NMM"),                                            # sahi's non-greedy merge (sahi_nmm_kernel)
+    dict(postprocess_type="NMM", match_metric="IOU", match_threshold=0.2, class_agnostic=True),
+    dict(postprocess_type="LSNMS", match_metric="IOU", match_threshold=0.5),  # runs as NMS
 ])
 @pytest.mark.parametrize("T,max_det,n_obj,seed", [(1, 8, 3, 0), (4, 16, 12, 1), (12, 100, 150, 2), (70, 300, 1200, 3)])
 def test_sahi_merge_bit_exact(T, max_det, n_obj, seed, kw):
