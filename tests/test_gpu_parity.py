@@ -132,6 +132,36 @@ def test_conv_patch_kernel_matches_oracle(case, monkeypatch):
     assert d.max().item() <= 2e-3 * max(1.0, base.float().abs().max().item()) and (d > 0).float().mean().item() < 0.05
 
 
+PERSIST_CASES = [
+    # B, H, W, cin, cout, cfg      tiles 8 / 9 = persistent 1x1 kernel (128 x 128, 128 x 64 tiles), variants 1-3
+    (70, 40, 40, 64, 128, 0x81), (70, 40, 40, 64, 128, 0x82), (9, 80, 80, 128, 128, 0x83),
+    (70, 40, 40, 96, 64, 0x91), (33, 37, 41, 32, 72, 0x92), (9, 80, 80, 192, 64, 0x93),
+    (17, 33, 47, 96, 512, 0x82),                                                             # 4 cout tiles per pixel tile
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES)
+def test_conv_persistent_1x1_matches_one_tile_per_workgroup(case, monkeypatch):
+    """conv1x1_persist_kernel (tiles walked by persistent workgroups, dedicated store waves) against the one-tile-per-workgroup
+    implicit-GEMM kernel -- same K walk, so bit for bit -- and the fp32 reference; more tiles than workgroups, ragged last tile."""
+    B, H, W, cin, cout, cfg = case
+    g = torch.Generator().manual_seed(cfg * 7 + cin)
+    x = h16(torch.randn(B, cin, H, W, generator=g))
+    w = h16(torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.5
+    wp, bp = O.pack_conv_weight(w, b, DEV)
+    xd = nhwc(x).half().to(DEV)
+    monkeypatch.setenv("BSY_CONV_CFG", str(0x21))
+    base = O.conv2d_nhwc(xd, wp, bp, cout, 1, 1, True)
+    monkeypatch.setenv("BSY_CONV_CFG", str(cfg))
+    out = O.conv2d_nhwc(xd, wp, bp, cout, 1, 1, True)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("BSY_CONV_CFG")
+    assert torch.equal(out, base)
+    y = F.silu(F.conv2d(x[:2], w, b))
+    np.testing.assert_allclose(nchw(out[:2].float().cpu()).numpy(), y.numpy(), rtol=2e-3, atol=2e-3)
+
+
 KORDER_CASES = [
     # B, H, W, cin, cout, stride, cfg     cfg = tile << 4 | variant; variant + 4 = chunk-major K walk (3x3 layers, implicit-GEMM tiles)
     (2, 40, 40, 128, 128, 2, 0x25),       # model.3's shape class: 128 x 128 tile, BK 32 / 3 stages
