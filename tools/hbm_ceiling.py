@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Practical HBM ceilings on this box for the activation sizes of YOLO11s (B = 64): device copy and read-only / write-only streams."""
+import torch
+dev = "cuda:0"
+def t(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n)
+    return best
+for mb in (26, 52, 105, 210, 419, 838):
+    n = mb * 1000 * 1000 // 2
+    x = torch.randn(n, device=dev, dtype=torch.float16)
+    y = torch.empty_like(x)
+    tc = t(lambda: y.copy_(x))
+    tr = t(lambda: x.sum())            # read-only (reduction)
+    tw = t(lambda: y.fill_(1.0))       # write-only
+    ta = t(lambda: torch.add(x, 1.0, out=y))
+    print(f"{mb:4d} MB: copy {2 * mb / tc / 1e3:5.2f} TB/s ({tc * 1e3:6.1f} us)   add {2 * mb / ta / 1e3:5.2f} TB/s   read {mb / tr / 1e3:5.2f} TB/s   fill {mb / tw / 1e3:5.2f} TB/s", flush=True)
