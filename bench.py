@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling) or in all (strong scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch images per GPU; strong: --batch images in all, split contiguously over the ranks")
+    ap.add_argument("--serial-nms", action="store_true",
+                    help="run NMS (and the detection all-gather) on the forward's stream; default: on a second stream, so that "
+                         "NMS of step i runs beside the forward of step i + 1 (every step's work still lies inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-runs", type=int, default=20, help="CPU baseline sample: runs of --cpu-batch images (~10 s in all)")
@@ -178,22 +181,34 @@ def main():
     pending = None   # the previous step's detection all-gather, in flight on RCCL's stream
     gathered = None
 
+    # Post-processing stream: NMS reads a prediction tensor of its own (the engine allocates `y` per call), so NMS of step i may run
+    # beside the forward of step i + 1 -- 64 one-workgroup-per-image kernels next to 256-CU conv launches.  The forward's stream
+    # never waits for it; torch.cuda.synchronize() at the end of the timed region does.
+    main = torch.cuda.current_stream(dev)
+    post = main if args.serial_nms else torch.cuda.Stream(device=dev)
+
     def step():
         nonlocal pending, gathered
         y, _ = eng(x, want_raw=False)
-        det, counts = HN.nms_batched(y, 0.25, 0.7, max_det=300)
-        if use_dist:
-            # ONE collective per step (counts packed behind the detections), overlapped with the NEXT step's forward:
-            # this step's kernels are already enqueued when the stream is ordered after the previous gather
-            if pending is not None:
-                gathered = pending.wait()
-            pending = gather_detections_async(det, counts)
+        if post is not main:
+            post.wait_stream(main)
+        with torch.cuda.stream(post):
+            det, counts = HN.nms_batched(y, 0.25, 0.7, max_det=300)
+            if post is not main:
+                y.record_stream(post)
+            if use_dist:
+                # ONE collective per step (counts packed behind the detections), overlapped with the NEXT step's forward:
+                # this step's kernels are already enqueued when the stream is ordered after the previous gather
+                if pending is not None:
+                    gathered = pending.wait()
+                pending = gather_detections_async(det, counts)
         return det, counts
 
     def drain():
         nonlocal pending, gathered
         if pending is not None:
-            gathered = pending.wait()
+            with torch.cuda.stream(post):
+                gathered = pending.wait()
             pending = None
 
     for _ in range(args.warmup):
@@ -271,6 +286,7 @@ def main():
                                    + ", seeded random weights, engine forward + HIP NMS (conf 0.25, iou 0.7, max_det 300)"
                                    + (" + RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": global_batch, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",
+                       "pipeline": "NMS on the forward's stream" if args.serial_nms else "NMS of step i on a second stream beside the forward of step i + 1",
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 1),
                        "model_gflop_per_image": round(plan.flops / B / 1e9, 2),
                        "whole_path_tflops": round(plan.flops / B * global_batch / (ms_step * 1e-3) / 1e12, 1)},
