@@ -61,6 +61,11 @@ struct ConvArgs {
     float lvl_stride;
     void* raw;
     int raw_f32, rawC;
+    // Box-branch tail (3x3 conv + the branch's last 1x1 conv + DFL decode in one launch; conv_mfma.hip conv3x3_patch_kernel<.., TAIL>):
+    // this op is the 3x3 conv (Cout = 64, its map never reaches HBM), tail_wgt / tail_bias the packed 64 -> 64 1x1 conv, epi = 3 and
+    // the decoder fields above describe what the tail writes.  nullptr: no tail.
+    const half_t* tail_wgt;
+    const float* tail_bias;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 #define BSY_CONV_MAX_CFG 64

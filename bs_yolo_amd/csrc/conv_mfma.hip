@@ -52,6 +52,8 @@ struct ConvK {
     float lvl_stride;
     void* y;
     void* raw;
+    const half_t* tail_wgt;  // box-branch tail (ConvArgs::tail_wgt): packed [128][64] 1x1 weights, f32 bias
+    const float* tail_bias;
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
     int dbg;  // ablation switches for profiling (BSY_CONV_DBG; results are WRONG under them): 1 = no DMA, 4 = no epilogue
     int korder;  // 0 = tap-major K walk (taps outer, channels inner: the packed order), 1 = chunk-major (BK channels of all
@@ -222,6 +224,59 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[NT][
 template <typename T>
 __device__ __forceinline__ void head_store(void* base, size_t idx, float v) { reinterpret_cast<T*>(base)[idx] = (T)v; }
 
+// DFL + dist2bbox of one pixel per lane pair (head.py:141-146, block.py:58-77): lo / hi = the 32 x 32 accumulators of couts 0..31 /
+// 32..63 of this lane's pixel; side sd's 16 bins sit in 8 registers of this lane and 8 of lane ^ 32.  Writes rows 0..3 of y (and the
+// raw logits when a raw map is bound).
+__device__ __forceinline__ void dfl_decode_store(const ConvK& p, const float* __restrict__ bias, const f32x16& lo, const f32x16& hi, bool mv,
+                                                 size_t ybase, size_t rbase, int pix, int lh) {
+    const int hw = p.OH * p.OW;
+    float dist[4];
+#pragma unroll
+    for (int sd = 0; sd < 4; ++sd) {
+        const int rb = 8 * (sd & 1);
+        float v[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * sd + 8 * g + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * g + e] = ((sd >> 1) ? hi : lo)[rb + 4 * g + e] + bv[e];
+        }
+        if (p.raw && mv) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const size_t ri = rbase + (size_t)(16 * sd + (i & 3) + 8 * (i >> 2) + 4 * lh) * hw;
+                if (p.raw_f32) head_store<float>(p.raw, ri, v[i]); else head_store<half_t>(p.raw, ri, v[i]);
+            }
+        }
+        float mx = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mx = fmaxf(mx, v[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float ex = __expf(v[i] - mx);
+            den += ex;
+            num += ex * (float)((i & 3) + 8 * (i >> 2) + 4 * lh);  // bin index of this register
+        }
+        den += __shfl_xor(den, 32, 64);
+        num += __shfl_xor(num, 32, 64);
+        dist[sd] = num / den;
+    }
+    if (mv && lh == 0) {
+        const int ay_i = pix / p.OW, ax_i = pix - ay_i * p.OW;
+        const float ax = (float)ax_i + 0.5f, ay = (float)ay_i + 0.5f;
+        const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+        const float o[4] = {((x1 + x2) * 0.5f) * p.lvl_stride, ((y1 + y2) * 0.5f) * p.lvl_stride,
+                            (x2 - x1) * p.lvl_stride, (y2 - y1) * p.lvl_stride};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t yi = ybase + (size_t)r * p.A;
+            if (p.y_f32) head_store<float>(p.y, yi, o[r]); else head_store<half_t>(p.y, yi, o[r]);
+        }
+    }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue_head(const ConvK& p, f32x16 (&acc)[NT][MT], int m0, int n0, int wm, int wn,
                                                    int lrow, int lh) {
@@ -259,51 +314,7 @@ __device__ __forceinline__ void conv_epilogue_head(const ConvK& p, f32x16 (&acc)
                 }
             }
         } else if (NT == 2) {  // epi 3; host guarantees WAVES_N == 1, n0 == 0, Cout == 64
-            float dist[4];
-#pragma unroll
-            for (int sd = 0; sd < 4; ++sd) {
-                const int a = sd >> 1, rb = 8 * (sd & 1);
-                float v[8];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + 16 * sd + 8 * g + 4 * lh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[a & (NT - 1)][b][rb + 4 * g + e] + bv[e];
-                }
-                if (p.raw && mv) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const size_t ri = rbase + (size_t)(16 * sd + (i & 3) + 8 * (i >> 2) + 4 * lh) * hw;
-                        if (p.raw_f32) head_store<float>(p.raw, ri, v[i]); else head_store<half_t>(p.raw, ri, v[i]);
-                    }
-                }
-                float mx = v[0];
-#pragma unroll
-                for (int i = 1; i < 8; ++i) mx = fmaxf(mx, v[i]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float den = 0.f, num = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float ex = __expf(v[i] - mx);
-                    den += ex;
-                    num += ex * (float)((i & 3) + 8 * (i >> 2) + 4 * lh);  // bin index of this register
-                }
-                den += __shfl_xor(den, 32, 64);
-                num += __shfl_xor(num, 32, 64);
-                dist[sd] = num / den;
-            }
-            if (mv && lh == 0) {
-                const int ay_i = pix / p.OW, ax_i = pix - ay_i * p.OW;
-                const float ax = (float)ax_i + 0.5f, ay = (float)ay_i + 0.5f;
-                const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
-                const float o[4] = {((x1 + x2) * 0.5f) * p.lvl_stride, ((y1 + y2) * 0.5f) * p.lvl_stride,
-                                    (x2 - x1) * p.lvl_stride, (y2 - y1) * p.lvl_stride};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t yi = ybase + (size_t)r * p.A;
-                    if (p.y_f32) head_store<float>(p.y, yi, o[r]); else head_store<half_t>(p.y, yi, o[r]);
-                }
-            }
+            dfl_decode_store(p, p.bias, acc[0][b], acc[NT - 1][b], mv, ybase, rbase, pix, lh);
         }
     }
 }
@@ -910,7 +921,11 @@ static int launch_persist(const ConvK& k, hipStream_t s) {
 // TW_ = tile width: 16 (8 x 16 tile: 128 pixels = the 128 pixel slots of the four MFMA pixel tiles) or 20 (6 x 20 tile: 120
 // pixels in the 128 slots, slot i = pixel (i / 20, i % 20)) -- a 20 x 20 map is 4 tiles of 6 x 20 instead of 6 tiles of
 // 8 x 16 (48 % of whose slots lie outside the map), a 40 x 40 map 14 instead of 15.
-template <int NT, int STAGES, int WM, int TW_ = CP_TW>
+// TAIL (NT == 1, four waves): the Detect box branch's last two layers in one launch -- this 3x3 conv (64 couts), then the
+// branch's 1x1 conv (64 -> 64 box logits) on the activated fp16 tile straight from LDS and the DFL decoder on its accumulators
+// (ConvArgs::tail_wgt).  Wave w takes pixel slots 32 w .. 32 w + 31 and all 64 couts (the decoder's layout: a side's 16 bins in
+// one lane pair).  Same operands, same K order as the separate 1x1 launch -> the same bits; the 64-channel map stays on chip.
+template <int NT, int STAGES, int WM, int TW_ = CP_TW, bool TAIL = false>
 __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) {
     constexpr int CP_TH = TW_ == 16 ? 4 * WM : 6, NW = 2 * WM, NTHR = 64 * NW;
     constexpr int PW_ = TW_ + 2;                            // patch row length (entries)
@@ -1058,6 +1073,16 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
         }
         if (++kh == 3) { kh = 0; ++chunk; }
     }
+    // TAIL: the 1x1 weights (A operand, [128][64] packed, k = channel; rows = box logits a * 32 + lrow) are fetched now, so that
+    // their latency passes under the SiLU / LDS stage below (every DMA has drained: the loop ends on vmcnt(0))
+    half8 ta[TAIL ? 4 : 1][2];
+    if (TAIL) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                ta[TAIL ? ks : 0][a] = *reinterpret_cast<const half8*>(p.tail_wgt + (size_t)(a * 32 + lrow) * 64 + 16 * ks + 8 * lh);
+    }
     __syncthreads();  // every wave has finished reading the last step: LDS becomes the output tile
 
     constexpr int LDT = TN + 8;
@@ -1081,6 +1106,25 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
         }
     }
     __syncthreads();
+    if (TAIL) {
+        static_assert(!TAIL || (NT == 1 && WM == 2), "tail: 64-cout tiles, four waves");
+        const int slot = wave * 32 + lrow;
+        f32x16 t0, t1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { t0[r] = 0.f; t1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half8 tb = *reinterpret_cast<const half8*>(smem + slot * LDT + 16 * ks + 8 * lh);
+            t0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[TAIL ? ks : 0][0], tb, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[TAIL ? ks : 0][1], tb, t1, 0, 0, 0);
+        }
+        const int oy = oy0 + slot / TW_, ox = ox0 + slot % TW_;
+        const bool mv = slot < NVALID && oy < p.H && ox < p.W;
+        const int pix = mv ? oy * p.W + ox : 0;
+        const int hw = p.H * p.W;
+        dfl_decode_store(p, p.tail_bias, t0, t1, mv, (size_t)n * p.nrows * p.A + p.a0 + pix, (size_t)n * p.rawC * hw + pix, pix, lh);
+        return;
+    }
     constexpr int CPRW = TN / 8, ITER = TM * CPRW / NTHR;
     half_t* dst = reinterpret_cast<half_t*>(p.dst);
 #pragma unroll
@@ -1100,7 +1144,7 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
     }
 }
 
-template <int NT, int STAGES, int WM, int TW_ = CP_TW>
+template <int NT, int STAGES, int WM, int TW_ = CP_TW, bool TAIL = false>
 static int launch_patch(const ConvK& k, hipStream_t s) {
     ConvK p = k;
     p.ntn = ceil_div(k.Cout, 64 * NT);
@@ -1108,7 +1152,7 @@ static int launch_patch(const ConvK& k, hipStream_t s) {
     p.tiles_y = ceil_div(k.H, TW_ == 16 ? 4 * WM : 6);
     const long long nblk = (long long)k.B * p.tiles_x * p.tiles_y * p.ntn;
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: tile count %lld out of range", nblk);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<NT, STAGES, WM, TW_>), dim3((unsigned)nblk), dim3(128 * WM), 0, s, p);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<NT, STAGES, WM, TW_, TAIL>), dim3((unsigned)nblk), dim3(128 * WM), 0, s, p);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
@@ -1383,6 +1427,12 @@ bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     if (cfg < 0 || tile > 13 || korder > 1) return false;
     // variant bit 4: chunk-major K walk -- implicit-GEMM tiles of aligned 3x3 layers only (a 1x1 layer has one tap)
     if (korder && (tile >= 8 || var < 1 || a.ksize != 3)) return false;
+    if (a.tail_wgt) {  // box-branch tail: the 64-cout patch tiles only (validity of the 3x3 conv itself: the same op without tail / decoder)
+        if ((tile != 11 && tile != 13) || korder) return false;
+        ConvArgs b = a;
+        b.tail_wgt = nullptr; b.tail_bias = nullptr; b.epi = 0;
+        return a.epi == 3 && a.Cout == 64 && !a.res && conv_cfg_valid(b, cfg);
+    }
     if (a.epi && tile >= 8) return false;           // fused decoder: implicit-GEMM kernel only
     if (a.epi == 3 && tile != 1) return false;      // DFL needs all 64 box couts in one wave: the 256 x 64 tile (4 x 1 waves, NT 2)
     if (tile >= 12) {  // 6x20-pixel patch tiles
@@ -1418,6 +1468,11 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         for (int i = 0; i < n; ++i) if (out[i] == c) return;
         if (n < max_out && conv_cfg_valid(a, c)) out[n++] = c;
     };
+    if (a.tail_wgt) {  // 3x3 conv + 1x1 + DFL: the four 64-cout patch configurations
+        if (ceil_div(a.W, 20) * ceil_div(a.H, 6) < ceil_div(a.W, 16) * ceil_div(a.H, 8)) { add(13, 2); add(13, 1); }
+        add(11, 2); add(11, 1); add(13, 2); add(13, 1);
+        return n;
+    }
     if (!aligned) {
         add(tile, 0);
         if (a.Cout > 32) { add(3, 0); add(6, 0); }
@@ -1471,6 +1526,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         if ((a.epi != 2 && a.epi != 3) || !a.y || a.A <= 0 || a.a0 < 0 || a.a0 + a.OH * a.OW > a.A || a.dst_scale > 1 || a.res)
             BSY_FAIL(BSY_ERR_ARG, "conv: bad fused-decoder arguments (epi %d)", a.epi);
         if (a.epi == 3 && (a.Cout != 64 || a.nrows < 4)) BSY_FAIL(BSY_ERR_ARG, "conv: DFL epilogue needs 64 box channels");
+        if (a.tail_wgt && (a.epi != 3 || !a.tail_bias || a.ksize != 3 || ((uintptr_t)a.tail_wgt & 15) || ((uintptr_t)a.tail_bias & 15)))
+            BSY_FAIL(BSY_ERR_ARG, "conv: bad box-branch tail arguments");
         if (a.epi == 2 && a.nrows < 4 + a.Cout) BSY_FAIL(BSY_ERR_ARG, "conv: y has %d rows, class epilogue needs %d", a.nrows, 4 + a.Cout);
         if (a.raw && a.rawC < (a.epi == 3 ? 64 : 64 + a.Cout)) BSY_FAIL(BSY_ERR_ARG, "conv: raw map has too few channels");
     }
@@ -1483,6 +1540,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     k.res = a.res; k.ldr = a.ldr; k.act = a.act; k.B = a.B; k.tiles_x = k.tiles_y = 0;
     k.epi = a.epi; k.y = a.y; k.y_f32 = a.y_f32; k.A = a.A; k.a0 = a.a0; k.nrows = a.nrows; k.lvl_stride = a.lvl_stride;
     k.raw = a.raw; k.raw_f32 = a.raw_f32; k.rawC = a.rawC;
+    k.tail_wgt = a.tail_wgt; k.tail_bias = a.tail_bias;
+    if (a.tail_wgt && !a.epi) BSY_FAIL(BSY_ERR_ARG, "conv: a box-branch tail needs the decoder arguments (epi 3)");
     k.dst_scale = a.dst_scale > 0 ? a.dst_scale : 1; k.dst_dy = a.dst_dy; k.dst_dx = a.dst_dx; k.ntn = 1;
     // ---- configuration: explicit (autotuned, ConvArgs::cfg) or heuristic -----------------------------------------
     if (a.ksize == 3 && (a.up0 || a.up1)) BSY_FAIL(BSY_ERR_ARG, "conv: upsampled source only with ksize 1");
@@ -1500,7 +1559,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     int cfg = a.cfg;
     if (cfg < 0 || !conv_cfg_valid(a, cfg)) {
         int list[BSY_CONV_MAX_CFG];
-        conv_candidates(a, list, BSY_CONV_MAX_CFG);
+        if (conv_candidates(a, list, BSY_CONV_MAX_CFG) <= 0) BSY_FAIL(BSY_ERR_ARG, "conv: no kernel configuration for this shape");
         cfg = list[0];
     }
     const int tile = cfg >> 4, var = cfg & 3;
@@ -1516,6 +1575,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     } while (0)
 #define BSY_TILE(KS_)                                                                     \
     do {                                                                                  \
+        if (k.tail_wgt && tile == 13 && var == 1) return launch_patch<1, 3, 2, 20, true>(k, s); \
+        if (k.tail_wgt && tile == 13) return launch_patch<1, 2, 2, 20, true>(k, s);       \
+        if (k.tail_wgt && tile == 11 && var == 1) return launch_patch<1, 3, 2, 16, true>(k, s); \
+        if (k.tail_wgt) return launch_patch<1, 2, 2, 16, true>(k, s);                     \
         if (tile == 12) return launch_patch<2, 2, 2, 20>(k, s);                           \
         if (tile == 13 && var == 1) return launch_patch<1, 3, 2, 20>(k, s);               \
         if (tile == 13) return launch_patch<1, 2, 2, 20>(k, s);                           \

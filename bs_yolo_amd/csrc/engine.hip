@@ -496,6 +496,7 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             a.res = R.h(op.res); a.ldr = op.res.buf >= 0 ? op.res.ld : 0;
             a.act = op.act; a.dst_scale = op.dst_scale; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
             a.epi = 0; a.y = nullptr; a.raw = nullptr; a.y_f32 = a.raw_f32 = a.A = a.a0 = a.nrows = a.rawC = 0; a.lvl_stride = 0.f;
+            a.tail_wgt = nullptr; a.tail_bias = nullptr;
             if (op.out_f32 >= 2) {  // fused Detect decoder: dst = the prediction tensor y, box[0] = the level's raw map (optional)
                 a.epi = op.out_f32; a.out_f32 = 0; a.dst = nullptr; a.ldd = 8; a.Cout = op.nl;
                 a.y = R.base(op.dst); a.y_f32 = op.out_dtype == BSY_F32; a.A = op.A; a.a0 = op.lvl_h[1]; a.nrows = op.dst.C;
@@ -503,6 +504,10 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
                 const bsy_view& rv = op.box[0];
                 const bool bound = rv.buf >= BSY_EXT_BASE && rv.buf - BSY_EXT_BASE < R.n_ext && R.ext[rv.buf - BSY_EXT_BASE];
                 a.raw = bound ? R.base(rv) : nullptr; a.raw_f32 = a.y_f32; a.rawC = rv.C;
+                if (op.out_f32 == 3 && op.mid_c > 0) {  // box-branch tail: this op is the 3x3 conv, (w2, b2) the branch's last 1x1 conv
+                    a.Cout = op.mid_c;
+                    a.tail_wgt = (const half_t*)(wb + op.w2_off); a.tail_bias = (const float*)(wb + op.b2_off);
+                }
             }
             a.cfg = op.tuned_cfg - 1;  // 0 = not tuned -> heuristic
             if (!R.ok) return BSY_ERR_ARG;

@@ -113,6 +113,8 @@ class Plan:
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
         self.fuse_head = (os.environ.get("BSY_FUSE_HEAD", "1") != "0") if fuse_head is None else bool(fuse_head)
+        # box-branch tail (cv2.x.1 + cv2.x.2 + DFL in one launch): part of the head fusion, BSY_FUSE_BOXTAIL=0 switches it off alone
+        self.fuse_boxtail = self.fuse_head and os.environ.get("BSY_FUSE_BOXTAIL", "1") != "0"
         self.fuse_dwpw = (os.environ.get("BSY_FUSE_DWPW", "1") != "0") if fuse_dwpw is None else bool(fuse_dwpw)
         self.merge_c3k = (os.environ.get("BSY_MERGE_C3K", "1") != "0") if merge_c3k is None else bool(merge_c3k)
         self.fuse_msca = (os.environ.get("BSY_FUSE_MSCA", "1") != "0") if fuse_msca is None else bool(fuse_msca)
@@ -468,6 +470,22 @@ class Plan:
                              mfma_flops=2 * self.B * src.H * src.W * cout * src.C))
         self.flops += 2 * self.B * src.H * src.W * cout * src.C
 
+    def _box_tail(self, name: str, i: int, src: T, level: int, a0: int, A: int, nc: int, stride: float):
+        """cv2.i.1 (3x3, 64 -> 64, SiLU) + cv2.i.2 (1x1, 64 -> 64 box logits) + DFL / dist2bbox (head.py:49-57, :141-146) as ONE
+        conv op: the patch kernel's TAIL form (conv_mfma.hip) multiplies its activated fp16 tile with the 1x1 weights straight from
+        LDS and decodes the accumulators -- bit for bit what the two launches produce, without the 64-channel map's round trip."""
+        n1, n2 = f"{name}.cv2.{i}.1", f"{name}.cv2.{i}.2"
+        k1 = self._wrec(n1, name=n1, kind="conv", cout=64, cin=src.C, k=3, perm=None)
+        k2 = self._wrec(n2, name=n2, kind="plain", cout=64, cin=64, k=1, perm=None)
+        y = T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc, 0, 0)
+        raw = T(L.BSY_EXT_BASE + self.EXT_RAW0 + level, 0, 0, 64 + nc, 0, 0)
+        fl = 2 * self.B * src.H * src.W * 64 * (9 * src.C + 64)
+        self.ops.append(dict(kind=L.OP_CONV, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, src1=None, dst=y, res=None,
+                             ksize=3, stride=1, pad=1, act=1, out_f32=3, wkey=k1, wkey2=k2, mid_c=64, dst_scale=1, name=n1 + "+2",
+                             cout=64, lane=self._lane, nl=64, nc=nc, nm=0, A=A, box=[raw], cls=[], msk=[], level=level,
+                             lvl_h=[src.H, a0], lvl_w=[src.W], lvl_stride=[stride], out_dtype=self.out_dtype, mfma_flops=fl))
+        self.flops += fl
+
     def detect(self, name: str, xs: List[T], nc: int, legacy: bool, nm: int = 0, npr: int = 0):
         """head.py:21-148 (+ Segment :175-197)."""
         ch = [t.C for t in xs]
@@ -485,11 +503,14 @@ class Plan:
             assert not x.up
             self._lane = 2 * i
             t = self.conv(f"{name}.cv2.{i}.0", x, c2, 3, 1)
-            t = self.conv(f"{name}.cv2.{i}.1", t, c2, 3, 1)
-            if fused:
-                self._head_conv(f"{name}.cv2.{i}.2", t, 64, 3, i, a0[i], A, nc, strides[i])
+            if fused and self.fuse_boxtail and c2 == 64:
+                self._box_tail(name, i, t, i, a0[i], A, nc, strides[i])
             else:
-                boxes.append(self.conv(f"{name}.cv2.{i}.2", t, 64, 1, 1, act=False, plain=True, out_f32=True))
+                t = self.conv(f"{name}.cv2.{i}.1", t, c2, 3, 1)
+                if fused:
+                    self._head_conv(f"{name}.cv2.{i}.2", t, 64, 3, i, a0[i], A, nc, strides[i])
+                else:
+                    boxes.append(self.conv(f"{name}.cv2.{i}.2", t, 64, 1, 1, act=False, plain=True, out_f32=True))
             self._lane = 2 * i + 1
             if legacy:
                 t = self.conv(f"{name}.cv3.{i}.0", x, c3, 3, 1)

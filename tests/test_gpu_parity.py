@@ -717,7 +717,8 @@ def test_engine_tuned_fused_equals_plain_on_odd_shapes(scale, shape):
     yp, rp = plain(x)
     torch.cuda.synchronize()
     d = (yf.float() - yp.float()).abs()
-    assert d[:, 4:].max() < 2e-3 and d[:, :4].max() < 0.25, (d[:, 4:].max(), d[:, :4].max())
+    # boxes: one f16 ulp of a coordinate in [256, 512) is 0.25 px (the widest input here is 416 pixels)
+    assert d[:, 4:].max() < 2e-3 and d[:, :4].max() <= 0.25, (d[:, 4:].max(), d[:, :4].max())
     for a, b in zip(rf, rp):
         assert (a.float() - b.float()).abs().max() < 2e-2 * max(1.0, b.float().abs().max().item())
     full.close()
@@ -778,6 +779,34 @@ def test_engine_no_harmful_reads_past_the_weight_blob(fam, scale, nc, task, shap
         assert float((y2.float() - y0.float()).abs().max()) < 0.05 * max(1.0, float(y0.float().abs().max()))
     for e in (plain, poisoned, tuned):
         e.close()
+
+
+@pytest.mark.parametrize("fam,scale,nc,shape", [("yolo11", "s", 80, (2, 640, 640)), ("yolo11", "n", 80, (3, 512, 544)), ("yolov8", "n", 80, (1, 512, 512)),
+                                                ("bsyolo11", "n", 12, (1, 640, 512))])
+def test_engine_box_branch_tail_is_bit_identical(fam, scale, nc, shape, monkeypatch):
+    """cv2.i.1 + cv2.i.2 + DFL in one launch (conv3x3_patch_kernel TAIL) against the two launches: y and the raw maps bit for bit, f16 and
+    f32 outputs, 8x16 and 6x20 tiles, ragged tile rows / columns.  Every level is at least 16 pixels high and wide, so the un-tuned plan
+    runs the separate 3x3 conv on the patch kernel too (the heuristic's condition): same K walk on both sides; smaller maps are
+    covered with tolerances by test_engine_tuned_fused_equals_plain_on_odd_shapes and the golden-graph tests."""
+    from bs_yolo_amd.plan import Plan
+    from bs_yolo_amd.weights import synth_state_dict
+    cfg = stock_cfg(fam, scale, nc)
+    sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=2)
+    B, H, W = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(8))
+    outs = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("BSY_FUSE_BOXTAIL", tail)
+        eng = YoloEngine(cfg, sd, autotune=False)
+        plan = eng.plan_for(B, H, W, torch.float16, torch.float16)[0]
+        assert sum(1 for o in plan.ops if o["kind"] == L.OP_CONV and o.get("mid_c")) == (3 if tail == "1" else 0)
+        y16, r16 = eng(x.half().to(DEV))
+        y32, r32 = eng(x.to(DEV))
+        torch.cuda.synchronize()
+        outs.append([y16.clone(), y32.clone()] + [r.clone() for r in r16] + [r.clone() for r in r32])
+        eng.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("fam,scale,nc,shape", [("yolo11", "s", 80, (8, 640, 640)), ("bsyolo11", "n", 12, (2, 1024, 1024))])
@@ -919,8 +948,11 @@ def test_engine_fused_decoder_matches_decode_kernel(dtype):
     yn, rn = fused(x, want_raw=False)
     torch.cuda.synchronize()
     tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-3, atol=1e-3)
-    # boxes: fp32 DFL with a different summation order; scores: identical formula on identical logits
-    np.testing.assert_allclose(yf.float().cpu().numpy(), yp.float().cpu().numpy(), **tol)
+    # scores: identical formula on identical logits.  Boxes: fp32 DFL with a different summation order -- and, since the box branch's
+    # last 3x3 conv runs inside the tail launch (patch kernel, chunk-major K walk) but as an implicit-GEMM launch in the plain plan
+    # (maps under 16 pixels here), a few 1-ulp flips of its fp16 map: 15 of 52 920 coordinates moved by up to 0.015 px
+    np.testing.assert_allclose(yf.float().cpu().numpy()[:, 4:], yp.float().cpu().numpy()[:, 4:], **tol)
+    np.testing.assert_allclose(yf.float().cpu().numpy()[:, :4], yp.float().cpu().numpy()[:, :4], rtol=1e-3, atol=5e-2)
     assert torch.equal(yn, yf) and all(r is None for r in rn)
     for a, b in zip(rf, rp):
         assert a.shape == b.shape

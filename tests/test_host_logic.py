@@ -56,9 +56,10 @@ def test_op_struct_layout():
 
 
 @pytest.mark.parametrize("scale,gflops,nconv", [("n", 6.48, 80), ("s", 21.47, 80), ("m", 67.98, 105)])
-def test_plan_work_matches_reference_counts(scale, gflops, nconv):
+def test_plan_work_matches_reference_counts(scale, gflops, nconv, monkeypatch):
     """Dense-conv FLOPs per 640x640 image equal the reference graph (BASELINE.md section 2 / SURVEY 8d); the
     reference counts 81 dense convs for n/s because DFL is a 1x1 conv there (block.py:58-77), here it lives in decode."""
+    monkeypatch.setenv("BSY_FUSE_BOXTAIL", "0")  # one op per conv module
     p = Plan(stock_cfg("yolo11", scale), 1, 640, 640, fuse_stem=False, fuse_bneck=False, fuse_dwpw=False, merge_c3k=False, fuse_tail=False)
     dense = 0
     n = 0
@@ -70,6 +71,26 @@ def test_plan_work_matches_reference_counts(scale, gflops, nconv):
     assert n == nconv
     assert abs(dense / 1e9 - gflops) < 0.01 * gflops
     assert p.meta["A"] == 8400 and p.meta["strides"] == [8.0, 16.0, 32.0]
+
+
+def test_box_branch_tail_is_one_op(monkeypatch):
+    """Detect's cv2.i.1 + cv2.i.2 (+ DFL) become ONE conv op (plan.py _box_tail) where the branch is 64 wide; the weight records --
+    and with them the blob layout and synth_state_dict's draws -- are those of the unfused plan."""
+    cfg = stock_cfg("yolo11", "s")
+    fused = Plan(cfg, 2, 640, 640)
+    monkeypatch.setenv("BSY_FUSE_BOXTAIL", "0")
+    plain = Plan(cfg, 2, 640, 640)
+    assert list(fused.wrecs) == list(plain.wrecs)
+    assert len(plain.ops) - len(fused.ops) == 3 and fused.flops == plain.flops
+    tails = [o for o in fused.ops if o["kind"] == L.OP_CONV and o.get("mid_c")]
+    assert [o["name"] for o in tails] == [f"model.23.cv2.{i}.1+2" for i in range(3)]
+    for o in tails:
+        assert (o["ksize"], o["out_f32"], o["act"], o["cout"], o["wkey2"]) == (3, 3, 1, 64, o["wkey"][:-1] + "2")
+    monkeypatch.delenv("BSY_FUSE_BOXTAIL")
+    # YOLO11x: the box branch is 96 wide (max(16, 384 // 4, 64)) -> no tail
+    assert not [o for o in Plan(stock_cfg("yolo11", "x"), 1, 64, 64).ops if o["kind"] == L.OP_CONV and o.get("mid_c")]
+    # Segment heads keep the separate decode op (mask coefficients): no tail either
+    assert not [o for o in Plan(stock_cfg("yolo11", "n", 80, "segment"), 1, 64, 64).ops if o["kind"] == L.OP_CONV and o.get("mid_c")]
 
 
 def test_c3k_branch_merge():
