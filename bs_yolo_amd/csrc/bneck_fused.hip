@@ -108,15 +108,16 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
     // Retire the weight / bias loads HERE: left pending, the compiler waits for them at their first use inside the tile
     // loop with vmcnt(0) -- on every iteration, which then also waits for the prefetch issued just before.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    int tile = blockIdx.x;
-    if (tile < p.ntiles) fetch(tile);
-    for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, p.ntiles);  // XCD-aware tile order (common.h)
+    int tile = tw.tile;
+    if (tile < tw.end) fetch(tile);
+    for (; tile < tw.end; tile += tw.step) {
         const int n = nn, oy0 = noy0, ox0 = nox0;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i)
             if (tid + 256 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
         __syncthreads();  // input patch visible; every wave is done with the previous tile's LDS
-        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+        if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
         // ---- conv 1: 180 hidden pixels = 6 MFMA pixel tiles over 4 waves ----------------------------------------------
         for (int mt = wave; mt < BN_NMT; mt += 4) {
@@ -290,16 +291,17 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
     };
 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the weight loads here, not inside the tile loop
-    int tile = blockIdx.x;
-    if (tile < p.ntiles) fetch(tile);
-    for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, p.ntiles);  // XCD-aware tile order (common.h)
+    int tile = tw.tile;
+    if (tile < tw.end) fetch(tile);
+    for (; tile < tw.end; tile += tw.step) {
         const int n = nn, oy0 = noy0, ox0 = nox0;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i)
             if (tid + 512 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
         half_t* ob = p.dst + ((long long)(n * p.H + oy0) * p.W + ox0) * p.ldd;
         __syncthreads();  // input patch visible (first iteration: the weights too); the previous tile's output has been read
-        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+        if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
         // ---- conv 1: 180 hidden pixels = 6 MFMA pixel tiles on waves 0-5 -----------------------------------------------------
         if (wave < BN_NMT) {

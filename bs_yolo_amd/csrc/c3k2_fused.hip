@@ -154,16 +154,17 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
     const half_t* a2base = swb + lrow * WBS + 8 * lh;
 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the weight loads here, not inside the tile loop (bneck_fused.hip)
-    int tile = blockIdx.x;
-    if (tile < p.ntiles) fetch(tile);
-    for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, p.ntiles);  // XCD-aware tile order (common.h)
+    int tile = tw.tile;
+    if (tile < tw.end) fetch(tile);
+    for (; tile < tw.end; tile += tw.step) {
         const int n = nn, oy0 = noy0, ox0 = nox0;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i)
             if (tid + 256 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
         half_t* ob = p.dst + ((long long)(n * p.H + oy0) * p.W + ox0) * p.ldd;  // output tile origin (uniform)
         __syncthreads();  // (A) x patch visible (and, first iteration, the weights)
-        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+        if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
         // ---- S1: cv1 (1x1, CIN -> 2C).  Seven jobs of one MFMA tile (32 pixels x 32 channels) over four waves: y1 = channels
         //      C .. 2C-1 on the five pixel tiles of the patch (zero outside the MAP: the Bottleneck's convs pad y1, not x), y0 =

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
 //
 // With one tile per workgroup the load -> MFMA -> store phases of those layers only overlap across the 2-5 resident
 // workgroups: removing the epilogue alone made them 2.4x faster, removing the DMA alone 2x.  Here a workgroup of 8 waves
-// walks tiles (tile = blockIdx.x + j * gridDim.x) with ONE continuous DMA ring:
+// walks tiles (XCD-aware order, common.h xcd_tile_walk) with ONE continuous DMA ring:
 //   waves 0-3 (compute): issue the LDS-DMA (running STAGES-1 K-steps ahead, ACROSS tile boundaries), MFMA, then park
 //                        bias + SiLU results as an fp16 tile in LDS and carry straight on with the next tile;
 //   waves 4-7 (store)  : walk the same barrier sequence, and after each tile's hand-over barrier move the parked tile to
@@ -706,8 +706,11 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = p.Kpad / BK;
     const int ntiles = p.ntm * p.ntn;
-    const int G = gridDim.x;
-    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;  // grid <= ntiles -> at least one
+    // XCD-aware tile walk (common.h xcd_tile_walk): the cout tiles of one pixel tile are neighbours in the tile order, so they run on
+    // ONE XCD at the same time and the second reads the pixels from its L2 (model.4.cv2: 540 MB of traffic for 367 MB otherwise)
+    const TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, ntiles);
+    const int T0 = tw.tile, G = tw.step;
+    const int my_tiles = T0 < tw.end ? (tw.end - T0 + G - 1) / G : 0;
     for (int i = tid; i < p.ntn * TN; i += 512) sbias[i] = p.bias[i];  // bias is padded to CoutPad (multiple of 128)
     __syncthreads();
 
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
         constexpr int CPRW = TN / 8, ITER = TM * CPRW / 256;
         half_t* dst = reinterpret_cast<half_t*>(p.dst);
         for (int t = 0; t < my_tiles; ++t) {
-            const int tile = blockIdx.x + t * G;
+            const int tile = T0 + t * G;
             const int m0 = (tile / p.ntn) * TM, n0 = (tile % p.ntn) * TN;
             for (int k = 0; k < nk; ++k) __builtin_amdgcn_s_barrier();  // B(t, k)
             __builtin_amdgcn_s_barrier();                              // E(t): tile t is parked
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
     bool rv[PIW];
     int it = 0, ikt = 0, s_cb = 0;
     auto setup_tile = [&](int tcount) {
-        const int tile = blockIdx.x + tcount * G;
+        const int tile = T0 + tcount * G;
         const int m0 = (tile / p.ntn) * TM, n0 = (tile % p.ntn) * TN;
 #pragma unroll
         for (int i = 0; i < PIW; ++i) {
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
         if (++ckt == nk) {
             ckt = 0;
-            const int n0 = ((blockIdx.x + ct * G) % p.ntn) * TN;
+            const int n0 = ((T0 + ct * G) % p.ntn) * TN;
             // park bias + SiLU as fp16 (the store waves finished reading the previous tile before B(ct, 0))
 #pragma unroll
             for (int b = 0; b < MT; ++b) {

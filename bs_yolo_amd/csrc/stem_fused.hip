@@ -112,15 +112,16 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
     // Retire the weight / bias loads HERE: left pending, the compiler waits for them at their first use inside the tile
     // loop with vmcnt(0) -- on every iteration, which then also waits for the prefetch issued just before.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    int tile = blockIdx.x;
-    if (tile < p.ntiles) fetch(tile);
-    for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, p.ntiles);  // XCD-aware tile order (common.h)
+    int tile = tw.tile;
+    if (tile < tw.end) fetch(tile);
+    for (; tile < tw.end; tile += tw.step) {
         const int n = nn, oy0 = noy0, ox0 = nox0;
 #pragma unroll
         for (int i = 0; i < ST_NLOAD; ++i)
             if (tid + 256 * i < ST_NITEM) img_item_park<T>(pre[i], simg + (it_r[i] * ST_ROWPX + 4 * it_j[i]) * 4);
         __syncthreads();  // image patch visible; every wave is done with the previous tile's LDS
-        if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+        if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
         // ---- layer 0: 297 patch pixels = 10 MFMA pixel tiles, dealt round-robin to the 4 waves ----------------------
         const int r00 = 2 * oy0 - 1, c00 = 2 * ox0 - 1;  // layer-0 coordinates of patch entry (0, 0)
