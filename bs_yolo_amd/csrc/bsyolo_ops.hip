@@ -138,6 +138,104 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const half_t* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-tiled form for the square stride-1 kernels of PMSFA (5 x 5, 7 x 7; block.py:3035-3054) and MSCA's conv0: PMSFA runs them on
+// 16 .. 64 channels, where a pixel's piece of the map is 32 .. 128 bytes and the window form above turns every load instruction
+// into 32 cache lines (model.2's 5 x 5 on 160 x 160 x 16: 0.18 ms for 105 MB of traffic).  Here a workgroup owns an 8 x TW pixel
+// tile of NCH 8-channel chunks (TW = 128 / NCH: 32 pixels x 32 channels .. 128 pixels x 8 channels), stages the (8 + K - 1) x
+// (TW + K - 1) input patch with row-contiguous 16-byte loads (zero padding = the descriptor's out-of-range result) and the K * K
+// weight rows of its channels into LDS, and every thread computes 4 consecutive pixels of one chunk from a register window of
+// 4 + K - 1 LDS reads per kernel row.  Arithmetic = dwconv_win_kernel's, step for step (bias first, taps in (dy, dx) order as
+// f32 FMAs on the f16 inputs): the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DWT_TH 8
+template <int K, int NCH>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const half_t* __restrict__ src, int lds_, int H, int W, int C,
+                                                          const float* __restrict__ w, int wld, const float* __restrict__ bias,
+                                                          half_t* __restrict__ dst, int ldd, int act_c, unsigned span, int tiles_x,
+                                                          int tiles_y, int ncg) {
+    constexpr int TW = 128 / NCH, PH = DWT_TH + K - 1, PW = TW + K - 1;
+    constexpr int PXS = NCH * 8 + 8;            // halves per patch pixel: one 16-byte piece of padding spreads the window reads over the banks
+    constexpr int NPIECE = PH * PW * NCH;
+    constexpr int NWIN = 4 + K - 1;
+    __shared__ __attribute__((aligned(16))) half_t sp[PH * PW * PXS];
+    __shared__ __attribute__((aligned(16))) float sw[(K * K + 1) * NCH * 8];  // [tap][channel of this group], then the bias row
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int cg = t % ncg; t /= ncg;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int c0 = cg * NCH * 8;                     // first channel of this workgroup
+    const int nch = min(NCH, (C - c0) >> 3);         // chunks that exist (the last channel group may be narrower)
+    const int oy0 = ty * DWT_TH, ox0 = tx * TW;
+    const bo_rsrc_t rs = bo_make_rsrc(src, span);
+    for (int i = tid; i < (K * K + 1) * NCH * 8; i += 256) {
+        const int row = i / (NCH * 8), c = i - row * (NCH * 8);
+        sw[i] = c < nch * 8 ? (row < K * K ? w[(size_t)row * wld + c0 + c] : bias[c0 + c]) : 0.f;
+    }
+    for (int i = tid; i < NPIECE; i += 256) {
+        const int ch = i % NCH, px = (i / NCH) % PW, py = i / (NCH * PW);
+        const int y = oy0 - K / 2 + py, x = ox0 - K / 2 + px;
+        const bool ok = ch < nch && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const half8 v = bo_load16(rs, ok ? 2u * ((unsigned)((n * H + y) * W + x) * (unsigned)lds_ + (unsigned)(c0 + ch * 8)) : BO_OOB);
+        *reinterpret_cast<half8*>(sp + (py * PW + px) * PXS + ch * 8) = v;
+    }
+    __syncthreads();
+    // item = (tile row, group of 4 pixels, chunk): 8 x (TW / 4) x NCH = 256 items, one per thread
+    const int ch = tid % NCH, gx = (tid / NCH) % (TW / 4), gy = tid / (NCH * (TW / 4));
+    if (ch >= nch) return;
+    float acc[4][8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sw + K * K * NCH * 8 + ch * 8), b1 = *reinterpret_cast<const f32x4*>(sw + K * K * NCH * 8 + ch * 8 + 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[p][j] = b0[j]; acc[p][4 + j] = b1[j]; }
+    }
+#pragma unroll 1
+    for (int dy = 0; dy < K; ++dy) {
+        const half_t* row = sp + ((gy + dy) * PW + 4 * gx) * PXS + ch * 8;
+        half8 win[NWIN];
+#pragma unroll
+        for (int q = 0; q < NWIN; ++q) win[q] = *reinterpret_cast<const half8*>(row + q * PXS);
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+            const float* wp = sw + (dy * K + dx) * NCH * 8 + ch * 8;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fma_mix8(acc[p], win[p + dx], w0, w1);
+        }
+    }
+    const int oy = oy0 + gy, c = c0 + ch * 8;
+    if (oy >= H) return;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int ox = ox0 + 4 * gx + p;
+        if (ox >= W) break;
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(c + j < act_c ? silu_f(acc[p][j]) : acc[p][j]);
+        *reinterpret_cast<half8*>(dst + ((size_t)(n * H + oy) * W + ox) * ldd + c) = o;
+    }
+}
+
+template <int K>
+static void launch_dw_tile(const DwGenArgs& a, unsigned span, hipStream_t s) {
+    const int nchunks = a.C / 8;
+    const int NCH = nchunks >= 4 ? 4 : (nchunks >= 2 ? 2 : 1);
+    const int TW = 128 / NCH;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + DWT_TH - 1) / DWT_TH, ncg = (nchunks + NCH - 1) / NCH;
+    const unsigned grid = (unsigned)((long long)a.B * tiles_y * tiles_x * ncg);
+#define DWT_GO(NCH_)                                                                                                          \
+    hipLaunchKernelGGL((dwconv_tile_kernel<K, NCH_>), dim3(grid), dim3(256), 0, s, a.src, a.lds, a.H, a.W, a.C, a.w, a.wld, a.b, \
+                       a.dst, a.ldd, a.act_c, span, tiles_x, tiles_y, ncg)
+    if (NCH == 4) DWT_GO(4);
+    else if (NCH == 2) DWT_GO(2);
+    else DWT_GO(1);
+#undef DWT_GO
+}
+
 int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s) {
     if (!a.src || !a.dst || !a.w || !a.b) BSY_FAIL(BSY_ERR_ARG, "dwconv: null pointer");
     if ((a.C & 7) || (a.lds & 7) || (a.ldd & 7) || (a.wld & 3) || ((uintptr_t)a.src & 15) || ((uintptr_t)a.dst & 15) ||
@@ -156,7 +254,12 @@ int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s) {
 #define DWG_WIN(KW_, S_)                                                                                                     \
     hipLaunchKernelGGL((dwconv_win_kernel<KW_, S_>), dim3((unsigned)((totw + 255) / 256)), dim3(256), 0, s, a.src, a.lds, a.B, \
                        a.H, a.W, a.C, OH, OW, a.kh, a.w, a.wld, a.b, a.dst, a.ldd, a.act_c, span)
-    if (a.kw == 1 && a.stride == 1) DWG_WIN(1, 1);
+    // square 5 x 5 / 7 x 7 stride-1 kernels: the LDS-tiled form (tile grid small enough for a 32-bit block index)
+    const bool tiled = a.kh == a.kw && (a.kw == 5 || a.kw == 7) && a.stride == 1 && !getenv("BSY_NO_DWTILE") &&
+                       (long long)a.B * ((a.H + 7) / 8) * ((a.W + 31) / 32) * (a.C / 8) < 0x7fffffffLL;
+    if (tiled && a.kw == 5) launch_dw_tile<5>(a, span, s);
+    else if (tiled) launch_dw_tile<7>(a, span, s);
+    else if (a.kw == 1 && a.stride == 1) DWG_WIN(1, 1);
     else if (a.kw == 3 && a.stride == 2) DWG_WIN(3, 2);
     else if (a.kw == 5 && a.stride == 1) DWG_WIN(5, 1);
     else if (a.kw == 7 && a.stride == 1) DWG_WIN(7, 1);

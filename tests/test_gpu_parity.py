@@ -417,6 +417,27 @@ def test_dwconv_generic_matches_oracle(kh, kw, stride, act):
     np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("k,shape,c", [(5, (2, 37, 45), 16), (7, (2, 37, 45), 16), (5, (1, 20, 20), 64), (7, (3, 8, 100), 32), (7, (1, 40, 40), 8),
+                                       (5, (2, 9, 13), 24), (7, (1, 160, 160), 40)])
+def test_dwconv_tiled_equals_window_kernel_and_oracle(k, shape, c, monkeypatch):
+    """LDS-tiled depthwise 5 x 5 / 7 x 7 (dwconv_tile_kernel: PMSFA's convs, block.py:3035-3054) against the window kernel -- the same
+    FMAs in the same order, so bit for bit -- and the fp32 reference: 1 / 2 / 4 chunks per workgroup, a narrower last channel group
+    (24, 40 channels), ragged tile rows and columns, maps smaller than a tile."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(100 * k + c)
+    x = h16(torch.randn(B, c, H, W, generator=g))
+    w = torch.randn(c, 1, k, k, generator=g) * (1.0 / (k * k)) ** 0.5
+    b = torch.randn(c, generator=g) * 0.2
+    ref = F.silu(F.conv2d(x, w, b, 1, k // 2, 1, c))
+    xd = nhwc(x).half().to(DEV)
+    out = O.dwconv_nhwc(xd, w, b, 1, True)
+    monkeypatch.setenv("BSY_NO_DWTILE", "1")
+    base = O.dwconv_nhwc(xd, w, b, 1, True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, base)
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("tag", ["ela64", "ela256", "ela40", "ela24"])  # 40 / 24: GroupNorm groups of 20 / 24 channels
 def test_ela_matches_reference_golden(tag):
     """ELA (nn/Addmodules/ELA.py:33-101) through bsy_ela against the fork's own module output (modules_bsyolo.npz)."""
