@@ -8,6 +8,13 @@ Three hooks, each using an extension point the reference already has (see INTEGR
                            ``model.yaml`` (the dict parse_model consumed, nn/tasks.py:313-321) and the weights from
                            ``model.state_dict()``.  Anything the engine does not cover (training mode, augment / visualize /
                            embed (tasks.py:134-164), CPU tensors, unsupported modules) goes to the original forward.
+  install(model)           per-module hook (the fallback level for graphs `accelerate` does not cover: a custom block, an
+                           unknown head).  Rebinds ``forward`` on every ``Conv`` / ``DWConv`` INSTANCE (nn/modules/conv.py:133-151,
+                           :224-229) -- again the reference's own idiom, ``m.forward = m.forward_fuse`` (nn/tasks.py:215) -- so
+                           that the block modules' Python forwards (C3k2, C2f, SPPF, C2PSA, PMSFA ... call their child Convs) run
+                           every convolution through ``bsy_conv2d`` / ``bsy_conv_first`` / ``bsy_dwconv``.  Activations stay
+                           torch tensors in channels_last memory format (= the kernels' NHWC, no copies); everything that is
+                           not a conv (cat, chunk, upsample, pooling, attention, the head's decode) stays with torch.
   install_nms(ops_module)  ``ultralytics.utils.ops.non_max_suppression`` is looked up as a module attribute on every
                            call (models/yolo/detect/predict.py:25, detect/val.py:95): replacing the attribute suffices.
   install_masks(ops_module) same for ``ultralytics.utils.ops.process_mask`` (models/yolo/segment/predict.py:53).
@@ -136,6 +143,129 @@ def restore(model):
                 st[k].close()
         del model._bsy_orig_forward, model._bsy_state
     return model
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-module hook
+# ---------------------------------------------------------------------------------------------------------------------
+def _conv_spec(m):
+    """(kind, k, s, act) if `m` is a reference Conv / DWConv instance the kernels cover, else None."""
+    conv, act = getattr(m, "conv", None), getattr(m, "act", None)
+    if not isinstance(conv, torch.nn.Conv2d) or act is None or type(m).__name__ not in ("Conv", "DWConv"):
+        return None
+    if isinstance(act, torch.nn.SiLU):
+        a = 1
+    elif isinstance(act, torch.nn.Identity):
+        a = 0
+    else:
+        return None
+    (kh, kw), (sh, sw), (ph, pw) = conv.kernel_size, conv.stride, conv.padding
+    if kh != kw or sh != sw or conv.dilation != (1, 1) or (ph, pw) != (kh // 2, kw // 2) or conv.padding_mode != "zeros":
+        return None
+    c1, c2, g = conv.in_channels, conv.out_channels, conv.groups
+    if g == 1 and kh in (1, 3) and sh in (1, 2) and c1 % 8 == 0 and c2 % 8 == 0:
+        return ("conv", kh, sh, a)
+    if g == 1 and c1 == 3 and (kh, sh) == (3, 2) and c2 % 8 == 0:
+        return ("first", kh, sh, a)
+    if g == c1 == c2 and kh % 2 == 1 and kh <= 31 and sh in (1, 2) and c1 % 8 == 0:
+        return ("dw", kh, sh, a)
+    return None
+
+
+def _conv_forward(m, spec):
+    """The replacement forward of one Conv / DWConv instance.  Falls back to the module's own forward for anything but a
+    fp16 CUDA NCHW tensor in eval mode; re-packs its weights when they change (``Tensor._version`` / storage)."""
+    from .ops import _p, _stream, pack_conv_weight
+    from .weights import fold_conv_bn
+    import ctypes as C
+    kind, k, s, act = spec
+    orig = m.forward
+    st = {"ver": None, "dev": None, "w": None, "b": None, "calls": 0, "fallbacks": 0}
+
+    def pack(dev):
+        sd = {"m.conv." + n: t for n, t in m.conv.state_dict().items()}
+        bn = getattr(m, "bn", None)
+        if st["fold_bn"]:
+            sd.update({"m.bn." + n: t for n, t in bn.state_dict().items()})
+        elif "m.conv.bias" not in sd:
+            sd["m.conv.bias"] = torch.zeros(m.conv.out_channels)
+        w, b = fold_conv_bn(sd, "m", float(bn.eps) if isinstance(bn, torch.nn.BatchNorm2d) else BN_EPS)
+        if kind == "dw":
+            c = m.conv.out_channels
+            st["w"] = w.view(c, k * k).t().contiguous().to(dev)
+            st["b"] = b.contiguous().to(dev)
+        else:
+            st["w"], st["b"] = pack_conv_weight(w, b, dev)
+
+    def fwd(self, x):
+        if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float16 or x.dim() != 4 or self.training
+                or x.shape[1] != self.conv.in_channels):
+            st["fallbacks"] += 1
+            return orig(x)
+        ver = _weights_version(self)
+        if st["ver"] != ver or st["dev"] != x.device:
+            pack(x.device)
+            st["ver"], st["dev"] = ver, x.device
+        B, c1, H, W = x.shape
+        c2 = self.conv.out_channels
+        OH, OW = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+        out = torch.empty((B, OH, OW, c2), dtype=torch.float16, device=x.device)
+        with torch.cuda.device(x.device):
+            if kind == "first":
+                xi = x.contiguous()
+                _L.check(_L.lib.bsy_conv_first(_p(xi), _L.dtype_code(xi.dtype), B, H, W, _p(st["w"]), _p(st["b"]), _p(out), c2, c2, k, s,
+                                               act, _stream(x)))
+            else:
+                xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)  # NHWC view, no copy when already channels_last
+                if kind == "conv":
+                    _L.check(_L.lib.bsy_conv2d(_p(xn), c1, B, H, W, c1, _p(st["w"]), _p(st["b"]), _p(out), c2, c2, k, s, act, None, 0, 0,
+                                               _stream(x)))
+                else:
+                    _L.check(_L.lib.bsy_dwconv(_p(xn), c1, B, H, W, c1, k, k, s, _p(st["w"]), c1, _p(st["b"]), _p(out), c2, act, _stream(x)))
+        st["calls"] += 1
+        return out.permute(0, 3, 1, 2)  # NCHW tensor in channels_last memory format
+
+    # un-fused module (its forward = conv -> bn -> act): BatchNorm is folded at pack time; after BaseModel.fuse() (tasks.py:209-215:
+    # conv replaced by the fused conv, `bn` deleted, forward = forward_fuse) conv.bias already holds it
+    st["fold_bn"] = isinstance(getattr(m, "bn", None), torch.nn.BatchNorm2d) and getattr(orig, "__name__", "") != "forward_fuse"
+    return fwd, st
+
+
+def install(model, verbose: bool = False) -> int:
+    """Per-module hook: every covered Conv / DWConv instance of `model` runs its convolution in the HIP library (fp16 CUDA
+    inputs in eval mode; anything else reaches the module's own forward).  Returns the number of instances rebound;
+    `uninstall(model)` undoes it.  Call it AFTER `model.fuse()` if the model is to be fused (fuse() rebinds `forward` itself).
+    Use `accelerate(model)` where the whole graph is covered -- it is 5-10x faster (fused blocks,
+    no per-layer Python); this is the level for graphs with modules the engine does not know."""
+    n = 0
+    for name, m in model.named_modules():
+        if hasattr(m, "_bsy_conv"):
+            continue
+        spec = _conv_spec(m)
+        if spec is None:
+            continue
+        fwd, st = _conv_forward(m, spec)
+        st["orig"] = m.__dict__.get("forward")  # an instance attribute (set by fuse()) or None (the class method)
+        m._bsy_conv = st
+        m.forward = types.MethodType(fwd, m)
+        n += 1
+        if verbose:
+            print(f"bs_yolo_amd.install: {name} -> {spec}")
+    return n
+
+
+def uninstall(model) -> int:
+    n = 0
+    for m in model.modules():
+        st = m.__dict__.pop("_bsy_conv", None)
+        if st is None:
+            continue
+        if st["orig"] is None:
+            del m.forward
+        else:
+            m.forward = st["orig"]
+        n += 1
+    return n
 
 
 def install_nms(ops_module):

@@ -319,3 +319,128 @@ def test_install_preprocess_dispatch():
     assert torch.equal(out.cpu(), want.half())
     t = torch.zeros(1, 3, 64, 96)
     assert p.preprocess(t) is t and p.calls == 1  # tensor sources skip the letterbox (predictor.py:123-134)
+
+
+# ---- per-module hook: plugin.install on stand-ins for the reference's Conv / DWConv classes -------------------------
+class Conv(torch.nn.Module):
+    """nn/modules/conv.py:133-151: conv -> bn -> act, `forward_fuse` = conv -> act (the class NAME is what plugin.install keys on)."""
+
+    def __init__(self, c1, c2, k=1, s=1, g=1, act=True):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(c1, c2, k, s, k // 2, groups=g, bias=False)
+        self.bn = torch.nn.BatchNorm2d(c2)
+        self.act = torch.nn.SiLU() if act is True else (act if isinstance(act, torch.nn.Module) else torch.nn.Identity())
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+    def forward_fuse(self, x):
+        return self.act(self.conv(x))
+
+
+class DWConv(Conv):
+    """nn/modules/conv.py:224-229."""
+
+    def __init__(self, c1, c2, k=1, s=1, act=True):
+        super().__init__(c1, c2, k, s, g=c1, act=act)
+
+
+class Block(torch.nn.Module):
+    """A block the engine has never heard of: C2f-like split / cat, a depthwise 5x5, an upsample and a pooling branch."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.cv1 = Conv(c, c, 1)
+        self.m = Conv(c // 2, c // 2, 3)
+        self.dw = DWConv(c // 2, c // 2, 5, act=False)
+        self.cv2 = Conv(c + c // 2, c, 1)
+        self.odd = Conv(c, c, 3, act=torch.nn.ReLU())   # an activation the kernels do not cover: stays with torch
+
+    def forward(self, x):
+        a, b = self.cv1(x).chunk(2, 1)
+        y = torch.cat((a, b, self.dw(self.m(b)) + b), 1)
+        return self.cv2(y) + torch.nn.functional.max_pool2d(x, 3, 1, 1)
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stem = Conv(3, 16, 3, 2)
+        self.down = Conv(16, 32, 3, 2)
+        self.b1 = Block(32)
+        self.d2 = Conv(32, 64, 3, 2)
+        self.b2 = Block(64)
+        self.head = Conv(96, 16, 1, act=False)
+
+    def forward(self, x):
+        p3 = self.b1(self.down(self.stem(x)))
+        p4 = self.b2(self.d2(p3))
+        up = torch.nn.functional.interpolate(p4, scale_factor=2.0, mode="nearest")
+        return self.head(torch.cat((up, p3), 1))
+
+
+def _randomise(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.weight.shape, generator=g) * 0.6 + 0.7
+            m.bias.data = torch.rand(m.bias.shape, generator=g) * 0.4 - 0.2
+            m.running_mean.data = torch.rand(m.running_mean.shape, generator=g) * 0.4 - 0.2
+            m.running_var.data = torch.rand(m.running_var.shape, generator=g) + 0.5
+
+
+def _fuse(net):
+    """BaseModel.fuse (nn/tasks.py:209-215) on the stand-ins: fold BN into the conv, drop `bn`, forward = forward_fuse."""
+    from bs_yolo_amd.weights import fold_conv_bn
+    for m in net.modules():
+        if isinstance(m, Conv) and hasattr(m, "bn"):
+            sd = {"m.conv.weight": m.conv.weight.data, **{"m.bn." + k: v for k, v in m.bn.state_dict().items()}}
+            w, b = fold_conv_bn(sd, "m", m.bn.eps)
+            fused = torch.nn.Conv2d(m.conv.in_channels, m.conv.out_channels, m.conv.kernel_size, m.conv.stride, m.conv.padding,
+                                    groups=m.conv.groups, bias=True)
+            fused.weight.data, fused.bias.data = w, b
+            m.conv = fused
+            delattr(m, "bn")
+            m.forward = m.forward_fuse
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_install_rebinds_every_conv_module_and_matches_torch(fused):
+    torch.manual_seed(3)
+    net = Net().eval()
+    _randomise(net, 3)
+    x = torch.rand(2, 3, 96, 64, generator=torch.Generator().manual_seed(1))
+    with torch.inference_mode():
+        ref = net(x)                                   # fp32 CPU: the "reference" result
+    if fused:
+        _fuse(net)
+        with torch.inference_mode():
+            assert torch.allclose(net(x), ref, atol=1e-4, rtol=1e-4)
+    gpu = net.half().to(DEV)
+    n = plugin.install(gpu)
+    convs = [m for m in gpu.modules() if isinstance(m, Conv)]
+    covered = [m for m in convs if hasattr(m, "_bsy_conv")]
+    assert n == len(covered) == len(convs) - 2 and all(not isinstance(m.act, torch.nn.ReLU) for m in covered)
+    with torch.inference_mode():
+        y = gpu(x.half().to(DEV))
+    torch.cuda.synchronize()
+    assert all(m._bsy_conv["calls"] == 1 and m._bsy_conv["fallbacks"] == 0 for m in covered)
+    assert y.dtype == torch.float16 and y.shape == ref.shape
+    d = (y.float().cpu() - ref).abs()
+    assert d.max() < 3e-2 * max(1.0, ref.abs().max().item()) and d.mean() < 3e-3, (d.max(), d.mean())
+    # weights change -> re-packed on the next call (EMA / load_state_dict / fine-tuning between evals)
+    with torch.no_grad():
+        covered[1].conv.weight.mul_(0.5)
+    with torch.inference_mode():
+        y2 = gpu(x.half().to(DEV))
+    assert not torch.equal(y2, y)
+    # fp32 / CPU inputs and training mode reach the modules' own forwards
+    st = covered[0]._bsy_conv
+    before = st["fallbacks"]
+    cpu = gpu.float().cpu()
+    with torch.inference_mode():
+        y32 = cpu(x)
+    assert y32.dtype == torch.float32 and st["fallbacks"] == before + 1 and y32.shape == ref.shape
+    # uninstall restores the original attribute state (instance `forward` only where fuse() had set one)
+    assert plugin.uninstall(cpu) == n
+    assert all(("forward" in m.__dict__) == fused for m in convs) and not any(hasattr(m, "_bsy_conv") for m in convs)
