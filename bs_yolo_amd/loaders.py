@@ -370,3 +370,13 @@ def predict_stream(engine, loader: LoadImagesPinned, conf: float = 0.25, iou: fl
         det, counts = nms_batched(y, conf, iou, classes=classes, agnostic=agnostic, max_det=max_det)
         scale_boxes_batched(det, counts, batch.im.shape[2:], batch.orig_shapes)
         yield batch, det, counts
+
+
+def predict_results(engine, loader: LoadImagesPinned, names=None, **kw):
+    """`predict_stream` with the reference's return type: a list of `results.Results` per batch (engine/predictor.py:240-262 +
+    models/yolo/detect/predict.py:20-45), boxes as device-resident row views of the NMS output."""
+    from .results import build_results
+    names = names or getattr(engine, "names", None) or {}
+    for batch, det, counts in predict_stream(engine, loader, **kw):
+        yield build_results(det, counts, batch.im0s, batch.paths, names, batch.orig_shapes)
+
