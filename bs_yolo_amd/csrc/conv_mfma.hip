@@ -617,33 +617,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
         if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES, s_tap, s_cb, tap, c8); BSY_ADVANCE_K(); }
         const half_t* sP = smem + (kt % STAGES) * STAGE;
         const half_t* sW = sP + TM * BK;
-        // all fragment reads of the K-step first (distinct registers), then the MFMA burst: the LDS latency is paid
-        // once per K-step instead of once per 16-wide sub-step (the compiler otherwise reuses the fragment registers
-        // and serialises read -> wait -> 4 MFMA -> read ...)
+        // Fragment reads run ONE 16-wide sub-step ahead of the MFMAs that use them (two register sets; the sched_barriers pin the
+        // order -- left alone the scheduler reuses one set and serialises read -> wait -> MFMAs).  The workgroup's waves leave the
+        // barrier together, so with all reads of the K-step in front of its MFMA burst (the round-1 form) every wave read while the
+        // matrix pipes idled and then every wave multiplied while the LDS idled: 20 us of a 10-us MFMA floor on model.8.cv2 with
+        // DMA and epilogue switched off.  Same MFMA order (ks, cout tile, pixel tile): same bits.
         constexpr int KSUB = BK / 16;
-        half8 bfr[KSUB][MT], afr[KSUB][NT];
-#pragma unroll
-        for (int ks = 0; ks < KSUB; ++ks) {
+        half8 bfr[2][MT], afr[2][NT];
+        auto rd = [&](const int ks, const int buf) {
             const int chunk = 2 * ks + lh;
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 const int row = (wm * MT + b) * 32 + lrow;
-                bfr[ks][b] = *reinterpret_cast<const half8*>(sP + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
+                bfr[buf][b] = *reinterpret_cast<const half8*>(sP + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
             }
 #pragma unroll
             for (int a = 0; a < NT; ++a) {
                 const int row = (wn * NT + a) * 32 + lrow;
-                afr[ks][a] = *reinterpret_cast<const half8*>(sW + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
+                afr[buf][a] = *reinterpret_cast<const half8*>(sW + row * BK + ((chunk ^ ((row >> SWS) & (CPR - 1))) << 3));
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA burst (the scheduler would sink them back)
+        };
+        rd(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < KSUB; ++ks)
+        for (int ks = 0; ks < KSUB; ++ks) {
+            if (ks + 1 < KSUB) rd(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int b = 0; b < MT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks & 1][a], bfr[ks & 1][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (p.dbg & 4) {
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.dst)[0] = 1.f;  // keep the accumulators live
