@@ -118,7 +118,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+        sys.exit(f"bench.py needs a ROCm GPU: the product path has no CPU fallback (rank {rank} of {world})")
     # BSY_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow with several ranks on ONE GPU (RCCL refuses two ranks on
     # one device); never a measurement
     backend = os.environ.get("BSY_BENCH_BACKEND", "nccl")

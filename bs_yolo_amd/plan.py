@@ -126,7 +126,12 @@ class Plan:
         self.meta: Dict = {}
         self._lane = 0
         self._build()
-        if os.environ.get("BSY_LANES", "1") == "0":  # test aid: every op on the caller's stream (a serial reference schedule)
+        # Side lanes (the Detect branches on their own streams) pay a fork / join event pair each: worth it when the branch kernels
+        # are long enough to overlap -- from about 12 images of 640 x 640 (measured: 0.74 vs 0.79 ms at 1 image, 0.94 vs 0.96 at 8,
+        # 1.25 vs 1.24 at 16, 1.92 vs 1.87 at 32, 3.3 vs 3.2 at 64).  BSY_LANES=0 / 1 forces one or the other (0: the tests' serial
+        # reference schedule).
+        lanes = os.environ.get("BSY_LANES")
+        if lanes == "0" or (lanes is None and B * H * W < 12 * 640 * 640):
             for o in self.ops:
                 if "lane" in o:
                     o["lane"] = 0
