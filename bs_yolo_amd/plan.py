@@ -63,6 +63,8 @@ class WRec:
     kw: Optional[int] = None           # dwg: kernel width when != k (strip convs)
     post: Optional[str] = None         # dwg: name of a depthwise 1x1 conv folded in after this one (MSCA dilconv)
     coef: Tuple[float, float, float] = (0.0, 0.0, 0.0)  # ela: sigmoid(ch_weight / sp_weight / res_weight), set when packed
+    real_cout: int = 0                 # the module's own output / input channels where the op runs on a width padded to a multiple of 8
+    real_cin: int = 0                  # (Detect's class branch with nc-dependent widths, head.py:39): zero weights in the padding; 0 = as cout / cin
     w_off: int = -1
     b_off: int = -1
 
@@ -155,7 +157,7 @@ class Plan:
     def conv(self, name: str, src: Union[T, Sequence[T]], cout: int, k: int = 1, s: int = 1, act: bool = True,
              dst: Optional[T] = None, res: Optional[T] = None, plain: bool = False, out_f32: bool = False,
              perm: Optional[List[int]] = None, name2: Optional[str] = None, wkind: Optional[str] = None,
-             wshape: Optional[Tuple[int, int, int]] = None) -> T:
+             wshape: Optional[Tuple[int, int, int]] = None, real: Tuple[int, int] = (0, 0)) -> T:
         """name2: a second Conv module of the same input and kernel whose output channels follow this one's (weights.py
         kind "conv2": the two folded weight matrices stacked along cout) -- one launch for both, cout = the total."""
         srcs = [src] if isinstance(src, T) else list(src)
@@ -175,7 +177,8 @@ class Plan:
             key = self._wrec(name + "+" + name2, name=name, kind="conv2", cout=cout, cin=cin, k=k, post=name2)
         else:
             wc, wi, wk = wshape or (cout, cin, k)  # wshape: the module's own weight shape where the op runs a re-laid-out copy
-            key = self._wrec(name, name=name, kind=wkind or ("plain" if plain else "conv"), cout=wc, cin=wi, k=wk, perm=perm)
+            key = self._wrec(name, name=name, kind=wkind or ("plain" if plain else "conv"), cout=wc, cin=wi, k=wk, perm=perm,
+                             real_cout=real[0], real_cin=real[1])
         self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
                              src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
                              act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane, cout=cout,
@@ -204,11 +207,11 @@ class Plan:
         self.flops += 2 * self.B * OH * OW * cout * 3 * k * k
         return dst
 
-    def dwconv(self, name: str, src: T, act: bool, dst: Optional[T] = None, res: Optional[T] = None) -> T:
+    def dwconv(self, name: str, src: T, act: bool, dst: Optional[T] = None, res: Optional[T] = None, real_c: int = 0) -> T:
         assert not src.up
         if dst is None:
             dst = self.alloc(src.C, src.H, src.W)
-        key = self._wrec(name, name=name, kind="dw", cout=src.C, cin=1, k=3)
+        key = self._wrec(name, name=name, kind="dw", cout=src.C, cin=1, k=3, real_cout=real_c)
         self.ops.append(dict(kind=L.OP_DWCONV, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, dst=dst, res=res,
                              ksize=3, stride=1, pad=1, act=int(act), wkey=key, name=name, lane=self._lane))
         self.flops += 2 * self.B * src.H * src.W * src.C * 9
@@ -229,14 +232,15 @@ class Plan:
         self.flops += 2 * self.B * OH * OW * src.C * kh * kw
         return dst
 
-    def dwpw(self, name: str, src: T, cout: int) -> T:
+    def dwpw(self, name: str, src: T, cout: int, real: Tuple[int, int] = (0, 0)) -> T:
         """nn.Sequential(DWConv(c, c, 3), Conv(c, cout, 1)) (head.py:49-57): one fused launch where conv_mfma.hip's
-        dwpw_fused_kernel takes the widths, else the two ordinary launches."""
+        dwpw_fused_kernel takes the widths, else the two ordinary launches.  real = the modules' own (cout, cin) where `cout` / `src`
+        are padded to a multiple of 8."""
         if not (self.fuse_dwpw and dwpw_supported(src.C, cout) and not src.up):
-            t = self.dwconv(name + ".0", src, act=True)
-            return self.conv(name + ".1", t, cout, 1, 1)
-        kd = self._wrec(name + ".0", name=name + ".0", kind="dw", cout=src.C, cin=1, k=3)
-        kp = self._wrec(name + ".1", name=name + ".1", kind="conv", cout=cout, cin=src.C, k=1, perm=None)
+            t = self.dwconv(name + ".0", src, act=True, real_c=real[1])
+            return self.conv(name + ".1", t, cout, 1, 1, real=real)
+        kd = self._wrec(name + ".0", name=name + ".0", kind="dw", cout=src.C, cin=1, k=3, real_cout=real[1])
+        kp = self._wrec(name + ".1", name=name + ".1", kind="conv", cout=cout, cin=src.C, k=1, perm=None, real_cout=real[0], real_cin=real[1])
         dst = self.alloc(cout, src.H, src.W)
         self.ops.append(dict(kind=L.OP_DWPW, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, dst=dst, ksize=3, stride=1, pad=1,
                              act=1, wkey=kd, wkey2=kp, name=name, lane=self._lane,
@@ -463,9 +467,9 @@ class Plan:
         self.meta.update(proto_hw=(p.H, p.W))
         return p
 
-    def _head_conv(self, name: str, src: T, cout: int, mode: int, level: int, a0: int, A: int, nc: int, stride: float):
+    def _head_conv(self, name: str, src: T, cout: int, mode: int, level: int, a0: int, A: int, nc: int, stride: float, real_cin: int = 0):
         """Last 1x1 conv of a Detect branch with the decoder fused into its epilogue (out_f32 = mode 2 / 3)."""
-        key = self._wrec(name, name=name, kind="plain", cout=cout, cin=src.C, k=1, perm=None)
+        key = self._wrec(name, name=name, kind="plain", cout=cout, cin=src.C, k=1, perm=None, real_cin=real_cin)
         y = T(L.BSY_EXT_BASE + self.EXT_Y, 0, 0, 4 + nc, 0, 0)
         raw = T(L.BSY_EXT_BASE + self.EXT_RAW0 + level, 0, 0, 64 + nc, 0, 0)
         self.ops.append(dict(kind=L.OP_CONV, H=src.H, W=src.W, OH=src.H, OW=src.W, src0=src, src1=None, dst=y, res=None,
@@ -517,16 +521,20 @@ class Plan:
                 else:
                     boxes.append(self.conv(f"{name}.cv2.{i}.2", t, 64, 1, 1, act=False, plain=True, out_f32=True))
             self._lane = 2 * i + 1
+            # c3 = max(ch0, min(nc, 100)) (head.py:39) need not be a multiple of 8 (YOLO11n with 65 .. 100 or more classes: 100): the
+            # branch then runs c3p channels wide with zero weights / biases in the padding -- SiLU(0) = 0 all the way, same results
+            c3p = make_divisible(c3, 8)
+            r3 = c3 if c3p != c3 else 0
             if legacy:
-                t = self.conv(f"{name}.cv3.{i}.0", x, c3, 3, 1)
-                t = self.conv(f"{name}.cv3.{i}.1", t, c3, 3, 1)
+                t = self.conv(f"{name}.cv3.{i}.0", x, c3p, 3, 1, real=(r3, 0))
+                t = self.conv(f"{name}.cv3.{i}.1", t, c3p, 3, 1, real=(r3, r3))
             else:
-                t = self.dwpw(f"{name}.cv3.{i}.0", x, c3)
-                t = self.dwpw(f"{name}.cv3.{i}.1", t, c3)
+                t = self.dwpw(f"{name}.cv3.{i}.0", x, c3p, real=(r3, 0))
+                t = self.dwpw(f"{name}.cv3.{i}.1", t, c3p, real=(r3, r3))
             if fused:
-                self._head_conv(f"{name}.cv3.{i}.2", t, nc, 2, i, a0[i], A, nc, strides[i])
+                self._head_conv(f"{name}.cv3.{i}.2", t, nc, 2, i, a0[i], A, nc, strides[i], real_cin=r3)
             else:
-                clss.append(self.conv(f"{name}.cv3.{i}.2", t, nc, 1, 1, act=False, plain=True, out_f32=True))
+                clss.append(self.conv(f"{name}.cv3.{i}.2", t, nc, 1, 1, act=False, plain=True, out_f32=True, real=(0, r3)))
             if nm:
                 self._lane = 2 * len(xs) + i
                 c4 = max(ch[0] // 4, nm)

@@ -69,6 +69,16 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f3
         w, b = torch.cat([w, w2]), torch.cat([b, b2])
     else:
         w, b = fold_conv_bn(sd, r.name, eps)
+    if r.real_cout or r.real_cin:
+        # the op runs wider than the module (plan.py detect(): widths padded to a multiple of 8): zero weights and biases in the padding
+        dw = w.shape[1] == 1 and r.kind in ("dw", "dwg", "dwg_plain", "dwg_ext")
+        co, ci = r.real_cout or r.cout, (1 if dw else (r.real_cin or r.cin))
+        assert tuple(w.shape[:2]) == (co, ci), (r.name, tuple(w.shape), (co, ci))
+        w2 = torch.zeros(r.cout, 1 if dw else r.cin, *w.shape[2:])
+        w2[:co, :ci] = w
+        b2 = torch.zeros(r.cout)
+        b2[:co] = b
+        w, b = w2, b2
     if r.kind == "first_s2d" and not f32:
         # 6x6 stride-2 pad-2 image conv (YOLOv5u's stem, cfg/models/v5/yolov5.yaml:16) = 3x3 stride-1 pad-1 conv over the
         # space-to-depth image [Y][X][(dy, dx, c)] (csrc/elementwise.hip s2d_kernel): input row 2 oy - 2 + kh with kh = 2 a + dy is
@@ -189,20 +199,21 @@ def synth_state_dict(plan: Plan, seed: int = 0, cls_gain: float = 0.1, cls_bias:
             sd[r.name + ".bn.running_var"] = torch.rand(co, generator=g) + 0.5
             continue
         if r.kind == "plain":
-            fan = r.cin * r.k * r.k
-            sd[r.name + ".weight"] = torch.randn(r.cout, r.cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
+            rci = r.real_cin or r.cin
+            fan = rci * r.k * r.k
+            sd[r.name + ".weight"] = torch.randn(r.real_cout or r.cout, rci, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
             if ".cv3." in r.name:
                 sd[r.name + ".weight"] *= cls_gain
-                sd[r.name + ".bias"] = torch.full((r.cout,), float(cls_bias))
+                sd[r.name + ".bias"] = torch.full((r.real_cout or r.cout,), float(cls_bias))
             elif ".cv2." in r.name:
                 sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) + 0.5
             else:
                 sd[r.name + ".bias"] = torch.rand(r.cout, generator=g) * 0.4 - 0.2
             continue
-        cin = 1 if r.kind == "dw" else r.cin
+        cin = 1 if r.kind == "dw" else (r.real_cin or r.cin)
         fan = cin * r.k * r.k
         # kind "conv2": two modules of half the width each, drawn in the order the unmerged plan draws them
-        for nm, co in (((r.name, r.cout // 2), (r.post, r.cout // 2)) if r.kind == "conv2" else ((r.name, r.cout),)):
+        for nm, co in (((r.name, r.cout // 2), (r.post, r.cout // 2)) if r.kind == "conv2" else ((r.name, r.real_cout or r.cout),)):
             sd[nm + ".conv.weight"] = torch.randn(co, cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
             sd[nm + ".bn.weight"] = torch.rand(co, generator=g) * 0.6 + 0.7
             sd[nm + ".bn.bias"] = torch.rand(co, generator=g) * 0.6 - 0.3

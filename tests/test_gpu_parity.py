@@ -1506,6 +1506,39 @@ def test_process_mask_native_and_scale_masks_match_reference_golden():
             np.testing.assert_allclose(s16.float().cpu().numpy(), PP.scale_masks(ph[None, :2].float(), shape).numpy(), rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("fam,nc,task", [("yolo11", 1, "detect"), ("yolo11", 3, "detect"), ("yolo11", 20, "detect"), ("yolov8", 5, "detect"),
+                                         ("yolo11", 2, "segment"), ("yolo11", 101, "detect"), ("yolov8", 70, "detect"), ("yolo11", 91, "segment")])
+def test_engine_class_counts_of_custom_datasets(fam, nc, task):
+    """nc = 1 .. 101 (custom datasets: the class convs have 1, 2, 3, 5, 20, 101 output channels -- not multiples of 8 -- and the class
+    BRANCH is c3 = max(ch0, min(nc, 100)) wide (head.py:39): 70, 91 or 100 channels on the n scale, which the engine pads to a multiple
+    of 8 with zero weights): both precisions against the oracle, fused decoder and Segment's decode op, legacy and depthwise heads."""
+    m = R.Model(fam, "n", nc, task)
+    P = R.synth_params(m, 6)
+    for k in P:
+        if ".cv3." in k and k.endswith(".2.bias"):
+            P[k] = P[k] + 4.0  # some anchors above conf 0.25, whatever nc is
+    cfg = stock_cfg(fam, "n", nc, task)
+    x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(nc))
+    with torch.inference_mode():
+        out = m.forward(P, x)
+    yref = out[0]
+    e32 = YoloEngine(cfg, P, precision="fp32")
+    y32 = e32(x.to(DEV))[0].cpu()
+    assert y32.shape == yref.shape == (2, 4 + nc + (32 if task == "segment" else 0), 12 * 20 + 6 * 10 + 3 * 5)
+    assert float((y32[:, 4:4 + nc] - yref[:, 4:4 + nc]).abs().max()) <= 1e-3 and float((y32[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 160
+    e16 = YoloEngine(cfg, P)
+    for xin in (x.half(), x):   # f16 and f32 output tensors of the fp16 engine
+        y16 = e16(xin.to(DEV))[0].float().cpu()
+        d = (y16 - yref).abs()
+        assert float(d[:, 4:4 + nc].max()) < 1e-2 and float(d[:, :4].max()) < 1.0, (float(d[:, 4:4 + nc].max()), float(d[:, :4].max()))
+    from bs_yolo_amd import nms as HN
+    det, cnt = HN.nms_batched(e16(x.half().to(DEV))[0], 0.25, 0.7, max_det=300, nc=nc)
+    n0 = int(cnt[0])
+    assert int(cnt.sum()) > 0 and (n0 == 0 or float(det[0, :n0, 5].max()) <= nc - 1)
+    e16.close()
+    e32.close()
+
+
 def test_engine_top_level_dwconv_layers_match_oracle():
     """A graph with `DWConv` layers of its own (conv.py:224-229; 3x3 s1 and 5x5 s2) through the engine, both precisions,
     against the oracle."""
