@@ -4,6 +4,7 @@ Run on the MI355X box with ``pytest -m gpu``.  Float kernels: tolerance stated p
 accumulation).  Integer / control-flow work (NMS decisions, letterbox pixels) is compared bit-exactly.
 """
 import json
+import math
 
 import numpy as np
 import pytest
@@ -1537,6 +1538,57 @@ def test_engine_class_counts_of_custom_datasets(fam, nc, task):
     assert int(cnt.sum()) > 0 and (n0 == 0 or float(det[0, :n0, 5].max()) <= nc - 1)
     e16.close()
     e32.close()
+
+
+@pytest.mark.parametrize("fam,scale", [("yolo11", "l"), ("yolo11", "x"), ("yolov8", "m"), ("yolov8", "x"), ("yolov5", "m"), ("yolov5", "l"), ("bsyolo11", "m")])
+def test_engine_large_scales_match_oracle(fam, scale):
+    """The l / x / m scales the golden fixtures do not hold (depth multiples 1.0 - 1.33, widths to 1.5: repeated C3k / C2f / C3 blocks,
+    96-wide box branch of YOLO11x, 640-channel maps of YOLOv8x): fp32 mode at the north-star tolerance, fp16 engine at its stated bounds."""
+    nc = 12 if fam == "bsyolo11" else 80
+    m = R.Model(fam, scale, nc, "detect")
+    P = _damped(R.synth_params(m, 7), 0.7)  # random weights this deep saturate the class scores otherwise (see _damped)
+    cfg = stock_cfg(fam, scale, nc)
+    x = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(7))
+    with torch.inference_mode():
+        yref, _ = m.forward(P, x)
+    e32 = YoloEngine(cfg, P, precision="fp32")
+    y32 = e32(x.to(DEV))[0].cpu()
+    e32.close()
+    assert float((y32[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3 and float((y32[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 96
+    e16 = YoloEngine(cfg, P)
+    d = (e16(x.half().to(DEV))[0].float().cpu() - yref).abs()
+    e16.close()
+    k = 3.0 if fam == "bsyolo11" else 1.0
+    assert float(d[:, 4:].max()) < k * 1e-2 and float(d[:, :4].max()) < k * 1.0, (float(d[:, 4:].max()), float(d[:, :4].max()))
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 1280), (2, 1280, 32), (7, 96, 32), (1, 1600, 1600), (130, 64, 64)])
+def test_engine_extreme_shapes_match_fp32_mode(shape):
+    """Strips, a 1600 x 1600 image and 130 images of 64 x 64: the fp16 engine against the fp32 correctness mode (itself pinned to the
+    reference at 1e-3) -- maps one pixel high at stride 32, 40 000-pixel levels, more images than any tile count assumption."""
+    cfg = stock_cfg("yolo11", "n")
+    m = R.Model("yolo11", "n", 80, "detect")
+    P = R.synth_params(m, 1)
+    B, H, W = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W))
+    e32 = YoloEngine(cfg, P, precision="fp32")
+    y32 = e32(x.to(DEV))[0].cpu()
+    e32.close()
+    e16 = YoloEngine(cfg, P)
+    y16 = e16(x.half().to(DEV))[0].float().cpu()
+    e16.close()
+    assert y16.shape == y32.shape == (B, 84, (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32))
+    d = (y16 - y32).abs()
+    # max over up to 650 000 anchors of the fp16-storage error (stock-graph bounds of the golden tests x 2; mean below 1e-4 / 0.05 px)
+    # boxes leave the fp16 engine as f16 for f16 inputs (as the reference's half model does): one ulp of a coordinate in [1024, 2048)
+    # is a whole pixel, so the box bounds follow the ulp of the image's larger side
+    ulp = 2.0 ** (math.floor(math.log2(max(H, W))) - 10)
+    assert float(d[:, 4:].max()) < 2e-2 and float(d[:, :4].max()) < max(3.0, 3 * ulp), (float(d[:, 4:].max()), float(d[:, :4].max()))
+    assert float(d[:, 4:].mean()) < 1e-4 and float(d[:, :4].mean()) < max(0.05, 0.25 * ulp), (float(d[:, 4:].mean()), float(d[:, :4].mean()))
+    if B * H * W <= 64 * 64 * 8:
+        with torch.inference_mode():
+            yref, _ = m.forward(P, x)
+        assert float((y32[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3
 
 
 def test_engine_top_level_dwconv_layers_match_oracle():
