@@ -136,7 +136,9 @@ def get_sliced_prediction(image, detection_model, slice_height: int = 640, slice
     """`image`: (H, W, 3) u8 (BGR as cv2 reads it when bgr=True);  `detection_model`: a YoloEngine (or any callable
     tiles (B, 3, h, w) -> (pred (B, 4+nc, A), ...)).  Returns (det (K, 6) fp32 [x1 y1 x2 y2 score cls] in image
     pixels, tile boxes).  `conf` is sahi's model_confidence_threshold; iou / max_det are the per-tile NMS settings of
-    the predictor (cfg/default.yaml)."""
+    the predictor (cfg/default.yaml).  `imgsz`: letterbox every slice to this model input size (the reference's flow: sahi hands
+    each slice to the ultralytics predictor); None = feed the slices natively when their size is a multiple of 32, else imgsz 640.
+    Slices larger than the image shrink to it (get_slice_bboxes)."""
     dev = detection_model.device if hasattr(detection_model, "device") else torch.device("cuda:0")
     img = _as_device_image(image, dev)
     H, W = int(img.shape[0]), int(img.shape[1])
@@ -148,10 +150,26 @@ def get_sliced_prediction(image, detection_model, slice_height: int = 640, slice
     s, e = shard_bounds(T, world)[rank]
     dets, cnts = [], []
     step = batch or max(e - s, 1)
+    th, tw = bboxes[0][3] - bboxes[0][1], bboxes[0][2] - bboxes[0][0]
+    # Native tiles (the slice IS the model input: one kernel cuts all of them) when no imgsz is asked for and the slice size suits the
+    # model's stride; otherwise every slice goes through the predictor's letterbox to `imgsz` and its boxes back through scale_boxes
+    # -- what sahi's ultralytics wrapper does with EVERY slice (detect-sahi.py's 800 x 800 slices reach the model at imgsz 640)
+    native = imgsz is None and th % 32 == 0 and tw % 32 == 0
     for i in range(s, e, step):
-        tiles = slice_image(img, bboxes[i:min(i + step, e)], half=half, swap_rb=bgr, device=dev)
+        chunk = bboxes[i:min(i + step, e)]
+        if native:
+            tiles = slice_image(img, chunk, half=half, swap_rb=bgr, device=dev)
+        else:
+            from .letterbox import preprocess
+            size = imgsz or 640  # cfg/default.yaml imgsz
+            crops = [img[b[1]:b[3], b[0]:b[2]] for b in chunk]
+            if not bgr:  # preprocess flips BGR -> RGB (predictor.py:127); an RGB source is flipped back first
+                crops = [c.flip(-1) for c in crops]
+            tiles = preprocess(crops, imgsz=(size, size), half=half, device=dev)
         pred = detection_model(tiles, want_raw=False)[0] if hasattr(detection_model, "plan_for") else detection_model(tiles)[0]
         d, c = nms_batched(pred, conf, iou, max_det=max_det, in_place=True)
+        if not native:
+            scale_boxes_batched(d, c, tiles.shape[2:], [(b[3] - b[1], b[2] - b[0]) for b in chunk])
         dets.append(d)
         cnts.append(c)
     if dets:
@@ -164,7 +182,7 @@ def get_sliced_prediction(image, detection_model, slice_height: int = 640, slice
     if perform_standard_pred and T > 1:  # sahi adds a full-image prediction to the slices'
         from .letterbox import preprocess
         size = imgsz or max(slice_height, slice_width)
-        full = preprocess([img], imgsz=(size, size), half=half, device=dev)
+        full = preprocess([img if bgr else img.flip(-1)], imgsz=(size, size), half=half, device=dev)
         pred = detection_model(full, want_raw=False)[0] if hasattr(detection_model, "plan_for") else detection_model(full)[0]
         d, c = nms_batched(pred, conf, iou, max_det=max_det, in_place=True)
         scale_boxes_batched(d, c, full.shape[2:], [(H, W)])

@@ -352,3 +352,42 @@ def test_sliced_prediction_config5_full_size():
     ref = S.sliced_merge(det.cpu().numpy(), cnt.cpu().numpy(), [[b[0], b[1]] for b in bb], (4000, 6000))
     assert ref.shape[0] == n and np.array_equal(out[:n].cpu().numpy(), ref)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,slice_hw,imgsz", [((900, 1300), (500, 500), 320), ((300, 700), (800, 800), None), ((640, 1280), (640, 640), 320)])
+def test_sliced_prediction_letterboxes_slices_like_the_predictor(hw, slice_hw, imgsz):
+    """The reference's flow -- sahi hands every slice to the ultralytics predictor, which letterboxes it to imgsz and scales the boxes
+    back (detect-sahi.py: 800 x 800 slices at imgsz 640) -- for slice sizes that are not multiples of 32, slices larger than the image
+    (they shrink to it) and an explicit imgsz: equal, bit for bit, to the same stages called one by one (preprocess -> engine -> NMS ->
+    scale_boxes -> merge), each of which has its own parity test."""
+    from bs_yolo_amd import letterbox as HLB, nms as HN, sahi as HS
+    from bs_yolo_amd.engine import YoloEngine
+    from bs_yolo_amd.graphs import stock_cfg
+    from oracle import yolo_ref as R
+    m = R.Model("yolo11", "n", 80, "detect")
+    P = R.synth_params(m, 0)
+    for k in P:
+        if ".cv3." in k and k.endswith(".2.bias"):
+            P[k] = P[k] + 2.5
+    eng = YoloEngine(stock_cfg("yolo11", "n"), P, autotune=False)
+    H, W = hw
+    img = np.random.default_rng(5).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    out, bboxes = HS.get_sliced_prediction(img, eng, slice_hw[0], slice_hw[1], 0.2, 0.2, perform_standard_pred=False, imgsz=imgsz,
+                                           batch=3)
+    assert bboxes == S.get_slice_bboxes(H, W, slice_hw[0], slice_hw[1], 0.2, 0.2)
+    assert all(b[2] <= W and b[3] <= H for b in bboxes)
+    size = imgsz or 640
+    dimg = torch.from_numpy(img).to(DEV)
+    dets, cnts = [], []
+    for x0, y0, x1, y1 in bboxes:
+        t = HLB.preprocess([dimg[y0:y1, x0:x1]], imgsz=(size, size), half=True, device=DEV)
+        d, c = HN.nms_batched(eng(t, want_raw=False)[0], 0.25, 0.7, max_det=300)
+        HN.scale_boxes_batched(d, c, t.shape[2:], [(y1 - y0, x1 - x0)])
+        dets.append(d)
+        cnts.append(c)
+    ref, n = HS.postprocess(torch.cat(dets), torch.cat(cnts), [[b[0], b[1]] for b in bboxes], full_shape=(H, W))
+    n = int(n)
+    assert n > 0 and out.shape == (n, 6) and torch.equal(out, ref[:n])
+    assert float(out[:, 2].max()) <= W and float(out[:, 3].max()) <= H
+    eng.close()
