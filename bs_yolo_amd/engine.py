@@ -50,7 +50,8 @@ class YoloEngine:
         # second level: the same layer (channels, kernel, stride, epilogue) at a similar size (pixel count within a factor of
         # two) reuses the winner without timing -- rect batches differ from each other by a few rows or columns
         self._tune_family: Dict[tuple, int] = {}
-        self.tune_stats = {"timed_ops": 0, "cached_ops": 0, "family_ops": 0, "autotune_calls": 0}
+        self.tune_stats = {"timed_ops": 0, "cached_ops": 0, "family_ops": 0, "autotune_calls": 0, "in_place_flips": 0}
+        self.tune_in_place = os.environ.get("BSY_TUNE_IN_PLACE", "1") != "0"  # second opinion on near-ties, see _autotune
         self._tune_file = os.environ.get("BSY_TUNE_CACHE")
         if self._tune_file and os.path.exists(self._tune_file):
             try:
@@ -141,8 +142,38 @@ class YoloEngine:
         self.tune_stats["cached_ops"] += sum(1 for sg in plan.conv_sigs if sg is not None) - todo
         L.check(L.lib.bsy_plan_autotune(h, ext, n, C.c_void_p(stream)))
         if todo:
-            out = (C.c_int32 * len(plan.ops))()
-            L.check(L.lib.bsy_plan_get_tuning(h, out, len(plan.ops)))
+            nops = len(plan.ops)
+            out = (C.c_int32 * nops)()
+            L.check(L.lib.bsy_plan_get_tuning(h, out, nops))
+            if self.tune_in_place:
+                # Second opinion for near-ties: bsy_plan_autotune launches one layer back to back (operands in L2 / Infinity Cache);
+                # here winner and runner-up of every newly tuned op are timed where they run -- serial profile passes of the whole
+                # forward, all winners then all runner-ups, best of three each -- and the faster one is kept
+                alt = (C.c_int32 * nops)()
+                L.check(L.lib.bsy_plan_get_tuning_alt(h, alt, nops))
+                idx = [i for i, sg in enumerate(plan.conv_sigs) if sg is not None and sg not in self._tune_cache and alt[i] >= 0 and out[i] >= 0]
+                if idx:
+                    def passes(k=3):
+                        best = [1e30] * nops
+                        ms = (C.c_float * nops)()
+                        for _ in range(k):
+                            L.check(L.lib.bsy_plan_profile(h, ext, n, C.c_void_p(stream), ms))
+                            best = [min(b, float(t)) for b, t in zip(best, ms)]
+                        return best
+                    t_win = passes()
+                    sel = (C.c_int32 * nops)(*([-1] * nops))
+                    for i in idx:
+                        sel[i] = alt[i]
+                    L.check(L.lib.bsy_plan_set_tuning(h, sel, nops))
+                    t_alt = passes()
+                    flips = 0
+                    for i in idx:
+                        if t_alt[i] < t_win[i]:
+                            out[i] = alt[i]
+                            flips += 1
+                        sel[i] = out[i]
+                    L.check(L.lib.bsy_plan_set_tuning(h, sel, nops))
+                    self.tune_stats["in_place_flips"] = self.tune_stats.get("in_place_flips", 0) + flips
             for sg, c in zip(plan.conv_sigs, out):
                 if sg is not None and c >= 0:
                     self._tune_cache.setdefault(sg, int(c))

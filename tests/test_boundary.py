@@ -27,6 +27,13 @@ from oracle import yolo_ref as R
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _heuristic_configs(monkeypatch):
+    """These tests compare the engine `accelerate` builds with one built beside it, bit for bit: both run the heuristic kernel
+    configurations (two timing-based autotunes may pick configurations that differ in fp32 summation order)."""
+    monkeypatch.setenv("BSY_AUTOTUNE", "0")
+
+
 class StandIn(torch.nn.Module):
     """What `accelerate` needs of a reference DetectionModel: `.yaml` (nn/tasks.py:313), `state_dict()` under the
     reference's names, `.training`, `.half()/.to()`, and a forward with the reference's signature (tasks.py:112-136)."""
