@@ -682,10 +682,15 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
         op.tuned_cfg = best_cfg + 1;
         // runner-up within 12 %: the host re-times the two IN PLACE (bsy_plan_profile passes of the whole forward) and keeps the one
         // that is faster where it runs -- back-to-back launches of one layer see its operands in the caches, the forward does not
-        float alt = 1e30f;
+        // (two runners-up: reserved0 and, for conv ops unused, head_dim hold them as id + 1)
+        float alt = 1e30f, alt2 = 1e30f;
         op.reserved0 = 0;
-        for (int c = 0; c < nc; ++c)
-            if (cand[c] != best_cfg && best_of[c] < alt && best_of[c] <= 1.12f * best) { alt = best_of[c]; op.reserved0 = cand[c] + 1; }
+        op.head_dim = 0;
+        for (int c = 0; c < nc; ++c) {
+            if (cand[c] == best_cfg || best_of[c] > 1.12f * best) continue;
+            if (best_of[c] < alt) { alt2 = alt; op.head_dim = op.reserved0; alt = best_of[c]; op.reserved0 = cand[c] + 1; }
+            else if (best_of[c] < alt2) { alt2 = best_of[c]; op.head_dim = cand[c] + 1; }
+        }
         a.cfg = best_cfg;
         rc = launch_conv(a, s);
     }
@@ -701,11 +706,11 @@ extern "C" int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n) {
     return BSY_OK;
 }
 
-// HOST array out[n_ops]: the runner-up configuration of the last bsy_plan_autotune for each op it timed (-1 = none within 12 % of the
-// winner, not a conv, or not timed by that call).
-extern "C" int bsy_plan_get_tuning_alt(bsy_plan* p, int32_t* out, int n) {
-    if (!p || !out || n != (int)p->ops.size()) BSY_FAIL(BSY_ERR_ARG, "plan_get_tuning_alt: bad argument");
-    for (int i = 0; i < n; ++i) out[i] = p->ops[i].kind == BSY_OP_CONV ? p->ops[i].reserved0 - 1 : -1;
+// HOST array out[n_ops]: the rank-th runner-up (1 or 2) of the last bsy_plan_autotune for each op it timed (-1 = none within 12 % of
+// the winner, not a conv, or not timed by that call).
+extern "C" int bsy_plan_get_tuning_alt(bsy_plan* p, int rank, int32_t* out, int n) {
+    if (!p || !out || n != (int)p->ops.size() || rank < 1 || rank > 2) BSY_FAIL(BSY_ERR_ARG, "plan_get_tuning_alt: bad argument");
+    for (int i = 0; i < n; ++i) out[i] = p->ops[i].kind == BSY_OP_CONV ? (rank == 1 ? p->ops[i].reserved0 : p->ops[i].head_dim) - 1 : -1;
     return BSY_OK;
 }
 

@@ -149,30 +149,34 @@ class YoloEngine:
                 # Second opinion for near-ties: bsy_plan_autotune launches one layer back to back (operands in L2 / Infinity Cache);
                 # here winner and runner-up of every newly tuned op are timed where they run -- serial profile passes of the whole
                 # forward, all winners then all runner-ups, best of three each -- and the faster one is kept
-                alt = (C.c_int32 * nops)()
-                L.check(L.lib.bsy_plan_get_tuning_alt(h, alt, nops))
-                idx = [i for i, sg in enumerate(plan.conv_sigs) if sg is not None and sg not in self._tune_cache and alt[i] >= 0 and out[i] >= 0]
-                if idx:
-                    def passes(k=3):
-                        best = [1e30] * nops
-                        ms = (C.c_float * nops)()
-                        for _ in range(k):
-                            L.check(L.lib.bsy_plan_profile(h, ext, n, C.c_void_p(stream), ms))
-                            best = [min(b, float(t)) for b, t in zip(best, ms)]
-                        return best
-                    t_win = passes()
+                def passes(k=3):
+                    best = [1e30] * nops
+                    ms = (C.c_float * nops)()
+                    for _ in range(k):
+                        L.check(L.lib.bsy_plan_profile(h, ext, n, C.c_void_p(stream), ms))
+                        best = [min(b_, float(t)) for b_, t in zip(best, ms)]
+                    return best
+                t_cur, flips = None, 0
+                for rank in (1, 2):
+                    alt = (C.c_int32 * nops)()
+                    L.check(L.lib.bsy_plan_get_tuning_alt(h, rank, alt, nops))
+                    idx = [i for i, sg in enumerate(plan.conv_sigs) if sg is not None and sg not in self._tune_cache and alt[i] >= 0 and out[i] >= 0]
+                    if not idx:
+                        break
+                    if t_cur is None:
+                        t_cur = passes()
                     sel = (C.c_int32 * nops)(*([-1] * nops))
                     for i in idx:
                         sel[i] = alt[i]
                     L.check(L.lib.bsy_plan_set_tuning(h, sel, nops))
                     t_alt = passes()
-                    flips = 0
                     for i in idx:
-                        if t_alt[i] < t_win[i]:
-                            out[i] = alt[i]
+                        if t_alt[i] < t_cur[i]:
+                            out[i], t_cur[i] = alt[i], t_alt[i]
                             flips += 1
                         sel[i] = out[i]
                     L.check(L.lib.bsy_plan_set_tuning(h, sel, nops))
+                if flips:
                     self.tune_stats["in_place_flips"] = self.tune_stats.get("in_place_flips", 0) + flips
             for sg, c in zip(plan.conv_sigs, out):
                 if sg is not None and c >= 0:

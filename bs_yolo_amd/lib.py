@@ -92,7 +92,7 @@ def _load() -> C.CDLL:
     lib.bsy_plan_run.argtypes = [vp, C.POINTER(vp), i32, vp]
     lib.bsy_plan_autotune.argtypes = [vp, C.POINTER(vp), i32, vp]
     lib.bsy_plan_get_tuning.argtypes = [vp, C.POINTER(C.c_int32), i32]
-    lib.bsy_plan_get_tuning_alt.argtypes = [vp, C.POINTER(C.c_int32), i32]
+    lib.bsy_plan_get_tuning_alt.argtypes = [vp, i32, C.POINTER(C.c_int32), i32]
     lib.bsy_plan_copy_buffer.argtypes = [vp, i32, vp, C.c_size_t]
     lib.bsy_plan_check_guards.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.bsy_plan_profile.argtypes = [vp, C.POINTER(vp), i32, vp, C.POINTER(f32)]

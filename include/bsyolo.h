@@ -160,9 +160,9 @@ int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream strea
 int bsy_plan_set_tuning(bsy_plan* p, const int32_t* cfg, int n_ops);
 /* HOST out[n_ops]: configuration id per op (tile << 4 | variant), -1 for non-conv / untuned ops. */
 int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n_ops);
-/* HOST array out[n_ops]: the runner-up of the last bsy_plan_autotune per op (-1: none within 12 % of the winner).  The host side re-times
- * winner and runner-up in place with bsy_plan_profile and keeps the faster (bs_yolo_amd/engine.py). */
-int bsy_plan_get_tuning_alt(bsy_plan* p, int32_t* out, int n_ops);
+/* HOST array out[n_ops]: the rank-th runner-up (1 or 2) of the last bsy_plan_autotune per op (-1: none within 12 % of the winner).  The
+ * host side re-times winner and runners-up in place with bsy_plan_profile and keeps the fastest (bs_yolo_amd/engine.py). */
+int bsy_plan_get_tuning_alt(bsy_plan* p, int rank, int32_t* out, int n_ops);
 /* Test aid: plans created with BSY_PLAN_GUARD=<bytes> in the environment keep a guard band of that many bytes (0xA5) behind
  * every workspace buffer; this call synchronises the device and reports the first buffer whose band was written (an
  * out-of-bounds store), *bad_buf = -1 when all are intact. */
