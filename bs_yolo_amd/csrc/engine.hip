@@ -767,6 +767,61 @@ extern "C" int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_st
     return BSY_OK;
 }
 
+// In-place autotune: every candidate configuration of every untuned conv op is timed WHERE IT RUNS -- serial profile passes of the
+// whole forward (bsy_plan_profile's event scheme), pass k running candidate k of every op at once, `rounds` passes per candidate index,
+// best time kept -- instead of back-to-back launches of one layer, which see their operands in L2 / Infinity Cache and ranked near-ties
+// differently from the forward (round 2: re-timing just the top three in place already moved the forward by 0.6-2.4 %).  Ops with a
+// preset (bsy_plan_set_tuning) are left alone.  Costs max_i(#candidates) x rounds forwards (~0.4 s for YOLO11s at 64 x 640 x 640).
+extern "C" int bsy_plan_autotune_in_place(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, int rounds) {
+    if (!p || (n_ext && !ext) || rounds < 1 || rounds > 16) BSY_FAIL(BSY_ERR_ARG, "plan_autotune_in_place: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = p->ops.size();
+    Resolver R{p, ext, n_ext};
+    std::vector<std::vector<int>> cand(n);
+    size_t K = 0;
+    for (size_t i = 0; i < n; ++i) {  // one plain pass: the operands of every op exist, and the conv ops yield their arguments
+        bsy_op& op = p->ops[i];
+        if (op.kind == BSY_OP_CONV && op.tuned_cfg <= 0 && op.prec == 0) {
+            ConvArgs a;
+            int rc = run_op(p, op, R, s, &a);
+            if (rc != BSY_OK) return rc;
+            int list[BSY_CONV_MAX_CFG];
+            const int nc = conv_candidates(a, list, BSY_CONV_MAX_CFG);
+            cand[i].assign(list, list + (nc > 0 ? nc : 0));
+            K = cand[i].size() > K ? cand[i].size() : K;
+        }
+        const int rc = run_op(p, op, R, s);
+        if (rc != BSY_OK) return rc;
+    }
+    if (K == 0) return BSY_OK;
+    std::vector<float> best(n, 1e30f), ms(n);
+    std::vector<int> best_c(n, -1);
+    for (size_t i = 0; i < n; ++i)
+        if (!cand[i].empty()) best_c[i] = cand[i][0];
+    for (size_t k = 0; k < K; ++k) {
+        for (size_t i = 0; i < n; ++i)
+            if (!cand[i].empty()) p->ops[i].tuned_cfg = (k < cand[i].size() ? cand[i][k] : best_c[i]) + 1;
+        for (int r = 0; r < rounds; ++r) {
+            const int rc = bsy_plan_profile(p, ext, n_ext, stream, ms.data());
+            if (rc != BSY_OK) {
+                for (size_t i = 0; i < n; ++i)
+                    if (!cand[i].empty()) p->ops[i].tuned_cfg = 0;
+                return rc;
+            }
+            for (size_t i = 0; i < n; ++i)
+                if (k < cand[i].size() && ms[i] < best[i]) { best[i] = ms[i]; best_c[i] = cand[i][k]; }
+        }
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (!cand[i].empty()) {
+            // near-tie between the two K walks of one tile: the chunk-major one (see bsy_plan_autotune)
+            p->ops[i].tuned_cfg = best_c[i] + 1;
+            p->ops[i].reserved0 = 0;
+            p->ops[i].head_dim = 0;
+        }
+    return BSY_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Stand-alone operators
 // ---------------------------------------------------------------------------------------------------------------

@@ -51,7 +51,10 @@ class YoloEngine:
         # two) reuses the winner without timing -- rect batches differ from each other by a few rows or columns
         self._tune_family: Dict[tuple, int] = {}
         self.tune_stats = {"timed_ops": 0, "cached_ops": 0, "family_ops": 0, "autotune_calls": 0, "in_place_flips": 0}
-        self.tune_in_place = os.environ.get("BSY_TUNE_IN_PLACE", "1") != "0"  # second opinion on near-ties, see _autotune
+        # how conv configurations are timed (see _autotune): "1" every candidate in place (default), "3" one layer at a time
+        # (bsy_plan_autotune) + its top three re-timed in place, "0" one layer at a time only
+        self.tune_mode = os.environ.get("BSY_TUNE_IN_PLACE", "1")
+        self.tune_in_place = self.tune_mode == "3"
         self._tune_file = os.environ.get("BSY_TUNE_CACHE")
         if self._tune_file and os.path.exists(self._tune_file):
             try:
@@ -140,7 +143,11 @@ class YoloEngine:
         self.tune_stats["autotune_calls"] += 1
         self.tune_stats["timed_ops"] += todo
         self.tune_stats["cached_ops"] += sum(1 for sg in plan.conv_sigs if sg is not None) - todo
-        L.check(L.lib.bsy_plan_autotune(h, ext, n, C.c_void_p(stream)))
+        if self.tune_mode == "1":
+            # every candidate of every new conv shape timed where it runs: pass k of the forward runs candidate k of all of them
+            L.check(L.lib.bsy_plan_autotune_in_place(h, ext, n, C.c_void_p(stream), 3))
+        else:
+            L.check(L.lib.bsy_plan_autotune(h, ext, n, C.c_void_p(stream)))
         if todo:
             nops = len(plan.ops)
             out = (C.c_int32 * nops)()

@@ -163,6 +163,10 @@ int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n_ops);
 /* HOST array out[n_ops]: the rank-th runner-up (1 or 2) of the last bsy_plan_autotune per op (-1: none within 12 % of the winner).  The
  * host side re-times winner and runners-up in place with bsy_plan_profile and keeps the fastest (bs_yolo_amd/engine.py). */
 int bsy_plan_get_tuning_alt(bsy_plan* p, int rank, int32_t* out, int n_ops);
+/* The same decision taken in place: candidate k of every untuned conv op runs in pass k of the whole forward (serial, events around every op,
+ * `rounds` passes per k), the fastest configuration per op is recorded.  Costs max(#candidates) x rounds forwards; what bs_yolo_amd/engine.py
+ * uses by default (BSY_TUNE_IN_PLACE=0: bsy_plan_autotune). */
+int bsy_plan_autotune_in_place(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, int rounds);
 /* Test aid: plans created with BSY_PLAN_GUARD=<bytes> in the environment keep a guard band of that many bytes (0xA5) behind
  * every workspace buffer; this call synchronises the device and reports the first buffer whose band was written (an
  * out-of-bounds store), *bad_buf = -1 when all are intact. */
