@@ -34,8 +34,8 @@ PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, ch
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)   # ~1 s of GPU work at the default workload
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scale", default="s")
     ap.add_argument("--family", default="yolo11", choices=["yolo11", "yolov8", "bsyolo11"],
                     help="graph: stock YOLO11 (the headline config), YOLOv8, or the fork's own BS-YOLO graph (nc = 12)")
