@@ -29,6 +29,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_MFMA_F32_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate (same table)
 
 
 def parse():
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling) or in all (strong scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch images per GPU; strong: --batch images in all, split contiguously over the ranks")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"],
+                    help="fp16: the product path (NHWC fp16 activations, the headline); fp32: the engine's fp32 mode -- fp32 storage and "
+                         "arithmetic on the fp32 matrix pipe, what plugin.accelerate gives callers of predict(half=False)")
     ap.add_argument("--serial-nms", action="store_true",
                     help="run NMS (and the detection all-gather) on the forward's stream; default: on a second stream, so that "
                          "NMS of step i runs beside the forward of step i + 1 (every step's work still lies inside the timed region)")
@@ -149,8 +153,10 @@ def main():
 
     cfg = stock_cfg(args.family, args.scale, 12 if args.family == "bsyolo11" else 80, "detect")
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
-    eng = YoloEngine(cfg, sd, device=local)
+    eng = YoloEngine(cfg, sd, device=local, precision=args.precision)
     S = args.imgsz
+    f32 = args.precision == "fp32"
+    peak = PEAK_MFMA_F32_TFLOPS if f32 else PEAK_MFMA_F16_TFLOPS
     if args.scaling == "strong":  # the global batch is fixed: this rank's contiguous share of it (parallel.shard_bounds)
         from bs_yolo_amd.parallel import shard_bounds
         lo, hi = shard_bounds(args.batch, world)[rank]
@@ -160,7 +166,7 @@ def main():
     else:
         B, global_batch = args.batch, world * args.batch
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.rand(B, 3, S, S, generator=g).half().to(dev)
+    x = torch.rand(B, 3, S, S, generator=g).to(torch.float32 if f32 else torch.float16).to(dev)
     if not (args.family == "yolo11" and args.scale == "s"):
         # The class head of synth_state_dict is calibrated for the headline graph (1.5 % of the anchors above conf 0.25).
         # Other graphs: rescale and shift it from the raw class logits of one probe forward (8 images) so that the same
@@ -176,7 +182,7 @@ def main():
             elif ".cv3." in k and k.endswith(".2.bias"):
                 sd[k] = torch.full_like(sd[k], math.log(0.25 / 0.75) - q)
         eng.close()
-        eng = YoloEngine(cfg, sd, device=local)
+        eng = YoloEngine(cfg, sd, device=local, precision=args.precision)
     from bs_yolo_amd.parallel import gather_detections_async
     pending = None   # the previous step's detection all-gather, in flight on RCCL's stream
     gathered = None
@@ -259,29 +265,35 @@ def main():
                 if t is None:
                     continue
                 if o["kind"] in (L.OP_CONV_FIRST, L.OP_STEM) and key == "src0":
-                    fam_bytes += B * 3 * o["H"] * o["W"] * 2
+                    fam_bytes += B * 3 * o["H"] * o["W"] * (4 if f32 else 2)
                 else:
                     fam_bytes += B * o["H"] * o["W"] * t.C * (4 if t.f32 else 2) // (4 if t.up else 1)
             mode = o.get("out_f32", 0)  # 0 f16 map, 1 f32 map, 2 / 3 fused decoder: class rows / 4 box rows of y (f16)
-            fam_bytes += B * o["OH"] * o["OW"] * ({2: o.get("cout", 0), 3: 4}.get(mode, o["dst"].C)) * (4 if mode == 1 else 2)
+            fam_bytes += B * o["OH"] * o["OW"] * ({2: o.get("cout", 0), 3: 4}.get(mode, o["dst"].C)) * (4 if (mode == 1 or f32) else 2)
         achieved = fam_flops / (fam_ms * 1e-3) / 1e12
         # HBM traffic of the same kernel family cannot be sampled from inside the process: it is the PMC measurement
         # committed under profiles/ (tools/pmc_bench_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # passes, gfx950 correction), per launch like `achieved`; only valid for the default workload
-        traffic, tsrc = None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        # passes, gfx950 correction), per launch like `achieved`; only valid for the default workload AND for the plan it was
+        # taken on: the file records the family's launch count, a different count here means the plan has changed since
+        traffic, tsrc, tnote = None, None, None
+        for name in ("r03_traffic.json", "r02_traffic.json"):
             tfile = ROOT / "profiles" / name
-            if tfile.exists() and args.family == "yolo11" and args.scale == "s" and S == 640 and B == 64:
-                traffic = round(json.load(open(tfile))["conv_mfma_hbm_bytes_per_launch_avg"])
+            if tfile.exists() and args.family == "yolo11" and args.scale == "s" and S == 640 and B == 64 and not f32:
+                tj = json.load(open(tfile))
+                if tj.get("conv_launches_per_step", n_fam) != n_fam:
+                    tnote = f"profiles/{name} was measured on a plan with {tj.get('conv_launches_per_step')} family launches per step, this one has {n_fam}: not reported"
+                    continue
+                traffic = round(tj["conv_mfma_hbm_bytes_per_launch_avg"])
                 tsrc = name
                 break
         fwd_ms = sum(t for (_, _, t) in prof)
         out = {
-            "metric": f"images/sec {NAMES[args.family]}{args.scale} {S}x{S} bs={B if args.scaling == 'weak' else global_batch} (forward + NMS)",
+            "metric": f"images/sec {NAMES[args.family]}{args.scale} {S}x{S} bs={B if args.scaling == 'weak' else global_batch} (forward + NMS)" + (", fp32 engine mode" if f32 else ""),
             "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{NAMES[args.family]}{args.scale} detect {S}x{S} fp16, "
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f16", "data": "synthetic",
+            "config": {"workload": f"{NAMES[args.family]}{args.scale} detect {S}x{S} {args.precision}, "
                                    + (f"batch {B} per GPU" if args.scaling == "weak" else f"global batch {global_batch} split over {world} GPU(s)")
                                    + ", seeded random weights, engine forward + HIP NMS (conf 0.25, iou 0.7, max_det 300)"
                                    + (" + RCCL all-gather of detections" if world > 1 else ""),
@@ -290,18 +302,20 @@ def main():
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 1),
                        "model_gflop_per_image": round(plan.flops / B / 1e9, 2),
                        "whole_path_tflops": round(plan.flops / B * global_batch / (ms_step * 1e-3) / 1e12, 1)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_MFMA_F16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tsrc})" if tsrc else None,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tsrc})" if tsrc else tnote,
                          "algorithmic_bytes_per_launch_avg": round(fam_bytes / n_fam),
-                         "kernel": "dense-conv family: every MFMA conv launch of one forward (conv_mfma_kernel, conv3x3_patch_kernel, "
-                                   "conv1x1_persist_kernel and the fused stem / Bottleneck / C3k2-tail / DWConv+1x1 kernels)",
+                         "kernel": ("dense-conv family of the fp32 mode: every conv launch of one forward (conv32_mfma_kernel, v_mfma_f32_32x32x2_f32; "
+                                    "peak = the fp32 matrix rate)") if f32 else
+                                   ("dense-conv family: every MFMA conv launch of one forward (conv_mfma_kernel, conv3x3_patch_kernel, "
+                                    "conv1x1_persist_kernel and the fused stem / Bottleneck / C3k2 / DWConv+1x1 kernels)"),
                          "launches_per_step": n_fam,
                          "flops_per_launch_avg": round(fam_flops / n_fam), "avg_launch_ms": round(fam_ms / n_fam, 5),
                          "family_ms_per_step": round(fam_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4),
                          "op_conv_only": {"launches_per_step": n_conv, "ms_per_step": round(conv_ms, 4),
                                           "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 1),
-                                          "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, 4),
+                                          "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4),
                                           "note": "the round-1 definition (plan ops of kind OP_CONV only), for continuity"}},
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only

@@ -38,6 +38,7 @@ SOURCES = {
     "val_ap.hip": ["-ffp-contract=off"],
     "sahi.hip": ["-ffp-contract=off"],
     "ref32.hip": ["-ffp-contract=off", "-fno-vectorize"],  # loop vectoriser: packed f32 math in attn32_kernel otherwise
+    "conv32_mfma.hip": ["-ffp-contract=off", "-fno-vectorize"],  # the same flags: its SiLU must be ref32.hip's bit for bit
     "engine.hip": [],
 }
 

@@ -191,7 +191,10 @@ struct Conv32Args {
     const float* res;
     int ldr, act, dst_scale, dst_dy, dst_dx;
 };
-int launch_conv32(const Conv32Args& a, hipStream_t s);
+int launch_conv32(const Conv32Args& a, hipStream_t s);          // routes to the MFMA kernel where it applies, else the scalar one
+int launch_conv32_scalar(const Conv32Args& a, hipStream_t s);   // ref32.hip: one thread per output, sequential fmaf chain
+bool conv32_mfma_supported(const Conv32Args& a);                // conv32_mfma.hip: v_mfma_f32_32x32x2_f32, the same chain bit for bit
+int launch_conv32_mfma(const Conv32Args& a, hipStream_t s);
 struct Dw32Args {
     const float* src;
     int lds, B, H, W, C, OH, OW, kh, kw, stride;
@@ -215,7 +218,8 @@ struct Mix32Args {
 };
 int launch_mix32(const Mix32Args& a, hipStream_t s);
 int launch_sppf32(float* buf, int ld, int B, int H, int W, int C, hipStream_t s);
-int launch_attn32(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s);
+int launch_attn32(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s,
+                  int impl = 0);  // impl 0: tiled kernel where it applies (key_dim 32, head_dim 64), 1: generic kernel, 2: tiled or error
 int launch_nhwc2nchw32(const float* src, int ld, int B, int C, int hw, void* out, int out_dtype, hipStream_t s);
 int launch_copy32(const float* src, int lds_, int up, int B, int H, int W, int C, float* dst, int ldd, hipStream_t s);
 int launch_gap32(const float* src, int lds_, int B, int H, int W, int C, float* out, int ldo, hipStream_t s);

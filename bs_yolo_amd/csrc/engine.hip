@@ -851,6 +851,46 @@ extern "C" int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, c
     return launch_conv(a, (hipStream_t)stream);
 }
 
+extern "C" int bsy_conv2d_f32(const float* x, int ldx, int B, int H, int W, int C1, const float* w, const float* b, float* y, int ldy,
+                              int C2, int ksize, int stride, int act, const float* res, int ldr, int impl, bsy_stream stream) {
+    if (!x || !w || !b || !y) BSY_FAIL(BSY_ERR_ARG, "conv2d_f32: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 <= 0 || ksize < 1 || !(ksize & 1) || (stride != 1 && stride != 2) || ldx < C1 || ldy < C2 ||
+        (res && ldr < C2) || impl < 0 || impl > 2)
+        BSY_FAIL(BSY_ERR_ARG, "conv2d_f32: bad shape");
+    Conv32Args a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = x; a.src_dtype = BSY_F32; a.ld0 = ldx; a.C0 = C1; a.B = B; a.H = H; a.W = W;
+    a.ks = ksize; a.stride = stride; a.pad = ksize / 2;  // autopad (nn/modules/conv.py:29-35)
+    a.OH = (H + 2 * a.pad - ksize) / stride + 1; a.OW = (W + 2 * a.pad - ksize) / stride + 1;
+    a.w = w; a.bias = b; a.dst = y; a.ldd = ldy; a.Cout = C2; a.res = res; a.ldr = ldr; a.act = act; a.dst_scale = 1;
+    if (impl == 1) return launch_conv32_scalar(a, (hipStream_t)stream);
+    if (impl == 2) return launch_conv32_mfma(a, (hipStream_t)stream);
+    return launch_conv32(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_conv_first_f32(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b, float* y, int ldy,
+                                 int C2, int ksize, int stride, int act, int impl, bsy_stream stream) {
+    if (!img || !w || !b || !y) BSY_FAIL(BSY_ERR_ARG, "conv_first_f32: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C2 <= 0 || ksize < 1 || !(ksize & 1) || (stride != 1 && stride != 2) || ldy < C2 || impl < 0 || impl > 2 ||
+        (img_dtype != BSY_F16 && img_dtype != BSY_F32))
+        BSY_FAIL(BSY_ERR_ARG, "conv_first_f32: bad shape");
+    Conv32Args a;
+    memset(&a, 0, sizeof(a));
+    a.first = 1; a.src0 = img; a.src_dtype = img_dtype; a.C0 = 3; a.B = B; a.H = H; a.W = W;
+    a.ks = ksize; a.stride = stride; a.pad = ksize / 2;
+    a.OH = (H + 2 * a.pad - ksize) / stride + 1; a.OW = (W + 2 * a.pad - ksize) / stride + 1;
+    a.w = w; a.bias = b; a.dst = y; a.ldd = ldy; a.Cout = C2; a.act = act; a.dst_scale = 1;
+    if (impl == 1) return launch_conv32_scalar(a, (hipStream_t)stream);
+    if (impl == 2) return launch_conv32_mfma(a, (hipStream_t)stream);
+    return launch_conv32(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_attention_f32(const float* qkv, int ld, int B, int N, int heads, int key_dim, int head_dim, float scale, float* out,
+                                 int ldo, int impl, bsy_stream stream) {
+    if (!qkv || !out || B <= 0 || N <= 0 || impl < 0 || impl > 2) BSY_FAIL(BSY_ERR_ARG, "attention_f32: bad argument");
+    return launch_attn32(qkv, ld, B, N, heads, key_dim, head_dim, scale, out, ldo, (hipStream_t)stream, impl);
+}
+
 extern "C" int bsy_conv_first(const void* img, int img_dtype, int B, int H, int W, const void* w, const float* b,
                               void* y, int ldy, int C2, int ksize, int stride, int act, bsy_stream stream) {
     if (!img || !w || !b || !y) BSY_FAIL(BSY_ERR_ARG, "conv_first: null pointer");

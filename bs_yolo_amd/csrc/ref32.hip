@@ -6,6 +6,8 @@
 // design (a few TFLOP/s); never on the benchmarked path.  Layout: NHWC f32, views (pointer incl. channel offset, ld).
 // Each kernel restates the reference arithmetic it replaces: Conv.forward_fuse conv.py:149-151, DWConv :224-229,
 // SPPF block.py:3145-3149, Attention :4279-4286, MSCAAttention nn/Addmodules/MSCA.py:53-88, ELA ELA.py:77-101.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -157,6 +159,63 @@ __global__ __launch_bounds__(64) void attn32_kernel(const float* qkv, int ld, in
     for (int d = 0; d < hd; ++d) o[d] = acc[d] / den;
 }
 
+// The same arithmetic -- one thread per query, keys visited in order, online softmax, every sum a sequential chain -- with the
+// head dimensions as compile-time constants (q and the output accumulator live in registers: attn32_kernel's runtime-indexed
+// acc[] sits in scratch memory) and the keys / values staged through LDS 64 rows at a time (all lanes read the same row:
+// broadcast reads).  YOLO11's C2PSA always has key_dim 32, head_dim 64 (block.py:4256-4262: head_dim = dim / num_heads with
+// num_heads = dim / 64, attn_ratio 0.5).  Same operations in the same order as attn32_kernel: the same bits.
+template <int KD, int HD>
+__global__ __launch_bounds__(256) void attn32_tiled_kernel(const float* qkv, int ld, int N, int heads, float scale, float* out, int ldo) {
+    constexpr int TK = 64;
+    __shared__ __attribute__((aligned(16))) float sK[TK][KD];
+    __shared__ __attribute__((aligned(16))) float sV[TK][HD];
+    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid, head = blockIdx.y, b = blockIdx.z;
+    const float* base = qkv + (size_t)b * N * ld;
+    const int koff = heads * KD + head * KD, voff = 2 * heads * KD + head * HD;
+    const bool live = i < N;
+    float q[KD], acc[HD];
+    {
+        const float* qp = base + (size_t)(live ? i : 0) * ld + head * KD;
+#pragma unroll
+        for (int c = 0; c < KD; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qp + c);
+            q[c] = v[0]; q[c + 1] = v[1]; q[c + 2] = v[2]; q[c + 3] = v[3];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    for (int j0 = 0; j0 < N; j0 += TK) {
+        const int nj = N - j0 < TK ? N - j0 : TK;
+        __syncthreads();  // the previous tile has been consumed
+        for (int id = tid; id < TK * (KD + HD) / 4; id += 256) {
+            const int r = id / ((KD + HD) / 4), c4 = (id % ((KD + HD) / 4)) * 4;
+            if (r < nj) {
+                const float* rowp = base + (size_t)(j0 + r) * ld;
+                if (c4 < KD) *reinterpret_cast<f32x4*>(&sK[r][c4]) = *reinterpret_cast<const f32x4*>(rowp + koff + c4);
+                else *reinterpret_cast<f32x4*>(&sV[r][c4 - KD]) = *reinterpret_cast<const f32x4*>(rowp + voff + c4 - KD);
+            }
+        }
+        __syncthreads();
+        for (int jj = 0; jj < nj; ++jj) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < KD; ++c) s = fmaf(q[c], sK[jj][c], s);
+            s *= scale;
+            const float nm = fmaxf(mx, s);
+            const float corr = expf(mx - nm), pj = expf(s - nm);
+            den = den * corr + pj;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * corr + pj * sV[jj][d];
+            mx = nm;
+        }
+    }
+    if (!live) return;
+    float* o = out + ((size_t)b * N + i) * ldo + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) *reinterpret_cast<f32x4*>(o + d) = f32x4{acc[d] / den, acc[d + 1] / den, acc[d + 2] / den, acc[d + 3] / den};
+}
+
 __global__ __launch_bounds__(256) void nhwc2nchw32_kernel(const float* src, int ld, int B, int C, int HW, void* out, int out_dtype) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)B * C * HW) return;
@@ -256,6 +315,13 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 int launch_conv32(const Conv32Args& a, hipStream_t s) {
+    // BSY_CONV32_SCALAR=1 (test / A-B aid): every conv on the scalar kernel
+    static const bool scalar_only = [] { const char* e = getenv("BSY_CONV32_SCALAR"); return e && atoi(e) != 0; }();
+    if (!scalar_only && conv32_mfma_supported(a)) return launch_conv32_mfma(a, s);
+    return launch_conv32_scalar(a, s);
+}
+
+int launch_conv32_scalar(const Conv32Args& a, hipStream_t s) {
     if (!a.src0 || !a.w || !a.bias || !a.dst || a.Cout <= 0 || a.B <= 0) BSY_FAIL(BSY_ERR_ARG, "conv32: bad argument");
     if (a.C1 && !a.src1) BSY_FAIL(BSY_ERR_ARG, "conv32: src1 missing");
     const long long M = (long long)a.B * a.OH * a.OW;
@@ -281,9 +347,15 @@ int launch_sppf32(float* buf, int ld, int B, int H, int W, int C, hipStream_t s)
     return BSY_OK;
 }
 
-int launch_attn32(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s) {
+int launch_attn32(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s, int impl) {
     if (!qkv || !out || hd > ATT32_MAXD || kd < 1 || hd < 1 || heads < 1) BSY_FAIL(BSY_ERR_ARG, "attn32: bad argument (head_dim <= %d)", ATT32_MAXD);
-    hipLaunchKernelGGL(attn32_kernel, dim3((N + 63) / 64, heads, B), dim3(64), 0, s, qkv, ld, B, N, heads, kd, hd, scale, out, ldo);
+    static const bool generic_only = [] { const char* e = getenv("BSY_ATTN32_GENERIC"); return e && atoi(e) != 0; }();  // test / A-B aid
+    if (impl == 2 && !(kd == 32 && hd == 64 && !(ld & 3) && !(ldo & 3) && !(((uintptr_t)qkv | (uintptr_t)out) & 15)))
+        BSY_FAIL(BSY_ERR_ARG, "attn32: the tiled kernel takes key_dim 32, head_dim 64, 16-byte aligned views");
+    if (impl != 1 && kd == 32 && hd == 64 && !generic_only && !(ld & 3) && !(ldo & 3) && !(((uintptr_t)qkv | (uintptr_t)out) & 15))
+        hipLaunchKernelGGL((attn32_tiled_kernel<32, 64>), dim3((N + 255) / 256, heads, B), dim3(256), 0, s, qkv, ld, N, heads, scale, out, ldo);
+    else
+        hipLaunchKernelGGL(attn32_kernel, dim3((N + 63) / 64, heads, B), dim3(64), 0, s, qkv, ld, B, N, heads, kd, hd, scale, out, ldo);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }

@@ -56,6 +56,26 @@ def conv2d_nhwc(x: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, cout: int, 
     return out
 
 
+def conv2d_nhwc_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int, s: int = 1, act: bool = True,
+                    res: Optional[torch.Tensor] = None, cin: Optional[int] = None, impl: int = 0) -> torch.Tensor:
+    """fp32 engine mode's conv: x (B,H,W,ld) f32 (first `cin` channels), w (Cout,Cin,k,k) f32, b (Cout) -> (B,OH,OW,Cout) f32.
+    impl 0 = the engine's routing, 1 = scalar kernel, 2 = fp32 MFMA kernel (bsy_conv2d_f32)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, H, W, ld = x.shape
+    cin = ld if cin is None else cin
+    cout = w.shape[0]
+    assert tuple(w.shape) == (cout, cin, k, k)
+    wk = w.detach().float().permute(2, 3, 1, 0).reshape(k * k * cin, cout).contiguous().to(x.device)
+    bk = b.detach().float().contiguous().to(x.device)
+    p = k // 2
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ldy = (cout + 3) // 4 * 4
+    out = torch.zeros((B, OH, OW, ldy), dtype=torch.float32, device=x.device)
+    L.check(L.lib.bsy_conv2d_f32(_p(x), ld, B, H, W, cin, _p(wk), _p(bk), _p(out), ldy, cout, k, s, int(act), _p(res),
+                                 res.shape[-1] if res is not None else 0, impl, _stream(x)))
+    return out
+
+
 def conv_first(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int = 3, s: int = 2, act: bool = True):
     """img BCHW fp16/fp32; w (Cout,3,3,3) fp32; -> NHWC fp16."""
     assert img.is_contiguous() and img.shape[1] == 3

@@ -58,11 +58,14 @@ def cfg_of(model) -> dict:
 
 def _weights_version(model) -> tuple:
     """Cheap fingerprint of the parameters and buffers: in-place updates (optimizer steps, EMA, load_state_dict's copy_)
-    bump ``Tensor._version``; ``.half()`` / ``.to()`` / ``fuse()`` replace the storages (data_ptr)."""
+    bump ``Tensor._version``; ``.half()`` / ``.to()`` / ``fuse()`` replace the storages (data_ptr).  Inference tensors
+    -- what ``fuse()`` creates under the predictor's / validator's ``smart_inference_mode`` (engine/predictor.py:219,
+    engine/validator.py:105) -- carry no version counter (reading it raises) and cannot be updated in place outside
+    inference mode, so their storage pointer is the whole fingerprint."""
     n, ver, ptr = 0, 0, 0
     for t in list(model.parameters()) + list(model.buffers()):
         n += 1
-        ver += t._version
+        ver += 0 if t.is_inference() else t._version
         ptr ^= t.data_ptr() + 0x9E3779B1 * n
     return (n, ver, ptr)
 

@@ -187,6 +187,23 @@ int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream
  * b: f32 [CoutPad]; y: (B,OH,OW,ldy); res same geometry as y or NULL. */
 int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, const void* w, const float* b, void* y, int ldy,
                int C2, int ksize, int stride, int act, const void* res, int ldr, int y_f32, bsy_stream stream);
+/* The same module in fp32 (the engine's fp32 mode: callers of predict() with the reference's default half=False,
+ * cfg/default.yaml:54, engine/predictor.py:131): NHWC f32 in/out, w f32 [k*k*C1][C2] with K order (kh, kw, cin), b f32 [C2].
+ * impl 0: the engine's routing (fp32 MFMA kernel, v_mfma_f32_32x32x2_f32, where C1 % 8 == 0, C2 % 4 == 0, strides % 4 == 0 and
+ * 16-byte aligned views; else the scalar kernel); 1: scalar kernel (one thread per output, sequential fmaf chain); 2: MFMA kernel
+ * (BSY_ERR_ARG where it does not apply).  Both kernels evaluate the same k-ordered fmaf chain: bit-identical results. */
+int bsy_conv2d_f32(const float* x, int ldx, int B, int H, int W, int C1, const float* w, const float* b, float* y, int ldy,
+                   int C2, int ksize, int stride, int act, const float* res, int ldr, int impl, bsy_stream stream);
+/* The image conv of the fp32 mode: img BCHW (f16 / f32) -> NHWC f32; w f32 [k*k*3][C2], K order (kh, kw, c).  impl as above (the
+ * MFMA kernel widens every tap to 8 k values, 5 of them zeros: the same chain, the same bits). */
+int bsy_conv_first_f32(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b, float* y, int ldy,
+                       int C2, int ksize, int stride, int act, int impl, bsy_stream stream);
+/* Attention (block.py:4279-4286) of the fp32 mode: qkv (B, N, ld) f32 rows [q (heads x key_dim) | k | v (heads x head_dim)] ->
+ * out (B, N, ldo) f32, one thread per query, keys in order, online softmax.  impl 0: the LDS-tiled kernel for key_dim 32 /
+ * head_dim 64 (every YOLO11 C2PSA), the generic one otherwise; 1: generic; 2: tiled (BSY_ERR_ARG where it does not apply).
+ * Same operations in the same order: bit-identical. */
+int bsy_attention_f32(const float* qkv, int ld, int B, int N, int heads, int key_dim, int head_dim, float scale, float* out,
+                      int ldo, int impl, bsy_stream stream);
 /* Packed sizes for a (C2, C1, k, k) conv: rows padded to 128 output channels, K = k*k*C1 padded to 32.
  * C1 == 3 (the image conv) packs a zero 4th input channel: K = k*k*4. */
 int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, int* k_pad);

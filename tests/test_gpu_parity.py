@@ -87,6 +87,110 @@ def test_conv_matches_oracle(case):
     np.testing.assert_allclose(got.numpy(), y.numpy(), **tol)
 
 
+CONV32_CASES = [
+    # B, H, W, cin, cout, k, s, act, res, ld extra
+    (2, 12, 10, 16, 32, 1, 1, True, False, 0),
+    (2, 12, 10, 16, 24, 3, 1, True, False, 8),       # view of a wider buffer
+    (1, 13, 11, 8, 16, 3, 2, True, False, 0),        # odd extents, K = 72 (K tail inside a 32-wide step)
+    (2, 20, 20, 64, 64, 3, 1, True, True, 0),        # Bottleneck.cv2 with shortcut
+    (2, 16, 16, 96, 128, 1, 1, True, False, 0),
+    (1, 40, 40, 128, 256, 3, 2, True, False, 0),     # two 128-cout tiles
+    (3, 9, 7, 32, 80, 1, 1, False, False, 0),        # Detect cls conv: ragged cout inside a 128-wide tile
+    (1, 7, 5, 256, 512, 1, 1, True, False, 0),       # M = 35: one partial pixel tile
+    (2, 33, 31, 40, 68, 3, 1, True, True, 0),        # Cin = 40 (a K-step straddles taps), cout 68
+    (1, 20, 20, 512, 256, 3, 1, True, True, 0),      # K = 4608
+]
+
+
+@pytest.mark.parametrize("case", CONV32_CASES)
+def test_conv32_mfma_equals_scalar(case):
+    """fp32 engine mode: the fp32-MFMA conv (conv32_mfma.hip, v_mfma_f32_32x32x2_f32) against the scalar kernel it replaces
+    (ref32.hip, one sequential fmaf chain per output) -- the SAME chain, so bit for bit -- and against torch's fp32 conv to
+    summation-order tolerance (1e-4 of the output range, the fp32 mode's per-layer bound)."""
+    B, H, W, cin, cout, k, s, act, use_res, ldx = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.5
+    y = F.conv2d(x, w, b, s, k // 2)
+    if act:
+        y = F.silu(y)
+    res = torch.randn(y.shape, generator=g) if use_res else None
+    if use_res:
+        y = y + res
+    xd = torch.zeros(B, H, W, cin + ldx)
+    xd[..., :cin] = nhwc(x)
+    xd[..., cin:] = float("nan")  # channels outside the view must never be read into a result
+    xd = xd.to(DEV)
+    rd = nhwc(res).to(DEV) if use_res else None
+    got = {impl: O.conv2d_nhwc_f32(xd, w, b, k, s, act, res=rd, cin=cin, impl=impl)[..., :cout].cpu() for impl in (1, 2, 0)}
+    torch.cuda.synchronize()
+    assert torch.equal(got[2], got[1]), (got[2] - got[1]).abs().max()
+    assert torch.equal(got[0], got[2])  # the routing picks the MFMA kernel for these shapes
+    rng = float(y.abs().max())
+    assert float((nchw(got[2]) - y).abs().max()) <= 1e-4 * max(rng, 1.0)
+
+
+def test_conv32_routing_falls_back_to_scalar():
+    """Shapes the MFMA kernel does not take (Cout % 4 != 0, Cin % 8 != 0) run on the scalar kernel through the same entry point."""
+    g = torch.Generator().manual_seed(5)
+    for cin, cout in ((16, 5), (12, 16)):
+        x = torch.randn(2, cin, 9, 9, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        y = F.silu(F.conv2d(x, w, b, 1, 1))
+        got = O.conv2d_nhwc_f32(nhwc(x).to(DEV), w, b, 3, 1, True)[..., :cout].cpu()
+        assert float((nchw(got) - y).abs().max()) <= 1e-4 * max(float(y.abs().max()), 1.0)
+        with pytest.raises(L.BsyError):
+            O.conv2d_nhwc_f32(nhwc(x).to(DEV), w, b, 3, 1, True, impl=2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_conv32_first_mfma_equals_scalar(dt):
+    """fp32 mode's image conv on the fp32 MFMA kernel (taps widened to 8 k values, 5 of them zero) = the scalar kernel, bit for bit."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(3)
+    B, H, W, cout = 3, 46, 38, 16
+    x = torch.rand(B, 3, H, W, generator=g).to(dt)
+    w = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(cout, generator=g) * 0.5
+    y = F.silu(F.conv2d(x.float(), w, b, 2, 1))
+    xd = x.to(DEV).contiguous()
+    wk = w.permute(2, 3, 1, 0).reshape(27, cout).contiguous().to(DEV)
+    bk = b.to(DEV)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    got = {}
+    for impl in (1, 2, 0):
+        out = torch.zeros(B, OH, OW, cout, device=DEV)
+        L.check(L.lib.bsy_conv_first_f32(O._p(xd), L.dtype_code(dt), B, H, W, O._p(wk), O._p(bk), O._p(out), cout, cout, 3, 2, 1, impl,
+                                         O._stream(xd)))
+        got[impl] = out.cpu()
+    assert torch.equal(got[2], got[1]) and torch.equal(got[0], got[2])
+    assert float((nchw(got[2]) - y).abs().max()) <= 1e-4 * max(float(y.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("N", [100, 400, 1600])
+def test_attention32_tiled_equals_generic(N):
+    """fp32 mode's attention: the LDS-tiled kernel (key_dim 32, head_dim 64) = the generic one bit for bit, and both = softmax
+    attention in torch fp32 to 1e-5."""
+    g = torch.Generator().manual_seed(N)
+    B, heads, kd, hd = 2, 2, 32, 64
+    ld = heads * (2 * kd + hd)
+    qkv = torch.randn(B, N, ld, generator=g)
+    q = qkv[..., :heads * kd].view(B, N, heads, kd).permute(0, 2, 1, 3)
+    k = qkv[..., heads * kd:2 * heads * kd].view(B, N, heads, kd).permute(0, 2, 1, 3)
+    v = qkv[..., 2 * heads * kd:].view(B, N, heads, hd).permute(0, 2, 1, 3)
+    ref = (torch.softmax((q @ k.transpose(-1, -2)) * kd ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, heads * hd)
+    qd = qkv.to(DEV)
+    got = {}
+    for impl in (1, 2, 0):
+        out = torch.zeros(B, N, heads * hd, device=DEV)
+        L.check(L.lib.bsy_attention_f32(O._p(qd), ld, B, N, heads, kd, hd, kd ** -0.5, O._p(out), heads * hd, impl, O._stream(qd)))
+        got[impl] = out.cpu()
+    assert torch.equal(got[2], got[1]) and torch.equal(got[0], got[2])
+    assert float((got[2] - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+
+
 PATCH_CASES = [
     # B, H, W, cin, cout, cfg, res      cfg = tile << 4 | variant: 161 = patch kernel TN 128, 177 = TN 64
     (2, 24, 40, 64, 64, 177, False),      # 40-wide map: 2.5 tiles per row

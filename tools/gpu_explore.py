@@ -71,12 +71,14 @@ def per_layer(tag="yolo11n_detect"):
     eng.close()
 
 
-def timing(scale="s", B=64, S=640, dt=torch.float16, family="yolo11"):
+def timing(scale="s", B=64, S=640, dt=torch.float16, family="yolo11", precision="fp16"):
     from bs_yolo_amd.plan import Plan
     from bs_yolo_amd.weights import synth_state_dict
     cfg = stock_cfg(family, scale, 12 if family == "bsyolo11" else 80)
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), 0)
-    eng = YoloEngine(cfg, sd)
+    eng = YoloEngine(cfg, sd, precision=precision)
+    if precision == "fp32":
+        dt = torch.float32
     x = torch.rand(B, 3, S, S, device=DEV).to(dt)
     for _ in range(3):
         y, _ = eng(x, want_raw=False)
@@ -129,4 +131,5 @@ if __name__ == "__main__":
         for tag in (sys.argv[2:] or ["yolo11n_detect", "yolo11s_detect"]):
             per_layer(tag)
     if what in ("time", "all"):
-        timing("s", int(sys.argv[2]) if len(sys.argv) > 2 else 64, 640, family=sys.argv[3] if len(sys.argv) > 3 else "yolo11")
+        timing("s", int(sys.argv[2]) if len(sys.argv) > 2 else 64, 640, family=sys.argv[3] if len(sys.argv) > 3 else "yolo11",
+               precision=sys.argv[4] if len(sys.argv) > 4 else "fp16")
