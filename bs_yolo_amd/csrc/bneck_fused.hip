@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
 // fragments no longer fit registers: 36 K-steps), 8 waves, one workgroup per CU (143 KiB of LDS):
 //   conv 1: 6 MFMA pixel tiles of the hidden patch on waves 0-5, 36 K-steps each;
 //   conv 2: 4 pixel tiles x 2 cout tiles on the 8 waves, 18 K-steps each, + shortcut from the input patch.
-// Lane-constant address arithmetic is hoisted out of the tile loop (c3k2_fused.hip).  K orders and epilogue arithmetic equal
-// conv_mfma.hip's tap-major implicit GEMM: bit-identical to the two-launch path through that kernel.
+// Lane-constant address arithmetic is hoisted out of the tile loop (c3k2_fused.hip).  K walks (conv_mfma.hip conv_korder: conv 1 with its
+// 64 input channels chunk-major over two 32-channel chunks, conv 2 one chunk) and epilogue arithmetic equal the conv kernels': bit-identical
+// to the two-launch path through any of their configurations.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int C, int CH>
 __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
@@ -310,9 +311,10 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KSA; ++ks) {
-                const int k0 = 16 * ks, tap = k0 / C, ch0 = (k0 % C) / 8;  // compile-time; lane half 1 = next chunk
+                // the layer's K walk (conv_mfma.hip conv_korder: 3x3, Cin % 32 == 0 -> chunk-major, 32-channel chunks): chunk, tap, 16-wide half
+                const int chunk = ks / 18, tap = (ks % 18) >> 1, k0 = tap * C + 32 * chunk + 16 * (ks & 1), ch0 = (k0 % C) / 8;  // compile-time
                 const half8 bf = *reinterpret_cast<const half8*>(xb + ((tap / 3) * BN_XC + tap % 3) * XS + ch0 * 8);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(a1base + 16 * ks), bf, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(a1base + k0), bf, acc, 0, 0, 0);
             }
             const unsigned keep = ((unsigned)(oy0 - 1 + r1) < (unsigned)p.H && (unsigned)(ox0 - 1 + c1) < (unsigned)p.W) ? 0xffffffffu : 0u;
             if (mm1 < BN_NM) {

@@ -71,6 +71,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 #define BSY_CONV_MAX_CFG 64
 int conv_candidates(const ConvArgs& a, int* out, int max_out);  // valid configuration ids, heuristic best first
 bool conv_cfg_valid(const ConvArgs& a, int cfg);
+int conv_korder(const ConvArgs& a);  // the layer's K walk (0 packed order, 1 / 2 chunk-major with 32- / 64-channel chunks): a function of its shape
 
 struct ConvFirstArgs {
     const void* img;

@@ -56,9 +56,11 @@ struct ConvK {
     const float* tail_bias;
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
     int dbg;  // ablation switches for profiling (BSY_CONV_DBG; results are WRONG under them): 1 = no DMA, 4 = no epilogue
-    int korder;  // 0 = tap-major K walk (taps outer, channels inner: the packed order), 1 = chunk-major (BK channels of all
-                 // ntaps taps, then the next BK channels): a stride-2 3x3 tile then re-reads its input lines within
-                 // ntaps K-steps -- from the XCD's L2 -- instead of once per tap, Cin / BK K-steps apart (variant bit 4)
+    int korder;  // the layer's K walk (conv_korder below: a function of the layer's SHAPE, never of the configuration): 0 = the packed
+                 // order (taps outer, channels inner), 1 = chunk-major with 32-channel chunks (32 channels of all ntaps taps, then
+                 // the next 32), 2 = chunk-major with 64-channel chunks (a BK-32 kernel visits the two halves of a chunk tap by tap).
+                 // Chunk-major: a stride-2 3x3 tile re-reads its input lines within ntaps K-steps -- from the XCD's L2 -- instead
+                 // of once per tap, Cin / BK K-steps apart; and it is the order the patch kernel sums in.
 };
 
 __device__ __attribute__((aligned(16))) unsigned int bsy_zero_page[16];  // zero-initialised; source of padded taps
@@ -571,19 +573,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
                 dma16(p.wgt + (size_t)(woff[j] + (unsigned)kt * 32u), sW + (wave * WIW + j) * RPI * BK);
         }
     };
-#define BSY_ADVANCE_K()                                                                          \
-    do {                                                                                         \
-        if (ALIGNED) {                                                                           \
-            if (p.korder) { /* chunk-major: all taps of BK channels, then the next BK channels */ \
-                if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += BK; }                               \
-            } else {                                                                             \
-                s_cb += BK;                                                                      \
-                if (s_cb >= Cin) { s_cb = 0; ++s_tap; }                                          \
-            }                                                                                    \
-        } else {                                                                                 \
-            c8 += 4;                                                                             \
-            while (c8 >= p.Cin8) { c8 -= p.Cin8; ++tap; }                                        \
-        }                                                                                        \
+#define BSY_ADVANCE_K()                                                                                  \
+    do {                                                                                                 \
+        if (ALIGNED) {                                                                                   \
+            if (p.korder == 1 || (p.korder == 2 && BK == 64)) { /* chunk-major, chunk = this kernel's BK */ \
+                if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += BK; }                                       \
+            } else if (p.korder == 2) { /* 64-channel chunks walked by a BK-32 kernel: (tap, half) */       \
+                if (s_cb & 32) { s_cb -= 32; if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += 64; } }        \
+                else s_cb += 32;                                                                         \
+            } else {                                                                                     \
+                s_cb += BK;                                                                              \
+                if (s_cb >= Cin) { s_cb = 0; ++s_tap; }                                                  \
+            }                                                                                            \
+        } else {                                                                                         \
+            c8 += 4;                                                                                     \
+            while (c8 >= p.Cin8) { c8 -= p.Cin8; ++tap; }                                                \
+        }                                                                                                \
     } while (0)
 
     f32x16 acc[NT][MT];
@@ -1420,6 +1425,19 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
     return BSY_OK;
 }
 
+// The K walk of a layer -- the order in which its products enter the fp32 accumulators, hence its result's bits -- is a function of
+// the layer's SHAPE alone; every kernel configuration that is valid for the layer sums in that order (round 3: a tuned plan
+// returns bit for bit what the heuristic plan returns, on any box).
+//   0: the packed order (taps outer, channels inner): 1x1 convs (one tap) and unaligned channel counts (generic variant only);
+//   1: chunk-major, 32-channel chunks: aligned 3x3 layers -- the patch kernel's order; implicit-GEMM tiles walk it with BK 32;
+//   2: chunk-major, 64-channel chunks: aligned 3x3 STRIDE-2 layers with Cin % 64 == 0 (no patch kernel there; the BK-64 tiles
+//      these layers run fastest on sum in this order, BK-32 tiles visit the two halves of a chunk tap by tap).
+int conv_korder(const ConvArgs& a) {
+    const int Cin = a.C0 + a.C1;
+    if (a.ksize != 3 || (Cin & 31) || (a.C0 & 31)) return 0;
+    return (a.stride == 2 && !(Cin & 63) && !(a.C0 & 63)) ? 2 : 1;
+}
+
 // Configuration ids: tile << 4 | variant.
 //   tile   : 0 = 256 px x 32 couts, 1 = 256 x 64, 2 = 128 x 128, 3 = 128 x 64 (4 waves); 4 = 256 x 128 (8 waves);
 //            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers);
@@ -1428,15 +1446,20 @@ extern "C" int bsy_conv_packed_dims(int C2, int C1, int ksize, int* cout_pad, in
 //            10 = 8x16 px x 128 couts (2-stage weight ring), 11 = 8x16 px x 64 couts (variant 1: 3 stages, 2: 2 stages):
 //            patch-based 3x3 stride-1 kernel; 12 / 13 = the same with 6x20-pixel tiles (maps whose width is a multiple of 20)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
-//            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages; + 4 = the same with the chunk-major K walk
-//            (ConvK::korder; 3x3 layers, implicit-GEMM tiles: sums in another order -> equal to fp32 rounding, not bit for bit)
+//            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages; + 4 on the implicit-GEMM tiles of a layer whose K walk is
+//            chunk-major (conv_korder != 0): part of the id so that ids recorded before round 3 for the packed order on such a
+//            layer are recognised as stale (invalid -> heuristic)
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
-    const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 3, korder = (cfg >> 2) & 3;
-    if (cfg < 0 || tile > 13 || korder > 1) return false;
-    // variant bit 4: chunk-major K walk -- implicit-GEMM tiles of aligned 3x3 layers only (a 1x1 layer has one tap)
-    if (korder && (tile >= 8 || var < 1 || a.ksize != 3)) return false;
+    const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 3, kbit = (cfg >> 2) & 3;
+    const int ko = conv_korder(a);
+    if (cfg < 0 || tile > 13 || kbit > 1) return false;
+    // the id's chunk-major bit must say what the layer's shape says (implicit-GEMM tiles; the other kernels have one order each)
+    if (tile < 8 && kbit != (ko ? 1 : 0)) return false;
+    if (tile >= 8 && kbit) return false;
+    if (ko && tile < 8 && var < 1) return false;
+    if (ko == 1 && tile < 8 && var == 3) return false;  // 32-channel chunks: a 64-deep K-step would pair the halves of two chunks
     if (a.tail_wgt) {  // box-branch tail: the 64-cout patch tiles only (validity of the 3x3 conv itself: the same op without tail / decoder)
-        if ((tile != 11 && tile != 13) || korder) return false;
+        if (tile != 11 && tile != 13) return false;
         ConvArgs b = a;
         b.tail_wgt = nullptr; b.tail_bias = nullptr; b.epi = 0;
         return a.epi == 3 && a.Cout == 64 && !a.res && conv_cfg_valid(b, cfg);
@@ -1447,8 +1470,8 @@ bool conv_cfg_valid(const ConvArgs& a, int cfg) {
         ConvArgs b = a;
         return conv_cfg_valid(b, ((tile - 2) << 4) | var);
     }
-    if (tile >= 10) {  // patch-based 3x3 stride-1 kernel (TN 128 / 64)
-        return (var == 1 || (var == 2 && tile == 11)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
+    if (tile >= 10) {  // patch-based 3x3 stride-1 kernel (TN 128 / 64): sums chunk-major over 32-channel chunks = K walk 1
+        return ko == 1 && (var == 1 || (var == 2 && tile == 11)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
                !(a.Cout & 7) && !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 &&
                (!a.res || (!(a.ldr & 7) && !((uintptr_t)a.res & 15))) && (tile == 10 ? a.Cout > 64 : true);
     }
@@ -1470,6 +1493,7 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
     const bool aligned = !(Cin & 31) && !(a.C0 & 31), aligned64 = !(Cin & 63) && !(a.C0 & 63);
     const long long M = (long long)a.B * a.OH * a.OW;
     const int tile = a.epi == 3 ? 1 : (a.Cout > 64 ? 2 : (a.Cout > 32 ? 1 : 0));  // heuristic default: widest cout tile that is not wasted
+    const int ko = conv_korder(a), km = ko ? 4 : 0;
     int n = 0;
     auto add = [&](int t, int v) {
         const int c = (t << 4) | v;
@@ -1488,13 +1512,14 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         return n;
     }
     // heuristic first (what an un-tuned plan runs: the r01 measurements' usual winners), then the exhaustive
-    // (tile x variant) sweep the autotuner times
+    // (tile x variant) sweep the autotuner times.  Every candidate of a layer sums in the layer's K walk (conv_cfg_valid).
     // 6x20 tiles where they need fewer tiles than 8x16 ones (20 x 20 maps: 4 instead of 6 per image)
     const bool t20 = ceil_div(a.W, 20) * ceil_div(a.H, 6) < ceil_div(a.W, 16) * ceil_div(a.H, 8);
-    if (!a.epi && a.ksize == 3 && a.stride == 1 && a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) add(t20 ? 13 : 11, 2);  // patch kernel
-    const int km = (a.ksize == 3 && a.stride == 2 && !getenv("BSY_NO_KORDER")) ? 4 : 0;  // stride-2 3x3 layers walk K chunk-major (see ConvK::korder)
-    if (!a.epi && !(a.Cout & 255) && aligned64 && M >= 16384) add(7, 3 | km);  // 256 x 256, 64-deep K-steps
-    add(tile, (aligned64 ? 3 : 1) | km);
+    const bool patch_ok = !getenv("BSY_NO_PATCH");
+    if (!a.epi && a.ksize == 3 && a.stride == 1 && a.H >= 16 && a.W >= 16 && patch_ok) add(t20 ? 13 : 11, 2);  // patch kernel
+    const int vbest = (aligned64 && ko != 1) ? 3 : 1;  // 64-deep K-steps where the K walk allows them
+    if (!a.epi && !(a.Cout & 255) && aligned64 && ko != 1 && M >= 16384) add(7, 3 | km);  // 256 x 256, 64-deep K-steps
+    add(tile, vbest | km);
     static const int tn[10] = {32, 64, 128, 64, 128, 128, 64, 256, 128, 64};
     for (int t = 0; t < 10; ++t) {
         if (tn[t] >= 2 * round_up(a.Cout, 32)) continue;      // more than half of the cout tile would be padding
@@ -1502,11 +1527,9 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (t == 4 && (a.Cout < 128 || M < 32768)) continue;    // 8-wave 256x128 only for wide, large layers
         if (t == 7 && M < 16384) continue;
         if (t >= 8 && (M < 65536 || getenv("BSY_NO_PERSIST"))) continue;                      // persistent tiles need several tiles per workgroup
-        for (int v = 1; v <= 3; ++v) add(t, v);
-        if (km && t < 8)  // chunk-major K walk: the taps' re-reads of a stride-2 layer stay in L2
-            for (int v = 1; v <= 3; ++v) add(t, v | 4);
+        for (int v = 1; v <= 3; ++v) add(t, v | (t < 8 ? km : 0));
     }
-    if (a.H >= 16 && a.W >= 16 && !getenv("BSY_NO_PATCH")) {  // 3x3 s1 patch kernel
+    if (a.H >= 16 && a.W >= 16 && patch_ok) {  // 3x3 s1 patch kernel
         add(10, 1); add(11, 1); add(11, 2);
         if (t20) { add(12, 1); add(13, 1); add(13, 2); }
     }
@@ -1571,7 +1594,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         cfg = list[0];
     }
     const int tile = cfg >> 4, var = cfg & 3;
-    k.korder = (cfg >> 2) & 1;
+    k.korder = conv_korder(a);
     // tile: 0 = 256x32, 1 = 256x64, 2 = 128x128, 3 = 128x64, 4 = 256x128 (8 waves), 5 = 64x128, 6 = 64x64
     // var : 0 = generic BK32 S3, 1 = aligned BK32 S3, 2 = aligned BK32 S2, 3 = aligned BK64 S2
 #define BSY_VAR(KS_, WM_, WN_, MT_, NT_)                                                  \

@@ -633,7 +633,8 @@ extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream
 
 // Per-op autotuning of the conv kernel configuration (tile shape / K-step / ring depth): runs the plan once, timing
 // every valid configuration of every conv op with HIP events on `stream` (1 warm-up + 3 timed launches each) and
-// records the fastest in the plan.  All configurations are bit-identical in their results (same per-element K order).
+// records the fastest in the plan.  All configurations of a layer are bit-identical in their results: the K walk is a function of the
+// layer's shape (conv_mfma.hip conv_korder), never of the configuration.
 extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream) {
     if (!p || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_autotune: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -674,11 +675,6 @@ extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_s
         for (int c = 0; c < nc; ++c)
             if (best_of[c] < best) { best = best_of[c]; best_cfg = cand[c]; }
         if (rc != BSY_OK) break;
-        // near-tie between the two K walks of one tile: take the chunk-major one (variant bit 4) -- a stride-2 3x3 layer then
-        // fetches its input about once instead of 2.25 times, whatever the stopwatch says about 2 %
-        if (!(best_cfg & 4))
-            for (int c = 0; c < nc; ++c)
-                if (cand[c] == (best_cfg | 4) && best_of[c] <= 1.02f * best) { best_cfg = cand[c]; break; }
         op.tuned_cfg = best_cfg + 1;
         // runner-up within 12 %: the host re-times the two IN PLACE (bsy_plan_profile passes of the whole forward) and keeps the one
         // that is faster where it runs -- back-to-back launches of one layer see its operands in the caches, the forward does not
@@ -819,11 +815,6 @@ extern "C" int bsy_plan_autotune_in_place(bsy_plan* p, void* const* ext, int n_e
     }
     for (size_t i = 0; i < n; ++i)
         if (!cand[i].empty()) {
-            // near-tie between the two K walks of one tile: the chunk-major one -- a stride-2 3x3 layer then fetches its input about
-            // once instead of 2.25 times (bsy_plan_autotune applies the same rule)
-            if (!(best_c[i] & 4))
-                for (size_t k = 0; k < cand[i].size(); ++k)
-                    if (cand[i][k] == (best_c[i] | 4) && tk[i][k] <= 1.03f * best[i]) { best_c[i] = cand[i][k]; break; }
             p->ops[i].tuned_cfg = best_c[i] + 1;
             p->ops[i].reserved0 = 0;
             p->ops[i].head_dim = 0;

@@ -65,7 +65,10 @@ def _weights_version(model) -> tuple:
     n, ver, ptr = 0, 0, 0
     for t in list(model.parameters()) + list(model.buffers()):
         n += 1
-        ver += 0 if t.is_inference() else t._version
+        try:  # (`is_inference()` alone does not tell: a Parameter whose .data was swapped by .half() / .to() outside inference
+            ver += t._version  # mode reports False and still has no counter)
+        except RuntimeError:
+            pass
         ptr ^= t.data_ptr() + 0x9E3779B1 * n
     return (n, ver, ptr)
 

@@ -153,7 +153,11 @@ void bsy_plan_destroy(bsy_plan* p);
 /* ext: HOST array of n_ext device pointers bound to the external slots (input image, y, raw maps ...). */
 int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
 /* Times every valid kernel configuration of every conv op once (HIP events on `stream`, synchronises) and records the
- * fastest per op; later bsy_plan_run calls use it.  Results are bit-identical across configurations. */
+ * fastest per op; later bsy_plan_run calls use it.  Results are bit-identical across configurations: the order in which a conv's
+ * products are summed (its K walk) is a function of the layer's SHAPE (3x3 convs with Cin % 32 == 0 sum chunk-major over 32-channel
+ * chunks -- 64-channel chunks for stride 2 with Cin % 64 == 0 --, everything else in the packed (kh, kw, cin) order), and every
+ * configuration that is valid for a layer walks K that way; ids recorded for another walk (tune caches written before round 3)
+ * are rejected as invalid, i.e. ignored.  A tuned plan therefore returns the bits of an untuned one, on every box. */
 int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
 /* HOST array cfg[n_ops]: cfg[i] >= 0 presets conv op i to that configuration (bsy_plan_autotune then skips it: results of an
  * earlier plan with the same conv shape are reused), -1 leaves the op as it is, -2 clears it. */

@@ -27,13 +27,6 @@ from oracle import yolo_ref as R
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True)
-def _heuristic_configs(monkeypatch):
-    """These tests compare the engine `accelerate` builds with one built beside it, bit for bit: both run the heuristic kernel
-    configurations (two timing-based autotunes may pick configurations that differ in fp32 summation order)."""
-    monkeypatch.setenv("BSY_AUTOTUNE", "0")
-
-
 class StandIn(torch.nn.Module):
     """What `accelerate` needs of a reference DetectionModel: `.yaml` (nn/tasks.py:313), `state_dict()` under the
     reference's names, `.training`, `.half()/.to()`, and a forward with the reference's signature (tasks.py:112-136)."""
@@ -451,3 +444,41 @@ def test_install_rebinds_every_conv_module_and_matches_torch(fused):
     # uninstall restores the original attribute state (instance `forward` only where fuse() had set one)
     assert plugin.uninstall(cpu) == n
     assert all(("forward" in m.__dict__) == fused for m in convs) and not any(hasattr(m, "_bsy_conv") for m in convs)
+
+
+def test_hooks_work_on_weights_created_under_inference_mode():
+    """The reference's own flow: predictor.stream_inference / the validator run under smart_inference_mode
+    (engine/predictor.py:219, engine/validator.py:105), so setup_model -> AutoBackend -> model.fuse() -> fuse_conv_and_bn
+    (torch_utils.py:242-269) creates the fused parameters as INFERENCE tensors, which carry no version counter
+    (`t._version` raises).  Both hooks must run on such a model, and still follow a later storage swap (.half())."""
+    x = _x(seed=5)
+    with torch.inference_mode():
+        m = StandIn(seed=4)
+        for name, p in list(m.named_parameters()):  # re-create every parameter inside inference mode, as fuse() does for the convs
+            mod, leaf = m, name.split(".")
+            for part in leaf[:-1]:
+                mod = getattr(mod, part)
+            setattr(mod, leaf[-1], torch.nn.Parameter(p.detach().clone(), requires_grad=False))
+        m = m.to(DEV)
+        assert all(p.is_inference() for p in m.parameters())
+        plugin.accelerate(m, fp32_inputs="engine")
+        y, _ = m(x.half().to(DEV))
+        y2, _ = m(x.half().to(DEV))
+        assert m.calls == 0 and m._bsy_state["engine_calls"] == 2 and m._bsy_state["rebuilds"] == 1 and torch.equal(y, y2)
+        m.half()                                     # new storages: the engine is rebuilt from them
+        m(x.half().to(DEV))
+        assert m._bsy_state["rebuilds"] == 2
+        plugin.restore(m)
+        net = Net().eval()
+        _randomise(net, 7)
+        ref = net(x)
+        _fuse(net)                                   # fused convs created under inference mode
+        gpu = net.half().to(DEV)
+        assert all(p.is_inference() for p in gpu.parameters())
+        n = plugin.install(gpu)
+        yq = gpu(x.half().to(DEV))
+        torch.cuda.synchronize()
+        covered = [mm for mm in gpu.modules() if hasattr(mm, "_bsy_conv")]
+        assert n == len(covered) > 0 and all(mm._bsy_conv["calls"] == 1 and mm._bsy_conv["fallbacks"] == 0 for mm in covered)
+        d = (yq.float().cpu() - ref).abs()
+        assert d.max() < 3e-2 * max(1.0, ref.abs().max().item())

@@ -213,7 +213,7 @@ PATCH_CASES = [
 @pytest.mark.parametrize("case", PATCH_CASES)
 def test_conv_patch_kernel_matches_oracle(case, monkeypatch):
     """3x3 stride-1 patch kernel (conv_mfma.hip, tiles 10/11 = 8x16-pixel tiles, 12/13 = 6x20) against the fp32 reference and against the implicit-GEMM
-    kernel (same operands, chunk-major instead of tap-major summation: equal to fp32 rounding, i.e. <= 1 fp16 ulp)."""
+    kernel, which walks K in the same order for these layers (conv_korder: chunk-major over 32-channel chunks): bit for bit."""
     B, H, W, cin, cout, cfg, use_res = case
     g = torch.Generator().manual_seed(cfg * 1000 + cin)
     x = h16(torch.randn(B, cin, H, W, generator=g))
@@ -226,15 +226,14 @@ def test_conv_patch_kernel_matches_oracle(case, monkeypatch):
     wp, bp = O.pack_conv_weight(w, b, DEV)
     xd = nhwc(x).half().to(DEV)
     rd = nhwc(res).half().to(DEV) if use_res else None
-    monkeypatch.delenv("BSY_CONV_CFG", raising=False)
+    monkeypatch.setenv("BSY_CONV_CFG", str(0x35))  # 128 x 64 implicit-GEMM tile, BK 32, the layer's chunk-major walk
     base = O.conv2d_nhwc(xd, wp, bp, cout, 3, 1, True, res=rd)
     monkeypatch.setenv("BSY_CONV_CFG", str(cfg))
     out = O.conv2d_nhwc(xd, wp, bp, cout, 3, 1, True, res=rd)
     torch.cuda.synchronize()
     monkeypatch.delenv("BSY_CONV_CFG")
     np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), y.numpy(), rtol=2e-3, atol=2e-3)
-    d = (out.float() - base.float()).abs()
-    assert d.max().item() <= 2e-3 * max(1.0, base.float().abs().max().item()) and (d > 0).float().mean().item() < 0.05
+    assert torch.equal(out, base)
 
 
 PERSIST_CASES = [
@@ -268,38 +267,59 @@ def test_conv_persistent_1x1_matches_one_tile_per_workgroup(case, monkeypatch):
 
 
 KORDER_CASES = [
-    # B, H, W, cin, cout, stride, cfg     cfg = tile << 4 | variant; variant + 4 = chunk-major K walk (3x3 layers, implicit-GEMM tiles)
-    (2, 40, 40, 128, 128, 2, 0x25),       # model.3's shape class: 128 x 128 tile, BK 32 / 3 stages
-    (1, 33, 31, 64, 256, 2, 0x77),        # 256 x 256 tile, BK 64; odd extents
-    (2, 20, 20, 256, 256, 2, 0x27),       # BK 64, 4 chunks x 9 taps
-    (3, 17, 23, 32, 48, 2, 0x16),         # one chunk: both walks visit the same K-steps; ragged cout, 2 stages
-    (2, 24, 24, 96, 64, 1, 0x35),         # stride 1 is valid too (the tuner only offers it for stride 2)
+    # B, H, W, cin, cout, k, stride, K walk (conv_mfma.hip conv_korder: 0 packed order, 1 / 2 chunk-major over 32- / 64-channel chunks)
+    (2, 40, 40, 128, 128, 3, 2, 2),       # model.3's shape class
+    (1, 33, 31, 64, 256, 3, 2, 2),        # odd extents; the 256 x 256 tile applies
+    (2, 20, 20, 256, 256, 3, 2, 2),       # 4 chunks x 9 taps
+    (3, 17, 23, 32, 48, 3, 2, 1),         # one 32-channel chunk, ragged cout
+    (2, 24, 24, 96, 64, 3, 1, 1),         # stride 1: the patch kernel's order, three chunks
+    (2, 24, 40, 128, 128, 3, 1, 1),       # stride 1, Cin % 64 == 0: still 32-channel chunks (no 64-deep K-steps)
+    (2, 16, 16, 96, 128, 1, 1, 0),        # 1x1: one tap, one order
+    (2, 12, 10, 24, 32, 3, 1, 0),         # unaligned channel count: generic variant only
 ]
 
 
 @pytest.mark.parametrize("case", KORDER_CASES)
-def test_conv_chunk_major_k_walk_matches_oracle(case, monkeypatch):
-    """Variant bit 4 of the implicit-GEMM configurations (conv_mfma.hip, ConvK::korder): all nine taps of a BK-channel chunk,
-    then the next chunk -- another summation order, so equal to the tap-major walk to fp32 rounding (<= 1 fp16 ulp)."""
-    B, H, W, cin, cout, s, cfg = case
-    g = torch.Generator().manual_seed(cfg * 1000 + cin)
+def test_conv_every_configuration_of_a_layer_is_bit_identical(case, monkeypatch):
+    """The K walk of a conv is a function of its shape (conv_mfma.hip conv_korder), not of the kernel configuration: every id the
+    library accepts for a layer -- implicit-GEMM tiles with BK 32 / 64 and 2 / 3 stages, patch tiles, persistent tiles -- returns
+    the same bits (round-2 VERDICT: results must not depend on what the autotuner timed), and ids of another walk (recorded by an
+    older tune cache) are rejected."""
+    B, H, W, cin, cout, k, s, ko = case
+    g = torch.Generator().manual_seed(1000 * cin + cout + k)
     x = h16(torch.randn(B, cin, H, W, generator=g))
-    w = h16(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    w = h16(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
     b = torch.randn(cout, generator=g) * 0.5
-    y = F.silu(F.conv2d(x, w, b, s, 1))
+    y = F.silu(F.conv2d(x, w, b, s, k // 2))
     wp, bp = O.pack_conv_weight(w, b, DEV)
     xd = nhwc(x).half().to(DEV)
-    monkeypatch.setenv("BSY_CONV_CFG", str(cfg & ~4))
-    base = O.conv2d_nhwc(xd, wp, bp, cout, 3, s, True)
-    monkeypatch.setenv("BSY_CONV_CFG", str(cfg))
-    out = O.conv2d_nhwc(xd, wp, bp, cout, 3, s, True)
-    torch.cuda.synchronize()
+    monkeypatch.delenv("BSY_CONV_CFG", raising=False)
+    base = O.conv2d_nhwc(xd, wp, bp, cout, k, s, True)  # the heuristic configuration
+    np.testing.assert_allclose(nchw(base.float().cpu()).numpy(), y.numpy(), rtol=2e-3, atol=2e-3)
+    accepted = []
+    for tile in range(14):
+        for var in range(8):
+            cfg = (tile << 4) | var
+            monkeypatch.setenv("BSY_CONV_CFG", str(cfg))
+            try:
+                out = O.conv2d_nhwc(xd, wp, bp, cout, k, s, True)
+            except L.BsyError:
+                continue
+            accepted.append(cfg)
+            assert torch.equal(out, base), hex(cfg)
     monkeypatch.delenv("BSY_CONV_CFG")
-    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), y.numpy(), rtol=2e-3, atol=2e-3)
-    d = (out.float() - base.float()).abs()
-    assert d.max().item() <= 2e-3 * max(1.0, base.float().abs().max().item()) and (d > 0).float().mean().item() < 0.05
-    if cin <= 32:
-        assert torch.equal(out, base)  # a single chunk: identical K-steps in identical order
+    torch.cuda.synchronize()
+    assert len(accepted) >= (1 if ko == 0 and k == 3 else 4), [hex(c) for c in accepted]
+    for cfg in accepted:
+        tile, var = cfg >> 4, cfg & 7
+        if tile < 8:  # implicit-GEMM ids carry the walk: chunk-major bit set iff the layer is chunk-major; no 64-deep steps on 32-channel chunks
+            assert bool(var & 4) == (ko != 0) and not (ko == 1 and (var & 3) == 3), hex(cfg)
+        else:
+            assert not (var & 4), hex(cfg)
+    if ko == 1 and s == 1:
+        assert any(c >> 4 >= 10 for c in accepted) and any(c >> 4 < 8 for c in accepted)  # patch AND implicit-GEMM tiles took part
+    if ko == 2:
+        assert any((c & 3) == 3 for c in accepted) and any((c & 3) in (1, 2) for c in accepted)  # 64-deep and 32-deep K-steps
 
 
 def test_conv_two_sources_and_upsample():
@@ -402,8 +422,7 @@ def test_stem_fused_rejects_unsupported():
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 40, 24), (3, 9, 13), (70, 8, 16), (1, 3, 5), (300, 16, 16)])
 def test_bottleneck_fused_matches_unfused_and_oracle(shape, widths, monkeypatch):
     """Bottleneck (block.py:3405-3419, k = (3,3), shortcut) as one launch (csrc/bneck_fused.hip; 32/16: YOLO11s model.2,
-    64/32: model.4 / model.16): bit-identical to two bsy_conv2d launches through the implicit-GEMM kernel (tap-major K order;
-    the second with the residual) and equal to the fp32 reference with the hidden map rounded to fp16.  Input and output are
+    64/32: model.4 / model.16): bit-identical to two bsy_conv2d launches (the second with the residual) and equal to the fp32 reference with the hidden map rounded to fp16.  Input and output are
     channel slices of one wider buffer, as inside C3k2's concat buffer; shapes cover ragged tiles, maps smaller than one tile
     and more tiles than persistent workgroups."""
     B, H, W = shape
@@ -421,10 +440,9 @@ def test_bottleneck_fused_matches_unfused_and_oracle(shape, widths, monkeypatch)
     w1p, b1p = O.pack_conv_weight(w1, b1, DEV)
     w2p, b2p = O.pack_conv_weight(w2, b2, DEV)
     xc = x.contiguous()
-    monkeypatch.setenv("BSY_CONV_CFG", str(3 << 4))  # 128 x 64 implicit-GEMM tile, generic variant (any Cin % 8 == 0): the tap-major K order the fused kernels share
+    monkeypatch.delenv("BSY_CONV_CFG", raising=False)  # any configuration: a layer's K walk depends on its shape only (conv_korder)
     mid = O.conv2d_nhwc(xc, w1p, b1p, ch, 3, 1, True)
     two = O.conv2d_nhwc(mid, w2p, b2p, c, 3, 1, True, res=xc)
-    monkeypatch.delenv("BSY_CONV_CFG")
     torch.cuda.synchronize()
     assert torch.equal(dbuf[..., 2 * c:], two)
     assert torch.equal(dbuf[..., :2 * c].cpu(), buf[..., :2 * c].half())  # the other slices are untouched
@@ -828,30 +846,55 @@ def test_predict_pipeline_config1_end_to_end():
     eng.close()
 
 
-@pytest.mark.parametrize("scale,shape", [("n", (1, 32, 32)), ("s", (3, 96, 224)), ("s", (2, 160, 32)), ("n", (5, 64, 416))])
-def test_engine_tuned_fused_equals_plain_on_odd_shapes(scale, shape):
-    """Every fusion + the autotuner's picks (patch / persistent / big-tile kernels) against the plain plan (one launch per
-    layer, heuristic implicit-GEMM configurations) on small, narrow and wide inputs: same prediction up to the fp32
-    summation-order differences of the patch kernel and the fused DFL (a few f16 ulps on isolated anchors), same raw maps."""
+@pytest.mark.parametrize("scale,shape", [("n", (1, 32, 32)), ("s", (3, 96, 224)), ("s", (2, 160, 32)), ("n", (5, 64, 416)), ("s", (16, 320, 320))])
+def test_engine_tuned_equals_untuned_bit_for_bit(scale, shape):
+    """Results do not depend on what the autotuner timed (round-2 VERDICT 3): every kernel configuration that is valid for a layer
+    sums in that layer's K walk (conv_mfma.hip conv_korder), so a tuned engine -- patch / persistent / big-tile kernels wherever
+    they won on THIS box -- returns bit for bit what the heuristic plan (autotune off) returns, and two separately tuned engines
+    agree with each other, through both tuners."""
     m = R.Model("yolo11", scale, 80, "detect")
     P = R.synth_params(m, 2)
     cfg = stock_cfg("yolo11", scale)
-    full = YoloEngine(cfg, P)
-    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_head=False, fuse_dwpw=False, merge_c3k=False, autotune=False)
+    B, H, W = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * W)).half().to(DEV)
+    plain = YoloEngine(cfg, P, autotune=False)
+    yp, rp = plain(x)
+    tuned_a = YoloEngine(cfg, P, autotune=True)
+    tuned_b = YoloEngine(cfg, P, autotune=True)
+    tuned_b.tune_mode = "0"  # the one-layer-at-a-time tuner (bsy_plan_autotune)
+    ya, ra = tuned_a(x)
+    yb, rb = tuned_b(x)
+    torch.cuda.synchronize()
+    assert tuned_a.tune_stats["timed_ops"] > 0 and tuned_b.tune_stats["timed_ops"] > 0
+    assert torch.equal(ya, yp) and torch.equal(yb, yp)
+    for a, b, c in zip(ra, rb, rp):
+        assert torch.equal(a, c) and torch.equal(b, c)
+    for e in (plain, tuned_a, tuned_b):
+        e.close()
+
+
+@pytest.mark.parametrize("scale,shape", [("n", (1, 32, 32)), ("s", (3, 96, 224)), ("s", (2, 160, 32)), ("n", (5, 64, 416))])
+def test_engine_fused_equals_plain_on_odd_shapes(scale, shape):
+    """Every fusion against the plain plan (one launch per layer) on small, narrow and wide inputs, both with the heuristic
+    configurations: the conv kernels and their fused forms agree bit for bit; what differs is the fused Detect decoder (DFL
+    expectation summed across a lane pair, head.py:141-146 in the conv epilogue) against the stand-alone decode kernel -- a few f32
+    ulps of a distance, i.e. at most one f16 ulp of an output."""
+    m = R.Model("yolo11", scale, 80, "detect")
+    P = R.synth_params(m, 2)
+    cfg = stock_cfg("yolo11", scale)
+    full = YoloEngine(cfg, P, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_stem=False, fuse_bneck=False, fuse_head=False, fuse_dwpw=False, merge_c3k=False, fuse_tail=False, autotune=False)
     B, H, W = shape
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * W)).half().to(DEV)
     yf, rf = full(x)
     yp, rp = plain(x)
     torch.cuda.synchronize()
     d = (yf.float() - yp.float()).abs()
-    # The tuned plan may run a layer on a kernel family with another fp32 summation order (patch / chunk-major K walk vs the plain
-    # plan's tap-major implicit GEMM): 1-ulp flips of fp16 maps that later layers amplify.  Bounds = a few f16 ulps of the outputs
-    # (scores: ulp 4.9e-4 .. 9.8e-4; one ulp of a coordinate in [256, 512) is 0.25 px, the widest input here is 416 pixels);
-    # the mean says these are isolated anchors
-    assert d[:, 4:].max() < 6e-3 and d[:, :4].max() <= 0.75, (d[:, 4:].max(), d[:, :4].max())
-    assert d[:, 4:].mean() < 2e-4 and d[:, :4].mean() < 0.05, (d[:, 4:].mean(), d[:, :4].mean())  # (the golden tests allow 1e-4 against the oracle)
+    # one ulp of a score is <= 9.8e-4, of a coordinate in [256, 512) 0.25 px (the widest input here is 416 pixels)
+    assert d[:, 4:].max() < 2e-3 and d[:, :4].max() <= 0.25, (d[:, 4:].max(), d[:, :4].max())
+    assert d[:, 4:].mean() < 5e-5 and d[:, :4].mean() < 0.02, (d[:, 4:].mean(), d[:, :4].mean())
     for a, b in zip(rf, rp):
-        assert (a.float() - b.float()).abs().max() < 2e-2 * max(1.0, b.float().abs().max().item())
+        assert torch.equal(a, b)  # the raw maps are the conv outputs themselves: identical
     full.close()
     plain.close()
 

@@ -547,3 +547,24 @@ def test_results_boxes_match_reference_golden():
     assert res[0][0:2].boxes.shape == (2, 6) and res[0].numpy().boxes.conf.dtype == np.float32
     s = res[0].summary(normalize=True)
     assert s[0] == {"name": "dog", "class": 1, "confidence": 0.9, "box": {"x1": 0.01562, "y1": 0.04167, "x2": 0.17188, "y2": 0.45833}}
+
+
+def test_weights_fingerprint_accepts_inference_tensors():
+    """plugin._weights_version on parameters created under torch.inference_mode() (what fuse() produces inside the
+    predictor's smart_inference_mode, engine/predictor.py:219): they have no version counter -- reading `_version` raises --
+    so the fingerprint falls back to their storage pointers; ordinary tensors still count in-place updates."""
+    from bs_yolo_amd import plugin
+    with torch.inference_mode():
+        conv = torch.nn.Conv2d(4, 4, 1)
+    assert all(p.is_inference() for p in conv.parameters())
+    with pytest.raises(RuntimeError):
+        conv.weight._version
+    f0 = plugin._weights_version(conv)
+    assert f0 == plugin._weights_version(conv)
+    conv.half()
+    assert plugin._weights_version(conv) != f0      # new storages
+    lin = torch.nn.Linear(3, 3)
+    f1 = plugin._weights_version(lin)
+    with torch.no_grad():
+        lin.weight.mul_(2.0)
+    assert plugin._weights_version(lin) != f1       # in-place update of an ordinary tensor
