@@ -361,7 +361,8 @@ class LoadImagesPinned:
 
 def predict_stream(engine, loader: LoadImagesPinned, conf: float = 0.25, iou: float = 0.7, max_det: int = 300,
                    classes=None, agnostic: bool = False):
-    """The predict loop of the hot path (engine/predictor.py:240-262 stream_inference without the Results objects):
+    """The predict loop of the hot path (engine/predictor.py:240-262 stream_inference; the reference builds its own Results from these tensors,
+    models/yolo/detect/predict.py:34-45):
     for every loader batch -> (batch, det (B, max_det, 6) fp32 with boxes scaled back to each original image
     (scale_boxes, ops.py:92-127), counts (B,) int32), all device-resident; the next batch decodes and uploads meanwhile."""
     from .nms import nms_batched, scale_boxes_batched
@@ -370,13 +371,3 @@ def predict_stream(engine, loader: LoadImagesPinned, conf: float = 0.25, iou: fl
         det, counts = nms_batched(y, conf, iou, classes=classes, agnostic=agnostic, max_det=max_det)
         scale_boxes_batched(det, counts, batch.im.shape[2:], batch.orig_shapes)
         yield batch, det, counts
-
-
-def predict_results(engine, loader: LoadImagesPinned, names=None, **kw):
-    """`predict_stream` with the reference's return type: a list of `results.Results` per batch (engine/predictor.py:240-262 +
-    models/yolo/detect/predict.py:20-45), boxes as device-resident row views of the NMS output."""
-    from .results import build_results
-    names = names or getattr(engine, "names", None) or {}
-    for batch, det, counts in predict_stream(engine, loader, **kw):
-        yield build_results(det, counts, batch.im0s, batch.paths, names, batch.orig_shapes)
-

@@ -375,29 +375,6 @@ def masks_native_fixtures():
     print("wrote masks_native", len(cases), "cases")
 
 
-def results_fixtures():
-    """engine/results.py Boxes (round 2): the reference's own xywh / xyxyn / xywhn on random detections, with and without a track id."""
-    from ultralytics.engine.results import Boxes as RefBoxes
-    g = torch.Generator().manual_seed(21)
-    out, cases = {}, []
-    for ci, (n, cols, shape) in enumerate([(7, 6, (480, 640)), (1, 6, (1080, 810)), (0, 6, (64, 64)), (5, 7, (4000, 6000))]):
-        xy = torch.rand(n, 2, generator=g) * torch.tensor([shape[1], shape[0]]) * 0.7
-        wh = torch.rand(n, 2, generator=g) * torch.tensor([shape[1], shape[0]]) * 0.3
-        rest = torch.rand(n, cols - 4, generator=g)
-        data = torch.cat((xy, xy + wh, rest), 1)
-        b = RefBoxes(data, shape)
-        out[f"c{ci}.data"] = data.numpy()
-        out[f"c{ci}.shape"] = np.asarray(shape)
-        for k in ("xyxy", "conf", "cls", "xywh", "xyxyn", "xywhn"):
-            out[f"c{ci}.{k}"] = getattr(b, k).numpy()
-        if cols == 7:
-            out[f"c{ci}.id"] = b.id.numpy()
-        cases.append(ci)
-    out["cases"] = np.asarray(cases)
-    np.savez_compressed(HERE / "results_boxes.npz", **out)
-    print("wrote results_boxes", len(cases), "cases")
-
-
 def synth_pred(b, nc, a, nm, seed, peaky, dtype=torch.float32):
     """(B, 4+nc+nm, A) prediction tensor in Detect's output format with duplicated / overlapping boxes."""
     g = torch.Generator().manual_seed(seed)
@@ -546,9 +523,6 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ap":  # only the ap_per_class vectors
         ap_fixtures()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "results":  # only the Boxes vectors (round 2)
-        results_fixtures()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bsyolo_modules":  # only the BS-YOLO module vectors (cases are appended: earlier ones keep their values)
         bsyolo_module_fixtures()

@@ -523,32 +523,6 @@ def test_bench_starts_its_own_ranks():
     assert re.search(r"bench\.py needs a ROCm GPU.*\(rank [01] of 2\)", r.stderr), r.stderr[-2000:]
 
 
-def test_results_boxes_match_reference_golden():
-    """bs_yolo_amd.results.Boxes (engine/results.py:939-1155) against the reference's own properties (results_boxes.npz): views and
-    coordinate arithmetic bit for bit, torch and numpy data, with and without a track id; Results / build_results bookkeeping."""
-    from bs_yolo_amd.results import Boxes, Results, build_results
-    z = np.load(ROOT / "tests" / "golden" / "results_boxes.npz")
-    for ci in z["cases"]:
-        data, shape = z[f"c{ci}.data"], tuple(int(v) for v in z[f"c{ci}.shape"])
-        for b in (Boxes(torch.from_numpy(data), shape), Boxes(data.copy(), shape)):
-            for k in ("xyxy", "conf", "cls", "xywh", "xyxyn", "xywhn"):
-                got = getattr(b, k)
-                got = got.numpy() if isinstance(got, torch.Tensor) else got
-                assert np.array_equal(got, z[f"c{ci}.{k}"]), (ci, k)
-            assert (b.id is None) == (data.shape[1] == 6) and len(b) == data.shape[0]
-            if data.shape[1] == 7:
-                assert np.array_equal(np.asarray(b.id), z[f"c{ci}.id"])
-            assert np.array_equal(np.asarray(b.xyxy), data[:, :4])  # the properties do not modify `data`
-    det = torch.zeros(2, 4, 6)
-    det[0, :3] = torch.tensor([[10., 20., 110., 220., .9, 1.], [0., 0., 50., 50., .8, 0.], [5., 5., 6., 6., .3, 1.]])
-    res = build_results(det, torch.tensor([3, 0], dtype=torch.int32), [np.zeros((480, 640, 3), np.uint8), np.zeros((100, 200, 3), np.uint8)],
-                        ["a.jpg", "b.jpg"], {0: "cat", 1: "dog"})
-    assert [len(r) for r in res] == [3, 0] and res[1].orig_shape == (100, 200) and res[0].path == "a.jpg"
-    assert res[0][0:2].boxes.shape == (2, 6) and res[0].numpy().boxes.conf.dtype == np.float32
-    s = res[0].summary(normalize=True)
-    assert s[0] == {"name": "dog", "class": 1, "confidence": 0.9, "box": {"x1": 0.01562, "y1": 0.04167, "x2": 0.17188, "y2": 0.45833}}
-
-
 def test_weights_fingerprint_accepts_inference_tensors():
     """plugin._weights_version on parameters created under torch.inference_mode() (what fuse() produces inside the
     predictor's smart_inference_mode, engine/predictor.py:219): they have no version counter -- reading `_version` raises --

@@ -132,13 +132,4 @@ def test_predict_stream_matches_unpipelined_path(tmp_path):
         HN.scale_boxes_batched(d, c, x.shape[2:], shapes[i:i + n])
         assert torch.equal(c, counts) and torch.equal(d, det) and int(c.sum()) > 0
         i += n
-    # the same loop with the reference's return type: Results per image (results.py), boxes = row views of the NMS output
-    res = [r for batch in HL.predict_results(eng, HL.LoadImagesPinned(files, batch=2, imgsz=320, device=DEV), conf=0.25, iou=0.7) for r in batch]
-    assert len(res) == 5 and [r.orig_shape for r in res] == shapes and [r.path for r in res] == [str(f) for f in files]
-    flat = [(d[k, :int(c[k])]) for _, d, c in got for k in range(d.shape[0])]
-    for r, d in zip(res, flat):
-        assert torch.equal(r.boxes.data, d[:, :6]) and r.boxes.data.is_cuda
-        assert len(r) == d.shape[0] and r.numpy().boxes.xywhn.shape == (d.shape[0], 4)
-        if len(r):
-            assert float(r.boxes.xyxyn.max()) <= 1.0 + 1e-6 and r.summary()[0]["name"] == r.names[int(r.boxes.cls[0])]
     eng.close()
