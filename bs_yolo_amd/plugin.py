@@ -11,10 +11,14 @@ Three hooks, each using an extension point the reference already has (see INTEGR
   install(model)           per-module hook (the fallback level for graphs `accelerate` does not cover: a custom block, an
                            unknown head).  Rebinds ``forward`` on every ``Conv`` / ``DWConv`` INSTANCE (nn/modules/conv.py:133-151,
                            :224-229) -- again the reference's own idiom, ``m.forward = m.forward_fuse`` (nn/tasks.py:215) -- so
-                           that the block modules' Python forwards (C3k2, C2f, SPPF, C2PSA, PMSFA ... call their child Convs) run
-                           every convolution through ``bsy_conv2d`` / ``bsy_conv_first`` / ``bsy_dwconv``.  Activations stay
-                           torch tensors in channels_last memory format (= the kernels' NHWC, no copies); everything that is
-                           not a conv (cat, chunk, upsample, pooling, attention, the head's decode) stays with torch.
+                           that the block modules' Python forwards (C2f, C3k, C2PSA, PMSFA ... call their child Convs) run
+                           every convolution through ``bsy_conv2d`` / ``bsy_conv_first`` / ``bsy_dwconv``; and on the block
+                           instances the library has an operator for: ``SPPF`` (block.py:3145-3149: ``bsy_sppf_pool`` on the
+                           concat buffer), ``Attention`` (:4267-4286: ``bsy_attention`` + the ``pe`` depthwise conv with the
+                           residual), ``Bottleneck`` / ``C3k2`` whose widths the fused kernels are built for (:3417-3419,
+                           :3796-3804: ``bsy_bottleneck_fused`` / ``bsy_c3k2_fused``) and ``Detect._inference``
+                           (head.py:100-131: ``bsy_detect_decode``).  Activations stay torch tensors in channels_last memory
+                           format (= the kernels' NHWC, no copies); the rest (cat, chunk, upsample ...) stays with torch.
   install_nms(ops_module)  ``ultralytics.utils.ops.non_max_suppression`` is looked up as a module attribute on every
                            call (models/yolo/detect/predict.py:25, detect/val.py:95): replacing the attribute suffices.
   install_masks(ops_module) same for ``ultralytics.utils.ops.process_mask`` (models/yolo/segment/predict.py:53).
@@ -237,40 +241,252 @@ def _conv_forward(m, spec):
     return fwd, st
 
 
-def install(model, verbose: bool = False) -> int:
-    """Per-module hook: every covered Conv / DWConv instance of `model` runs its convolution in the HIP library (fp16 CUDA
-    inputs in eval mode; anything else reaches the module's own forward).  Returns the number of instances rebound;
-    `uninstall(model)` undoes it.  Call it AFTER `model.fuse()` if the model is to be fused (fuse() rebinds `forward` itself).
-    Use `accelerate(model)` where the whole graph is covered -- it is 5-10x faster (fused blocks,
+def _silu_conv(m, k=None, s=1, groups=1) -> bool:
+    """`m` is a reference Conv (+BN) + SiLU module with a square k x k kernel (k None: any), stride s, "same" padding."""
+    conv, act = getattr(m, "conv", None), getattr(m, "act", None)
+    return (isinstance(conv, torch.nn.Conv2d) and isinstance(act, torch.nn.SiLU) and conv.groups == groups
+            and conv.kernel_size[0] == conv.kernel_size[1] and (k is None or conv.kernel_size[0] == k)
+            and conv.stride == (s, s) and conv.padding == (conv.kernel_size[0] // 2,) * 2 and conv.dilation == (1, 1))
+
+
+def _folded(m):
+    """(weight, bias) fp32 of a reference Conv module, BatchNorm folded in when the module still has one (un-fused)."""
+    from .weights import fold_conv_bn
+    sd = {"m.conv." + n: t for n, t in m.conv.state_dict().items()}
+    bn = getattr(m, "bn", None)
+    if isinstance(bn, torch.nn.BatchNorm2d) and getattr(m.forward, "__name__", "") != "forward_fuse":
+        sd.update({"m.bn." + n: t for n, t in bn.state_dict().items()})
+    elif "m.conv.bias" not in sd:
+        sd["m.conv.bias"] = torch.zeros(m.conv.out_channels)
+    return fold_conv_bn(sd, "m", float(bn.eps) if isinstance(bn, torch.nn.BatchNorm2d) else BN_EPS)
+
+
+def _block_spec(m):
+    """Which block operator of the library covers `m` (a reference module instance), or None."""
+    from . import lib as L
+    name = type(m).__name__
+    if name == "SPPF":
+        pool = getattr(m, "m", None)
+        if (isinstance(pool, torch.nn.MaxPool2d) and pool.kernel_size == 5 and pool.stride == 1 and pool.padding == 2
+                and _silu_conv(getattr(m, "cv1", None), 1) and _silu_conv(getattr(m, "cv2", None), 1)
+                and m.cv1.conv.out_channels % 8 == 0 and m.cv2.conv.in_channels == 4 * m.cv1.conv.out_channels):
+            return "sppf"
+    if name == "Attention":
+        if (all(hasattr(m, a) for a in ("qkv", "proj", "pe", "num_heads", "key_dim", "head_dim", "scale"))
+                and m.key_dim == 32 and m.head_dim == 64 and _conv_spec(m.qkv) == ("conv", 1, 1, 0) and _conv_spec(m.proj) == ("conv", 1, 1, 0)
+                and _conv_spec(m.pe) == ("dw", 3, 1, 0)):
+            return "attention"
+    if name == "Bottleneck":
+        cv1, cv2 = getattr(m, "cv1", None), getattr(m, "cv2", None)
+        if (getattr(m, "add", False) and _silu_conv(cv1, 3) and _silu_conv(cv2, 3)
+                and L.lib.bsy_bottleneck_fused_supported(cv1.conv.in_channels, cv1.conv.out_channels) == 1):
+            return "bottleneck"
+    if name in ("C3k2", "C2f"):
+        mm = getattr(m, "m", None)
+        if (isinstance(mm, torch.nn.ModuleList) and len(mm) == 1 and type(mm[0]).__name__ == "Bottleneck" and getattr(mm[0], "add", False)
+                and _silu_conv(getattr(m, "cv1", None), 1) and _silu_conv(getattr(m, "cv2", None), 1)
+                and _silu_conv(mm[0].cv1, 3) and _silu_conv(mm[0].cv2, 3) and mm[0].cv1.conv.out_channels * 2 == m.c
+                and L.lib.bsy_c3k2_fused_supported(m.cv1.conv.in_channels, m.c, m.cv2.conv.out_channels) == 1):
+            return "c3k2"
+    if name in ("Detect", "Segment"):
+        if (getattr(m, "reg_max", 0) == 16 and 1 <= getattr(m, "nl", 0) <= 3 and not getattr(m, "export", False)
+                and getattr(m, "format", None) is None and hasattr(m, "_inference")):
+            return "detect"
+    return None
+
+
+def _nhwc(x):
+    """NCHW fp16 tensor -> its NHWC view (no copy when the tensor is already in channels_last memory format)."""
+    return x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
+def _block_forward(m, kind):
+    """The replacement `forward` (`_inference` for Detect) of one block instance.  fp16 CUDA tensors in eval mode; anything
+    else reaches the module's own method.  Weights are re-packed when they change (`_weights_version`)."""
+    from .ops import _p, _stream, pack_conv_weight
+    attr = "_inference" if kind == "detect" else "forward"
+    orig = getattr(m, attr)
+    st = {"ver": None, "dev": None, "w": None, "calls": 0, "fallbacks": 0, "kind": kind, "attr": attr}
+
+    def usable(self, x):
+        return torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and not self.training
+
+    def ready(self, dev):
+        ver = _weights_version(self)
+        if st["ver"] != ver or st["dev"] != dev:
+            st["w"] = pack(self, dev)
+            st["ver"], st["dev"] = ver, dev
+        return st["w"]
+
+    if kind == "sppf":
+        def pack(self, dev):
+            return [pack_conv_weight(*_folded(c), dev) for c in (self.cv1, self.cv2)]
+
+        def fwd(self, x):
+            if not usable(self, x) or x.shape[1] != self.cv1.conv.in_channels:
+                st["fallbacks"] += 1
+                return orig(x)
+            (w1, b1), (w2, b2) = ready(self, x.device)
+            B, c1, H, W = x.shape
+            c_, c2 = self.cv1.conv.out_channels, self.cv2.conv.out_channels
+            xn = _nhwc(x)
+            cat = torch.empty((B, H, W, 4 * c_), dtype=torch.float16, device=x.device)
+            out = torch.empty((B, H, W, c2), dtype=torch.float16, device=x.device)
+            with torch.cuda.device(x.device):
+                s = _stream(x)  # cv1 writes channels [0, c_) of the concat buffer, the pools fill the rest in place, cv2 reads all of it
+                _L.check(_L.lib.bsy_conv2d(_p(xn), c1, B, H, W, c1, _p(w1), _p(b1), _p(cat), 4 * c_, c_, 1, 1, 1, None, 0, 0, s))
+                _L.check(_L.lib.bsy_sppf_pool(_p(cat), 4 * c_, B, H, W, c_, s))
+                _L.check(_L.lib.bsy_conv2d(_p(cat), 4 * c_, B, H, W, 4 * c_, _p(w2), _p(b2), _p(out), c2, c2, 1, 1, 1, None, 0, 0, s))
+            st["calls"] += 1
+            return out.permute(0, 3, 1, 2)
+    elif kind == "attention":
+        def pack(self, dev):
+            nh, kd, hd = self.num_heads, self.key_dim, self.head_dim
+            per = 2 * kd + hd  # the module emits [q k v] per head (block.py:4274-4276); the kernels want [q | k | v] by heads
+            perm = torch.tensor([h * per + i for h in range(nh) for i in range(kd)] + [h * per + kd + i for h in range(nh) for i in range(kd)]
+                                + [h * per + 2 * kd + i for h in range(nh) for i in range(hd)])
+            wq, bq = _folded(self.qkv)
+            wpe, bpe = _folded(self.pe)
+            c = nh * hd
+            return [pack_conv_weight(wq[perm], bq[perm], dev), pack_conv_weight(*_folded(self.proj), dev),
+                    (wpe.view(c, 9).t().contiguous().to(dev), bpe.contiguous().to(dev))]
+
+        def fwd(self, x):
+            if not usable(self, x) or x.shape[1] != self.num_heads * self.head_dim:
+                st["fallbacks"] += 1
+                return orig(x)
+            (wq, bq), (wp, bp), (wd, bd) = ready(self, x.device)
+            B, c, H, W = x.shape
+            nh, kd, hd = self.num_heads, self.key_dim, self.head_dim
+            ld = nh * (2 * kd + hd)
+            xn = _nhwc(x)
+            qkv = torch.empty((B, H, W, ld), dtype=torch.float16, device=x.device)
+            att = torch.empty((B, H, W, c), dtype=torch.float16, device=x.device)
+            xo = torch.empty_like(att)
+            out = torch.empty_like(att)
+            with torch.cuda.device(x.device):
+                s = _stream(x)
+                _L.check(_L.lib.bsy_conv2d(_p(xn), c, B, H, W, c, _p(wq), _p(bq), _p(qkv), ld, ld, 1, 1, 0, None, 0, 0, s))
+                _L.check(_L.lib.bsy_attention(_p(qkv), ld, B, H * W, nh, kd, hd, float(self.scale), _p(att), c, s))
+                v = qkv[..., 2 * nh * kd:]  # v @ attn^T + pe(v): the depthwise conv reads the v slice and adds the attention output
+                _L.check(_L.lib.bsy_dwconv3x3(_p(v), ld, B, H, W, c, _p(wd), _p(bd), _p(xo), c, 0, _p(att), c, s))
+                _L.check(_L.lib.bsy_conv2d(_p(xo), c, B, H, W, c, _p(wp), _p(bp), _p(out), c, c, 1, 1, 0, None, 0, 0, s))
+            st["calls"] += 1
+            return out.permute(0, 3, 1, 2)
+    elif kind == "bottleneck":
+        def pack(self, dev):
+            return [pack_conv_weight(*_folded(c), dev) for c in (self.cv1, self.cv2)]
+
+        def fwd(self, x):
+            if not usable(self, x) or x.shape[1] != self.cv1.conv.in_channels:
+                st["fallbacks"] += 1
+                return orig(x)
+            (w1, b1), (w2, b2) = ready(self, x.device)
+            B, c, H, W = x.shape
+            xn = _nhwc(x)
+            out = torch.empty((B, H, W, c), dtype=torch.float16, device=x.device)
+            with torch.cuda.device(x.device):
+                _L.check(_L.lib.bsy_bottleneck_fused(_p(xn), xn.stride(2), B, H, W, c, self.cv1.conv.out_channels, _p(w1), _p(b1), _p(w2), _p(b2),
+                                                     _p(out), c, 1, _stream(x)))
+            st["calls"] += 1
+            return out.permute(0, 3, 1, 2)
+    elif kind == "c3k2":
+        def pack(self, dev):
+            return [pack_conv_weight(*_folded(c), dev) for c in (self.cv1, self.m[0].cv1, self.m[0].cv2, self.cv2)]
+
+        def fwd(self, x):
+            if not usable(self, x) or x.shape[1] != self.cv1.conv.in_channels:
+                st["fallbacks"] += 1
+                return orig(x)
+            pk = ready(self, x.device)
+            B, cin, H, W = x.shape
+            c2 = self.cv2.conv.out_channels
+            xn = _nhwc(x)
+            out = torch.empty((B, H, W, c2), dtype=torch.float16, device=x.device)
+            with torch.cuda.device(x.device):
+                _L.check(_L.lib.bsy_c3k2_fused(_p(xn), xn.stride(2), B, H, W, cin, self.c, c2, _p(pk[0][0]), _p(pk[0][1]), _p(pk[1][0]), _p(pk[1][1]),
+                                               _p(pk[2][0]), _p(pk[2][1]), _p(pk[3][0]), _p(pk[3][1]), _p(out), c2, _stream(x)))
+            st["calls"] += 1
+            return out.permute(0, 3, 1, 2)
+    else:  # detect: Detect._inference(x) with x = the per-level (B, 64 + nc, h, w) logit maps (head.py:100-131)
+        import ctypes as C
+
+        def pack(self, dev):
+            return None
+
+        def fwd(self, x):
+            xs = list(x) if isinstance(x, (list, tuple)) else None
+            nm = 0
+            if (xs is None or len(xs) != self.nl or self.training or getattr(self, "export", False)
+                    or not all(torch.is_tensor(t) and t.is_cuda and t.dtype in (torch.float16, torch.float32) and t.dim() == 4
+                               and t.shape[1] == self.no and t.shape[0] == xs[0].shape[0] for t in xs)):
+                st["fallbacks"] += 1
+                return orig(x)
+            B, nl, nc = xs[0].shape[0], self.nl, self.nc
+            dev, dt = xs[0].device, xs[0].dtype
+            maps = [t.permute(0, 2, 3, 1).float().contiguous() for t in xs]  # (B, h, w, no) f32: what bsy_detect_decode reads
+            A = sum(t.shape[1] * t.shape[2] for t in maps)
+            y = torch.empty((B, 4 + nc, A), dtype=dt, device=dev)
+            vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+            box = (vp * nl)(*[t.data_ptr() for t in maps])
+            cls = (vp * nl)(*[t.data_ptr() + 64 * 4 for t in maps])
+            ldv = (i32 * nl)(*[self.no] * nl)
+            hh = (i32 * nl)(*[t.shape[1] for t in maps])
+            ww = (i32 * nl)(*[t.shape[2] for t in maps])
+            sv = (f32 * nl)(*[float(v) for v in self.stride])
+            with torch.cuda.device(dev):
+                _L.check(_L.lib.bsy_detect_decode(box, ldv, cls, ldv, None, None, hh, ww, sv, nl, B, nc, nm, _p(y), _L.dtype_code(dt), _stream(y)))
+            st["calls"] += 1
+            return y
+    return fwd, st
+
+
+def install(model, verbose: bool = False, blocks: bool = True) -> int:
+    """Per-module hook: every covered Conv / DWConv instance of `model` runs its convolution in the HIP library, and (blocks=True)
+    every SPPF / Attention / Detect instance -- and every Bottleneck / C3k2 whose widths the fused kernels are built for -- runs on
+    the library's block operator (fp16 CUDA inputs in eval mode; anything else reaches the module's own method).  Returns the
+    number of instances rebound; `uninstall(model)` undoes it.  Call it AFTER `model.fuse()` if the model is to be fused (fuse()
+    rebinds `forward` itself).  Use `accelerate(model)` where the whole graph is covered -- it is 5-10x faster (all blocks fused,
     no per-layer Python); this is the level for graphs with modules the engine does not know."""
     n = 0
     for name, m in model.named_modules():
-        if hasattr(m, "_bsy_conv"):
+        if hasattr(m, "_bsy_conv") or hasattr(m, "_bsy_block"):
             continue
         spec = _conv_spec(m)
-        if spec is None:
+        if spec is not None:
+            fwd, st = _conv_forward(m, spec)
+            st["orig"] = m.__dict__.get("forward")  # an instance attribute (set by fuse()) or None (the class method)
+            m._bsy_conv = st
+            m.forward = types.MethodType(fwd, m)
+            n += 1
+            if verbose:
+                print(f"bs_yolo_amd.install: {name} -> {spec}")
             continue
-        fwd, st = _conv_forward(m, spec)
-        st["orig"] = m.__dict__.get("forward")  # an instance attribute (set by fuse()) or None (the class method)
-        m._bsy_conv = st
-        m.forward = types.MethodType(fwd, m)
-        n += 1
-        if verbose:
-            print(f"bs_yolo_amd.install: {name} -> {spec}")
+        kind = _block_spec(m) if blocks else None
+        if kind is not None:
+            fwd, st = _block_forward(m, kind)
+            st["orig"] = m.__dict__.get(st["attr"])
+            m._bsy_block = st
+            setattr(m, st["attr"], types.MethodType(fwd, m))
+            n += 1
+            if verbose:
+                print(f"bs_yolo_amd.install: {name} -> {kind}")
     return n
 
 
 def uninstall(model) -> int:
     n = 0
     for m in model.modules():
-        st = m.__dict__.pop("_bsy_conv", None)
-        if st is None:
-            continue
-        if st["orig"] is None:
-            del m.forward
-        else:
-            m.forward = st["orig"]
-        n += 1
+        for key, attr in (("_bsy_conv", None), ("_bsy_block", None)):
+            st = m.__dict__.pop(key, None)
+            if st is None:
+                continue
+            a = st.get("attr", "forward")
+            if st["orig"] is None:
+                delattr(m, a)
+            else:
+                setattr(m, a, st["orig"])
+            n += 1
     return n
 
 
