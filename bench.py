@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"],
                     help="fp16: the product path (NHWC fp16 activations, the headline); fp32: the engine's fp32 mode -- fp32 storage and "
                          "arithmetic on the fp32 matrix pipe, what plugin.accelerate gives callers of predict(half=False)")
+    ap.add_argument("--graph", default="off", choices=["on", "off"],
+                    help="replay the forward as ONE captured hipGraph launch (engine graph mode).  Off by default: measured SLOWER than the "
+                         "eager replay at every batch size on ROCm 7.2 (8 images: 1.17 vs 0.92 ms per forward + NMS; DESIGN.md section 6)")
     ap.add_argument("--serial-nms", action="store_true",
                     help="run NMS (and the detection all-gather) on the forward's stream; default: on a second stream, so that "
                          "NMS of step i runs beside the forward of step i + 1 (every step's work still lies inside the timed region)")
@@ -153,7 +156,6 @@ def main():
 
     cfg = stock_cfg(args.family, args.scale, 12 if args.family == "bsyolo11" else 80, "detect")
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
-    eng = YoloEngine(cfg, sd, device=local, precision=args.precision)
     S = args.imgsz
     f32 = args.precision == "fp32"
     peak = PEAK_MFMA_F32_TFLOPS if f32 else PEAK_MFMA_F16_TFLOPS
@@ -165,6 +167,8 @@ def main():
             sys.exit(f"--scaling strong: batch {args.batch} leaves rank {rank} of {world} without images")
     else:
         B, global_batch = args.batch, world * args.batch
+    use_graph = args.graph == "on"
+    eng = YoloEngine(cfg, sd, device=local, precision=args.precision, graph=use_graph)
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(B, 3, S, S, generator=g).to(torch.float32 if f32 else torch.float16).to(dev)
     if not (args.family == "yolo11" and args.scale == "s"):
@@ -182,7 +186,7 @@ def main():
             elif ".cv3." in k and k.endswith(".2.bias"):
                 sd[k] = torch.full_like(sd[k], math.log(0.25 / 0.75) - q)
         eng.close()
-        eng = YoloEngine(cfg, sd, device=local, precision=args.precision)
+        eng = YoloEngine(cfg, sd, device=local, precision=args.precision, graph=use_graph)
     from bs_yolo_amd.parallel import gather_detections_async
     pending = None   # the previous step's detection all-gather, in flight on RCCL's stream
     gathered = None
@@ -190,6 +194,9 @@ def main():
     # Post-processing stream: NMS reads a prediction tensor of its own (the engine allocates `y` per call), so NMS of step i may run
     # beside the forward of step i + 1 -- 64 one-workgroup-per-image kernels next to 256-CU conv launches.  The forward's stream
     # never waits for it; torch.cuda.synchronize() at the end of the timed region does.
+    if use_graph:  # the legacy default stream cannot be captured: the forward gets a stream of its own
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     main = torch.cuda.current_stream(dev)
     post = main if args.serial_nms else torch.cuda.Stream(device=dev)
 
@@ -299,6 +306,8 @@ def main():
                                    + (" + RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": global_batch, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",
                        "pipeline": "NMS on the forward's stream" if args.serial_nms else "NMS of step i on a second stream beside the forward of step i + 1",
+                       "forward_launch": ("one captured hipGraph launch per forward (%d captured, %d replayed)" % (eng.graph_stats["captures"], eng.graph_stats["replays"]))
+                                         if use_graph else "eager: one launch per op",
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 1),
                        "model_gflop_per_image": round(plan.flops / B / 1e9, 2),
                        "whole_path_tflops": round(plan.flops / B * global_batch / (ms_step * 1e-3) / 1e12, 1)},

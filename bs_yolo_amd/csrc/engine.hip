@@ -20,6 +20,7 @@ struct bsy_engine {
     // addresses it through host-assigned offsets).  Grows, never shrinks; plans resolve the base at run time.
     char* arena = nullptr;
     size_t arena_bytes = 0;
+    unsigned arena_gen = 0;  // bumped whenever the arena moves: captured graphs hold its addresses
 };
 
 struct bsy_plan {
@@ -39,6 +40,18 @@ struct bsy_plan {
                                          // an event that still has a waiter pending is never re-recorded)
     float last_event_overhead_ms = 0.f;  // bsy_plan_profile: median empty event interval of the last call
     size_t guard = 0;                    // bytes of guard band behind every buffer (BSY_PLAN_GUARD)
+    // captured forwards (bsy_plan_graph_launch): one executable graph per set of external pointers, oldest first
+    struct Captured {
+        std::vector<void*> ext;
+        unsigned arena_gen;
+        hipGraphExec_t exec;
+    };
+    std::vector<Captured> graphs;
+    bool graph_unavailable = false;      // a capture failed once: this plan runs eagerly from then on
+    void drop_graphs() {
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
 };
 
 extern "C" int bsy_engine_create(int device, bsy_engine** out) {
@@ -162,6 +175,7 @@ extern "C" int bsy_plan_create_arena(bsy_engine* e, const bsy_op* ops, int n_ops
         if (e->arena) { HIP_TRY(hipFree(e->arena)); e->arena = nullptr; e->arena_bytes = 0; }
         if (hipMalloc((void**)&e->arena, need) != hipSuccess) BSY_FAIL(BSY_ERR_ALLOC, "plan_create_arena: hipMalloc(%zu) failed", need);
         e->arena_bytes = need;
+        ++e->arena_gen;
         // zero once so that padding channels nobody writes start finite (later tenants of a region leave ordinary f16 / f32
         // activations behind; no kernel consumes padding channels)
         HIP_TRY(hipMemset(e->arena, 0, need));
@@ -206,6 +220,7 @@ extern "C" int bsy_plan_check_guards(bsy_plan* p, int32_t* bad_buf, int64_t* bad
 
 extern "C" void bsy_plan_destroy(bsy_plan* p) {
     if (!p) return;
+    p->drop_graphs();
     for (auto ev : p->events) (void)hipEventDestroy(ev);
     for (auto ev : p->lane_done) if (ev) (void)hipEventDestroy(ev);
     for (auto st : p->lanes) if (st) (void)hipStreamDestroy(st);
@@ -631,12 +646,61 @@ extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream
     return rc;
 }
 
+// The forward as ONE graph launch.  At a rank's share of a strong-scaled batch (8 or 16 images: 70-odd launches of 4-15 us) the
+// eager replay is bound by the host's launch rate and by the fork / join events of the head lanes; a captured graph hands the
+// whole dependency structure -- lanes included, they become edges -- to the GPU's command processor in one submission.
+// The graph bakes in every address: it is cached per set of external pointers (callers that cycle through a few input / output
+// buffers hit the cache; at most BSY_GRAPH_MAX = 8 graphs per plan, oldest dropped), and dropped when the arena moves or the
+// tuning changes.  Captures on `stream` in thread-local mode (bsy_plan_run issues nothing but kernel launches and event
+// record / wait pairs); if a capture fails the plan runs eagerly, now and later.  *captured (may be null): 1 when this call
+// had to capture, 0 when it replayed a cached graph, -1 when it ran eagerly.
+#define BSY_GRAPH_MAX 8
+extern "C" int bsy_plan_graph_launch(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, int* captured) {
+    if (!p || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_graph_launch: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (captured) *captured = -1;
+    if (p->graph_unavailable || !s) return bsy_plan_run(p, ext, n_ext, stream);  // (the null stream cannot be captured)
+    const unsigned gen = p->use_arena ? p->eng->arena_gen : 0u;
+    std::vector<void*> key(ext, ext + n_ext);
+    for (size_t i = 0; i < p->graphs.size(); ++i)
+        if (p->graphs[i].arena_gen == gen && p->graphs[i].ext == key) {
+            if (captured) *captured = 0;
+            HIP_TRY(hipGraphLaunch(p->graphs[i].exec, s));
+            return BSY_OK;
+        }
+    for (size_t i = 0; i < p->graphs.size();)  // graphs of an arena that has moved since
+        if (p->graphs[i].arena_gen != gen) { (void)hipGraphExecDestroy(p->graphs[i].exec); p->graphs.erase(p->graphs.begin() + i); } else ++i;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        p->graph_unavailable = true;
+        return bsy_plan_run(p, ext, n_ext, stream);
+    }
+    const int rc = bsy_plan_run(p, ext, n_ext, stream);
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc != BSY_OK || ec != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        p->graph_unavailable = true;
+        if (rc != BSY_OK) return rc;  // the plan itself is at fault: report it
+        return bsy_plan_run(p, ext, n_ext, stream);
+    }
+    (void)hipGraphDestroy(graph);
+    if (p->graphs.size() >= BSY_GRAPH_MAX) { (void)hipGraphExecDestroy(p->graphs.front().exec); p->graphs.erase(p->graphs.begin()); }
+    p->graphs.push_back(bsy_plan::Captured{key, gen, exec});
+    if (captured) *captured = 1;
+    HIP_TRY(hipGraphLaunch(exec, s));
+    return BSY_OK;
+}
+
 // Per-op autotuning of the conv kernel configuration (tile shape / K-step / ring depth): runs the plan once, timing
 // every valid configuration of every conv op with HIP events on `stream` (1 warm-up + 3 timed launches each) and
 // records the fastest in the plan.  All configurations of a layer are bit-identical in their results: the K walk is a function of the
 // layer's shape (conv_mfma.hip conv_korder), never of the configuration.
 extern "C" int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream) {
     if (!p || (n_ext && !ext)) BSY_FAIL(BSY_ERR_ARG, "plan_autotune: bad argument");
+    p->drop_graphs();
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -714,6 +778,7 @@ extern "C" int bsy_plan_get_tuning_alt(bsy_plan* p, int rank, int32_t* out, int 
 // the op as it is, -2 clears it (heuristic / to be tuned).  A preset that is not valid for the op's shape is ignored at launch.
 extern "C" int bsy_plan_set_tuning(bsy_plan* p, const int32_t* cfg, int n) {
     if (!p || !cfg || n != (int)p->ops.size()) BSY_FAIL(BSY_ERR_ARG, "plan_set_tuning: bad argument");
+    p->drop_graphs();  // captured forwards hold the old configurations' launches
     for (int i = 0; i < n; ++i) {
         if (p->ops[i].kind != BSY_OP_CONV || cfg[i] == -1) continue;
         p->ops[i].tuned_cfg = cfg[i] >= 0 ? cfg[i] + 1 : 0;
@@ -770,6 +835,7 @@ extern "C" int bsy_plan_profile(bsy_plan* p, void* const* ext, int n_ext, bsy_st
 // preset (bsy_plan_set_tuning) are left alone.  Costs max_i(#candidates) x rounds forwards (~0.4 s for YOLO11s at 64 x 640 x 640).
 extern "C" int bsy_plan_autotune_in_place(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, int rounds) {
     if (!p || (n_ext && !ext) || rounds < 1 || rounds > 16) BSY_FAIL(BSY_ERR_ARG, "plan_autotune_in_place: bad argument");
+    p->drop_graphs();
     hipStream_t s = (hipStream_t)stream;
     const size_t n = p->ops.size();
     Resolver R{p, ext, n_ext};

@@ -26,7 +26,7 @@ class YoloEngine:
                  autotune: Optional[bool] = None, fuse_stem: Optional[bool] = None,
                  fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None, fuse_dwpw: Optional[bool] = None,
                  merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None, fuse_tail: Optional[bool] = None,
-                 max_plans: Optional[int] = None, precision: str = "fp16"):
+                 max_plans: Optional[int] = None, precision: str = "fp16", graph: Optional[bool] = None, graph_ring: int = 3):
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
@@ -66,6 +66,17 @@ class YoloEngine:
         # liveness-based buffer reuse (Plan.assign_offsets).  Off under BSY_ARENA_REUSE=0 (tests that read intermediate
         # layers back) and under BSY_PLAN_GUARD (guard bands behind every buffer: the plan then owns a private workspace)
         self.reuse = os.environ.get("BSY_ARENA_REUSE", "1") != "0" and not os.environ.get("BSY_PLAN_GUARD")
+        # Graph mode (opt-in: graph=True / BSY_GRAPH=1): the forward of a shape is captured once per set of buffer addresses and
+        # replayed as ONE hipGraph launch (bsy_plan_graph_launch) -- what a rank needs at its 8- or 16-image share of a strong-
+        # scaled batch, where 70-odd launches of 4-15 us are bound by the host's launch rate.  The graph bakes addresses in, so the
+        # outputs come from a ring of `graph_ring` preallocated sets per shape: a returned `y` is overwritten by the graph_ring-th
+        # forward after it (the reference's predict / val loops consume `preds` within the iteration, engine/predictor.py:254-262).
+        # Head lanes are on at every size in this mode (fork / join are graph edges).
+        self.graph = (os.environ.get("BSY_GRAPH", "0") == "1") if graph is None else bool(graph)
+        self.graph_ring = max(1, int(graph_ring))
+        self._rings: Dict[Tuple, dict] = {}
+        self._gstream = None
+        self.graph_stats = {"captures": 0, "replays": 0, "eager": 0}
         self.autotune = ((os.environ.get("BSY_AUTOTUNE", "1") != "0") if autotune is None else bool(autotune)) and precision == "fp16"
         # pack once with a throw-away plan (op list structure does not depend on the input size)
         self.fuse_stem = fuse_stem  # None: BSY_FUSE_STEM env (default on); False keeps layers 0 and 1 as two launches
@@ -87,7 +98,8 @@ class YoloEngine:
 
     def _fuse_kw(self):
         return dict(fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head, fuse_dwpw=self.fuse_dwpw,
-                    merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail, precision=self.precision)
+                    merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail, precision=self.precision,
+                    lanes=True if getattr(self, "graph", False) else None)
 
     # -- plans --------------------------------------------------------------------------------------------------
     def plan_for(self, B: int, H: int, W: int, in_dtype: torch.dtype, out_dtype: torch.dtype):
@@ -121,8 +133,10 @@ class YoloEngine:
         preset = (C.c_int32 * len(plan.ops))(*[self._tune_cache.get(sg, -1) if sg is not None else -1 for sg in plan.conv_sigs])
         L.check(L.lib.bsy_plan_set_tuning(h, preset, len(plan.ops)))
         while len(self._plans) >= max(self.max_plans, 1):  # evict the least recently used shape
-            _, (_, old) = self._plans.popitem(last=False)
+            old_key, (_, old) = self._plans.popitem(last=False)
             L.lib.bsy_plan_destroy(old)
+            for rk in [k for k in self._rings if k[0] == old_key]:
+                del self._rings[rk]
         self._plans[key] = (plan, h)
         return plan, h
 
@@ -243,21 +257,49 @@ class YoloEngine:
             return y, ([torch.cat([o[1][l] for o in outs]) for l in range(3)] if want_raw else [None] * 3)
         plan, h = self.plan_for(B, H, W, im.dtype, im.dtype)
         m = plan.meta
-        y = torch.empty((B, 4 + m["nc"] + m["nm"], m["A"]), dtype=im.dtype, device=self.device)
-        raws: List[Optional[torch.Tensor]] = [None, None, None]
-        if want_raw:
-            raws = [torch.empty((B, m["no"], lh, lw), dtype=im.dtype, device=self.device) for lh, lw in m["levels"]]
-        proto = None
-        if m["nm"]:
-            ph, pw = m["proto_hw"]
-            proto = torch.empty((B, m["nm"], ph, pw), dtype=im.dtype, device=self.device)
+
+        def outputs():
+            y = torch.empty((B, 4 + m["nc"] + m["nm"], m["A"]), dtype=im.dtype, device=self.device)
+            raws: List[Optional[torch.Tensor]] = [None, None, None]
+            if want_raw:
+                raws = [torch.empty((B, m["no"], lh, lw), dtype=im.dtype, device=self.device) for lh, lw in m["levels"]]
+            proto = None
+            if m["nm"]:
+                ph, pw = m["proto_hw"]
+                proto = torch.empty((B, m["nm"], ph, pw), dtype=im.dtype, device=self.device)
+            return y, raws, proto
+
+        if self.graph:  # outputs from this shape's ring: the captured graphs hold their addresses
+            ring = self._rings.setdefault(((B, H, W, im.dtype, im.dtype), bool(want_raw)), {"i": 0, "slots": []})
+            if len(ring["slots"]) < self.graph_ring:
+                ring["slots"].append(outputs())
+            y, raws, proto = ring["slots"][ring["i"] % len(ring["slots"])]
+            ring["i"] += 1
+        else:
+            y, raws, proto = outputs()
         ext, n = self._ext(im, y, raws, proto)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.autotune and (B, H, W, im.dtype) not in self._tuned:
             # first call for this shape: pick the fastest kernel configuration per conv op (runs the plan once)
             self._tuned.add((B, H, W, im.dtype))
             self._autotune(plan, h, ext, n, stream)
-        L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
+        if self.graph:
+            how = C.c_int(-1)
+            if stream == 0:
+                # the legacy default stream cannot be captured: capture / replay on a stream of the engine's, ordered after the
+                # caller's work and joined back into it (two event pairs per forward)
+                cur = torch.cuda.current_stream(self.device)
+                if self._gstream is None:
+                    self._gstream = torch.cuda.Stream(device=self.device)
+                self._gstream.wait_stream(cur)
+                im.record_stream(self._gstream)
+                L.check(L.lib.bsy_plan_graph_launch(h, ext, n, C.c_void_p(self._gstream.cuda_stream), C.byref(how)))
+                cur.wait_stream(self._gstream)
+            else:
+                L.check(L.lib.bsy_plan_graph_launch(h, ext, n, C.c_void_p(stream), C.byref(how)))
+            self.graph_stats[{1: "captures", 0: "replays"}.get(how.value, "eager")] += 1
+        else:
+            L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
         if m["nm"]:  # Segment.forward (head.py:197): (cat(y, mc), (raw, mc, proto)); y already carries the mc rows
             return y, (raws, y[:, 4 + m["nc"]:], proto)
         return y, raws

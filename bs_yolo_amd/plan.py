@@ -103,7 +103,7 @@ class Plan:
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
                  fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None,
-                 fuse_tail: Optional[bool] = None, precision: str = "fp16"):
+                 fuse_tail: Optional[bool] = None, precision: str = "fp16", lanes: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         if precision not in ("fp16", "fp32"):
             raise ValueError(f"precision must be 'fp16' or 'fp32', not {precision!r}")
@@ -132,8 +132,9 @@ class Plan:
         # are long enough to overlap -- from about 12 images of 640 x 640 (measured: 0.74 vs 0.79 ms at 1 image, 0.94 vs 0.96 at 8,
         # 1.25 vs 1.24 at 16, 1.92 vs 1.87 at 32, 3.3 vs 3.2 at 64).  BSY_LANES=0 / 1 forces one or the other (0: the tests' serial
         # reference schedule).
-        lanes = os.environ.get("BSY_LANES")
-        if lanes == "0" or (lanes is None and B * H * W < 12 * 640 * 640):
+        # `lanes` (argument): the engine's graph mode asks for them at every size -- in a captured graph fork / join are edges, not events.
+        env = os.environ.get("BSY_LANES")
+        if env == "0" or (env is None and not lanes and (lanes is not None or B * H * W < 12 * 640 * 640)):
             for o in self.ops:
                 if "lane" in o:
                     o["lane"] = 0

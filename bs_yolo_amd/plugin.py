@@ -84,9 +84,10 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
     engine/predictor.py:131).  The product path stores activations in fp16, which is NOT the fp32 model's arithmetic
     (max |dscore| up to 6e-3 against the fp32 reference, vs the north-star's 1e-3), so it is never
     applied to fp32 callers silently:
-      ``"engine_fp32"`` (default)  the engine's fp32 correctness mode: fp32 storage and arithmetic on the GPU
-                                   (csrc/ref32.hip; |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz against the fp32 reference;
-                                   simple kernels, a few TFLOP/s);
+      ``"engine_fp32"`` (default)  the engine's fp32 mode: fp32 storage, convs on the fp32 matrix pipe (csrc/conv32_mfma.hip,
+                                   exact f32 products and sums; |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz against the fp32
+                                   reference; ~70 TFLOP/s, 3.2 k images/s for YOLO11s 640 x 640 -- 1/6 of the fp16 path; a
+                                   one-time log line says so);
       ``"engine"``                 opt in to the fast fp16-storage path for fp32 inputs (outputs come back as fp32);
       ``"reference"``              leave fp32 inputs to the original forward.
     ``BSY_FP32_INPUTS`` overrides the default.  fp16 inputs (``half=True`` / ``model.half()``) always run on the fp16
@@ -128,6 +129,14 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
             state["fallbacks"] += 1
             return orig_forward(x, *args, **kwargs)
         want32 = x.dtype == torch.float32 and fp32_mode == "engine_fp32"
+        if want32 and not state.get("fp32_notice"):
+            state["fp32_notice"] = True  # once per model: which engine default callers (predict(half=False)) are on, and the way out
+            import logging
+            logging.getLogger("bs_yolo_amd").warning(
+                "fp32 images run in the engine's fp32 mode (fp32 storage, fp32 matrix pipe: the fp32 model's numbers, about 1/6 of the "
+                "fp16 path's throughput -- YOLO11s 640x640: ~3.2 k vs ~20 k images/s per MI355X).  For the fp16 product path call "
+                "predict(half=True) or accelerate(model, fp32_inputs='engine'); fp32_inputs='reference' keeps fp32 inputs on the "
+                "original forward.")
         try:
             y, raws = _engine_for(x.device, "fp32" if want32 else "fp16")(x)
         except (_L.BsyError, NotImplementedError, AssertionError) as e:  # a shape / graph the engine rejects: the reference runs it

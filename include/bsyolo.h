@@ -152,6 +152,13 @@ size_t bsy_engine_arena_bytes(const bsy_engine* e);
 void bsy_plan_destroy(bsy_plan* p);
 /* ext: HOST array of n_ext device pointers bound to the external slots (input image, y, raw maps ...). */
 int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
+/* The same forward as ONE graph launch: the first call with a given set of external pointers captures bsy_plan_run on `stream`
+ * (thread-local capture; side lanes become graph edges) and instantiates it, later calls with the same pointers replay it -- one
+ * submission instead of 70-odd launches, which is what bounds a forward at the 8- or 16-image share of a strong-scaled batch.
+ * Up to 8 graphs per plan (oldest dropped); all are dropped when the arena moves or the plan's tuning changes.  `stream` must not
+ * be the null stream (falls back to bsy_plan_run, as it does for good if a capture ever fails).  *captured (optional): 1 captured
+ * now, 0 replayed, -1 ran eagerly.  Results are those of bsy_plan_run bit for bit (the same launches). */
+int bsy_plan_graph_launch(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, int* captured);
 /* Times every valid kernel configuration of every conv op once (HIP events on `stream`, synchronises) and records the
  * fastest per op; later bsy_plan_run calls use it.  Results are bit-identical across configurations: the order in which a conv's
  * products are summed (its K walk) is a function of the layer's SHAPE (3x3 convs with Cin % 32 == 0 sum chunk-major over 32-channel

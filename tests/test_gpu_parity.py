@@ -873,6 +873,46 @@ def test_engine_tuned_equals_untuned_bit_for_bit(scale, shape):
         e.close()
 
 
+@pytest.mark.parametrize("fam,scale,nc,task,shape", [("yolo11", "s", 80, "detect", (8, 640, 640)), ("yolo11", "n", 80, "segment", (2, 96, 160)),
+                                                     ("bsyolo11", "n", 12, "detect", (3, 128, 96))])
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_engine_graph_mode_equals_eager(fam, scale, nc, task, shape, own_stream):
+    """Graph mode (bsy_plan_graph_launch: the forward captured once per set of buffer addresses, replayed as one hipGraph launch,
+    head lanes as graph edges) returns the eager engine's bits; a graph is captured once per ring slot and then replayed; a
+    returned tensor is overwritten graph_ring forwards later and not before; on the legacy default stream the engine captures
+    on a stream of its own."""
+    m = R.Model("yolo11" if fam == "yolo11" else fam, scale, nc, task)
+    P = R.synth_params(m, 3)
+    cfg = stock_cfg(fam, scale, nc, task)
+    B, H, W = shape
+    xs = [torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(10 + i)).half().to(DEV) for i in range(2)]
+    eager = YoloEngine(cfg, P, autotune=False)
+    graph = YoloEngine(cfg, P, autotune=False, graph=True, graph_ring=2)
+    pg, _ = graph.plan_for(B, H, W, torch.float16, torch.float16)
+    assert any(o.get("lane", 0) > 0 for o in pg.ops)  # lanes at every size in graph mode
+    stream = torch.cuda.Stream(device=DEV) if own_stream else torch.cuda.current_stream(DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        ref = [eager(x) for x in xs]
+        outs = []
+        for rep in range(3):
+            for x in xs:
+                y, extra = graph(x)
+                outs.append((y, extra, y.clone()))
+    torch.cuda.synchronize()
+    # 2 inputs x 2 ring slots: the pairing (input, slot) repeats with period 2 -> two captures, the rest replays
+    assert graph.graph_stats == {"captures": 2, "replays": 4, "eager": 0}, graph.graph_stats
+    for i, (y, extra, snap) in enumerate(outs):
+        y_ref, e_ref = ref[i % 2]
+        assert torch.equal(snap, y_ref)                   # what the call returned, when it returned
+        assert y.data_ptr() == outs[i % 2][0].data_ptr()  # ring of two: the same two buffers over and over
+    flat = lambda e: [t for t in (e if isinstance(e, (list, tuple)) else [e]) for t in (t if isinstance(t, (list, tuple)) else [t]) if t is not None]  # noqa: E731
+    for a, b in zip(flat(outs[-1][1]), flat(ref[1][1])):
+        assert torch.equal(a, b)
+    eager.close()
+    graph.close()
+
+
 @pytest.mark.parametrize("scale,shape", [("n", (1, 32, 32)), ("s", (3, 96, 224)), ("s", (2, 160, 32)), ("n", (5, 64, 416))])
 def test_engine_fused_equals_plain_on_odd_shapes(scale, shape):
     """Every fusion against the plain plan (one launch per layer) on small, narrow and wide inputs, both with the heuristic
