@@ -955,7 +955,10 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
     constexpr int OTILE = TM * (TN + 8);
     constexpr int RING = 2 * PBUF + STAGES * WST;
     constexpr int SMEM = RING > OTILE ? RING : OTILE;
-    static_assert(STAGES == 2 || (STAGES == 3 && WM == 2), "ring depth (the 8-wave form deals the weight DMA unevenly: vmcnt(0) only)");
+    static_assert(STAGES == 2 || ((STAGES == 3 || STAGES == 4) && WM == 2), "ring depth (the 8-wave form deals the weight DMA unevenly: vmcnt(0) only)");
+    // STAGES <= 4: the patch of chunk c is issued at kernel row 0 of chunk c - 1, i.e. before (or in the same step as, and then ahead
+    // of) the weights of chunk c's first step as long as those are issued at most three steps ahead; a deeper ring would let that
+    // step's wait pass with the patch still in flight.
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
     half_t* sW = smem + 2 * PBUF;
 
@@ -1045,9 +1048,14 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
         // wait for W(k) (and everything older: this chunk's patch); younger: W(k+1 .. k+STAGES-2) and, when this is the
         // kernel row after a patch issue, the next chunk's patch
         const int younger = min(STAGES - 2, nsteps - 1 - k);
-        const bool p_young = STAGES > 2 ? (kh == 1 && chunk + 1 < nchunks) : false;
+        // the next chunk's patch is issued at kernel row 0, behind W(k + STAGES - 2) of that step: it is younger than W(k) during the
+        // following STAGES - 2 steps
+        const bool p_young = STAGES > 2 ? (kh >= 1 && kh <= STAGES - 2 && chunk + 1 < nchunks) : false;
         if (younger <= 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (STAGES > 3 && younger >= 2) {
+            if (p_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WIW + PIW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WIW) : "memory");
         } else if (p_young) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIW + PIW) : "memory");
         } else {
@@ -1443,7 +1451,7 @@ int conv_korder(const ConvArgs& a) {
 //            5 = 64 x 128, 6 = 64 x 64 (4 waves; small tiles = many resident workgroups for the latency-bound thin-K layers);
 //            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128);
 //            8 = 128 x 128, 9 = 128 x 64 persistent 1x1 kernel (4 compute + 4 store waves, tiles walked per workgroup);
-//            10 = 8x16 px x 128 couts (2-stage weight ring), 11 = 8x16 px x 64 couts (variant 1: 3 stages, 2: 2 stages):
+//            10 = 8x16 px x 128 couts (2-stage weight ring), 11 = 8x16 px x 64 couts (variant 1: 3 stages, 2: 2 stages, 3: 4 stages):
 //            patch-based 3x3 stride-1 kernel; 12 / 13 = the same with 6x20-pixel tiles (maps whose width is a multiple of 20)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages; + 4 on the implicit-GEMM tiles of a layer whose K walk is
@@ -1471,7 +1479,7 @@ bool conv_cfg_valid(const ConvArgs& a, int cfg) {
         return conv_cfg_valid(b, ((tile - 2) << 4) | var);
     }
     if (tile >= 10) {  // patch-based 3x3 stride-1 kernel (TN 128 / 64): sums chunk-major over 32-channel chunks = K walk 1
-        return ko == 1 && (var == 1 || (var == 2 && tile == 11)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
+        return ko == 1 && (var == 1 || ((var == 2 || var == 3) && tile == 11)) && a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && !(a.C0 & 31) && !a.out_f32 &&
                !(a.Cout & 7) && !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 &&
                (!a.res || (!(a.ldr & 7) && !((uintptr_t)a.res & 15))) && (tile == 10 ? a.Cout > 64 : true);
     }
@@ -1501,8 +1509,8 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (n < max_out && conv_cfg_valid(a, c)) out[n++] = c;
     };
     if (a.tail_wgt) {  // 3x3 conv + 1x1 + DFL: the four 64-cout patch configurations
-        if (ceil_div(a.W, 20) * ceil_div(a.H, 6) < ceil_div(a.W, 16) * ceil_div(a.H, 8)) { add(13, 2); add(13, 1); }
-        add(11, 2); add(11, 1); add(13, 2); add(13, 1);
+        if (ceil_div(a.W, 20) * ceil_div(a.H, 6) < ceil_div(a.W, 16) * ceil_div(a.H, 8)) { add(13, 2); add(13, 1); add(13, 3); }
+        add(11, 2); add(11, 1); add(11, 3); add(13, 2); add(13, 1); add(13, 3);
         return n;
     }
     if (!aligned) {
@@ -1530,8 +1538,8 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         for (int v = 1; v <= 3; ++v) add(t, v | (t < 8 ? km : 0));
     }
     if (a.H >= 16 && a.W >= 16 && patch_ok) {  // 3x3 s1 patch kernel
-        add(10, 1); add(11, 1); add(11, 2);
-        if (t20) { add(12, 1); add(13, 1); add(13, 2); }
+        add(10, 1); add(11, 1); add(11, 2); add(11, 3);
+        if (t20) { add(12, 1); add(13, 1); add(13, 2); add(13, 3); }
     }
     return n;
 }
@@ -1607,14 +1615,18 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
 #define BSY_TILE(KS_)                                                                     \
     do {                                                                                  \
         if (k.tail_wgt && tile == 13 && var == 1) return launch_patch<1, 3, 2, 20, true>(k, s); \
+        if (k.tail_wgt && tile == 13 && var == 3) return launch_patch<1, 4, 2, 20, true>(k, s); \
         if (k.tail_wgt && tile == 13) return launch_patch<1, 2, 2, 20, true>(k, s);       \
         if (k.tail_wgt && tile == 11 && var == 1) return launch_patch<1, 3, 2, 16, true>(k, s); \
+        if (k.tail_wgt && tile == 11 && var == 3) return launch_patch<1, 4, 2, 16, true>(k, s); \
         if (k.tail_wgt) return launch_patch<1, 2, 2, 16, true>(k, s);                     \
         if (tile == 12) return launch_patch<2, 2, 2, 20>(k, s);                           \
         if (tile == 13 && var == 1) return launch_patch<1, 3, 2, 20>(k, s);               \
+        if (tile == 13 && var == 3) return launch_patch<1, 4, 2, 20>(k, s);               \
         if (tile == 13) return launch_patch<1, 2, 2, 20>(k, s);                           \
         if (tile == 10) return launch_patch<2, 2, 2>(k, s);                               \
         if (tile == 11 && var == 1) return launch_patch<1, 3, 2>(k, s);                   \
+        if (tile == 11 && var == 3) return launch_patch<1, 4, 2>(k, s);                   \
         if (tile == 11) return launch_patch<1, 2, 2>(k, s);                               \
         if (tile == 8 && var == 1) return launch_persist<2, 2, 2, 2, 3, 32>(k, s);        \
         if (tile == 8 && var == 2) return launch_persist<2, 2, 2, 2, 2, 32>(k, s);        \

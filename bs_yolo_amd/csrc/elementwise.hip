@@ -188,40 +188,46 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(half_t* __restrict__ buf
     *reinterpret_cast<half8*>(op + 3 * C) = m13;
 }
 
-// LDS version: one workgroup owns the whole H x W map of one (image, 8-channel chunk); each MaxPool2d(5,1,2) is a row
-// pass + a column pass (10 LDS reads instead of 25 global ones), chained three times without leaving the CU.
-__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(half_t* __restrict__ buf, int ld, int H, int W, int C) {
+// LDS version: one workgroup owns the whole H x W map of one image and CG adjacent 8-channel chunks (CG = as many as LDS takes, up
+// to 8: a pixel's piece is then 16 CG contiguous bytes -- with one chunk per workgroup every load and store was an isolated 16-byte
+// piece 2 ld bytes away from the next, and the 20 x 20 x 256 pool of YOLO11s took 45 us for 105 MB); each MaxPool2d(5,1,2) is a row
+// pass + a column pass (10 LDS reads instead of 25 global ones), chained three times without leaving the CU.  Item = (pixel, chunk),
+// chunk fastest.  Maxima are exact: the result does not depend on CG.
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(half_t* __restrict__ buf, int ld, int H, int W, int C, int CG) {
     extern __shared__ __attribute__((aligned(16))) half8 sp[];
-    const int HW = H * W;
-    half8* A = sp;        // current map
-    half8* R = sp + HW;   // row-pooled map
-    const int c = blockIdx.x * 8;
+    const int HW = H * W, NI = HW * CG;
+    half8* A = sp;        // current map  [pixel][chunk]
+    half8* R = sp + NI;   // row-pooled map
+    const int c = blockIdx.x * CG * 8;
     const int n = blockIdx.y;
     half_t* base = buf + (size_t)n * HW * ld + c;
-    for (int i = threadIdx.x; i < HW; i += 256) A[i] = *reinterpret_cast<const half8*>(base + (size_t)i * ld);
+    for (int it = threadIdx.x; it < NI; it += 256) {
+        const int i = it / CG, ck = it - i * CG;
+        A[it] = *reinterpret_cast<const half8*>(base + (size_t)i * ld + ck * 8);
+    }
     __syncthreads();
     for (int pass = 1; pass <= 3; ++pass) {
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            const int y = i / W, x = i - y * W;
-            half8 m = A[i];
+        for (int it = threadIdx.x; it < NI; it += 256) {
+            const int i = it / CG, y = i / W, x = i - y * W;
+            half8 m = A[it];
 #pragma unroll
             for (int d = 1; d <= 2; ++d) {
-                if (x - d >= 0) m = hmax8(m, A[i - d]);
-                if (x + d < W) m = hmax8(m, A[i + d]);
+                if (x - d >= 0) m = hmax8(m, A[it - d * CG]);
+                if (x + d < W) m = hmax8(m, A[it + d * CG]);
             }
-            R[i] = m;
+            R[it] = m;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            const int y = i / W;
-            half8 m = R[i];
+        for (int it = threadIdx.x; it < NI; it += 256) {
+            const int i = it / CG, ck = it - i * CG, y = i / W;
+            half8 m = R[it];
 #pragma unroll
             for (int d = 1; d <= 2; ++d) {
-                if (y - d >= 0) m = hmax8(m, R[i - d * W]);
-                if (y + d < H) m = hmax8(m, R[i + d * W]);
+                if (y - d >= 0) m = hmax8(m, R[it - d * W * CG]);
+                if (y + d < H) m = hmax8(m, R[it + d * W * CG]);
             }
-            A[i] = m;
-            *reinterpret_cast<half8*>(base + (size_t)i * ld + pass * C) = m;
+            A[it] = m;
+            *reinterpret_cast<half8*>(base + (size_t)i * ld + pass * C + ck * 8) = m;
         }
         __syncthreads();
     }
@@ -232,7 +238,12 @@ int launch_sppf_pool(half_t* buf, int ld, int B, int H, int W, int C, hipStream_
     const long long total = (long long)B * H * W * (C / 8);
     if (total <= 0) BSY_FAIL(BSY_ERR_ARG, "sppf_pool: empty");
     if ((size_t)H * W * 32 <= 64 * 1024) {  // both LDS maps fit: the usual 20x20 .. 40x40 P5 maps
-        hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(C / 8, B), dim3(256), (size_t)H * W * 32, s, buf, ld, H, W, C);
+        // chunks per workgroup: the largest divisor of C / 8 (at most 8) whose two maps fit 64 KiB and that still leaves two
+        // workgroups per CU (a workgroup walks its map serially: at 8 images, 4 chunks each took 28 us against 11 us for 1)
+        int cg = 1;
+        for (int k = 8; k > 1; --k)
+            if ((C / 8) % k == 0 && (size_t)H * W * 32 * k <= 64 * 1024 && (long long)(C / 8 / k) * B >= 512) { cg = k; break; }
+        hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(C / 8 / cg, B), dim3(256), (size_t)H * W * 32 * cg, s, buf, ld, H, W, C, cg);
         HIP_TRY(hipGetLastError());
         return BSY_OK;
     }
