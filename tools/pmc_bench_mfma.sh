@@ -4,13 +4,16 @@
 # (counters only with --kernel-trace, their own run).  SQ_VALU_MFMA_BUSY_CYCLES = sum over the SIMDs of the cycles their
 # matrix pipe is busy (32 per v_mfma_f32_32x32x16_f16, MI355X_MICROARCH.md); GRBM_GUI_ACTIVE = sum over the 8 XCDs of the
 # cycles the dispatch is active  ->  utilisation = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs).
-# usage: tools/pmc_bench_mfma.sh <conv launches per forward>   -> gpurun_out/mfma_util.txt
+# usage: tools/pmc_bench_mfma.sh [conv launches per forward]   -> gpurun_out/mfma_util.txt   (the launch count is read from the bench
+# line of the profiled run, roofline.launches_per_step, unless given)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_bench_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "rc=$?"
-python3 - $R ${1:-68} <<'PY' | tee $R/gpurun_out/mfma_util.txt
-import csv, glob, os, sys
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_bench_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_bench_mfma.json 2> /dev/null; echo "rc=$?"
+python3 - $R ${1:-0} <<'PY' | tee $R/gpurun_out/mfma_util.txt
+import csv, glob, json, os, sys
 R, NCONV = sys.argv[1], int(sys.argv[2])
+if NCONV <= 0:
+    NCONV = int(json.loads(open(f"{R}/gpurun_out/pmc_bench_mfma.json").read().strip().splitlines()[-1])["roofline"]["launches_per_step"])
 f = sorted(glob.glob(f"{R}/gpurun_out/pmc_bench_mfma/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))
 CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")

@@ -2,17 +2,20 @@
 # HBM traffic of one bench step per kernel family: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes
 # (MI355X_MICROARCH.md "HBM": FETCH_SIZE reports exactly half of a wide coalesced read stream on gfx950 -> doubled;
 # WRITE_SIZE is exact; both in KiB).  Writes gpurun_out/traffic.json; copy it to profiles/ to have bench.py report it.
-# usage: tools/pmc_bench_traffic.sh <family launches per forward = roofline.launches_per_step>   ("conv_mfma_kernel" below = the whole
-# dense-conv family incl. the fused conv kernels)
+# usage: tools/pmc_bench_traffic.sh [family launches per forward]   ("conv_mfma_kernel" below = the whole dense-conv family incl. the
+# fused conv kernels).  The launch count that windows "the last forward" is read from the bench line of the profiled run itself
+# (roofline.launches_per_step); the optional argument only overrides it.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench_$c -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "$c rc=$?"
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench_$c -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_bench_$c.json 2> /dev/null; echo "$c rc=$?"
 done
-python3 - $R ${1:-76} <<'PY'
+python3 - $R ${1:-0} <<'PY'
 import csv, glob, json, os, sys
 R = sys.argv[1]
-NCONV = int(sys.argv[2])  # conv launches per forward = roofline.launches_per_step of bench.py
+NCONV = int(sys.argv[2])  # 0: take roofline.launches_per_step of the profiled bench run
+if NCONV <= 0:
+    NCONV = int(json.loads(open(f"{R}/gpurun_out/pmc_bench_FETCH_SIZE.json").read().strip().splitlines()[-1])["roofline"]["launches_per_step"])
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = sorted(glob.glob(f"{R}/gpurun_out/pmc_bench_{c}/*/*counter_collection.csv"), key=os.path.getmtime)[-1]

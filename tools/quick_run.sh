@@ -1,6 +1,6 @@
 #!/bin/bash
 # one gpurun call: GPU tests, then (unless the tests were killed) per-op timing, the bench line and a 2-rank gloo rehearsal
-# usage: tools/r2_run.sh <tag> [pytest -k expression]
+# usage: tools/quick_run.sh <tag> [pytest -k expression]
 tag=$1; kexpr=$2
 mkdir -p gpurun_out
 if [ -n "$kexpr" ]; then
