@@ -907,6 +907,217 @@ static int launch_persist(const ConvK& k, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Weights-resident streaming 1x1 kernel (configuration tiles 14 / 15; round 3) for the HBM-bound 1x1 layers at 160^2 / 80^2.
+//
+// What held those layers at 3.3-4.6 TB/s (a device copy runs at 5.4): every 128-pixel tile re-staged the layer's whole weight
+// matrix from L2 into LDS (model.4.cv2: 49 KB of pixels + 98 KB of weights per tile pair = 14 B/clk/CU, the LDS-DMA rate of a CU),
+// and load / MFMA / store phases of a tile only overlap across workgroups.  Here a persistent workgroup (4 waves, two per CU)
+// works on ONE cout tile for the whole launch and keeps its weights -- every wave the A fragments of its 32 NT couts over all of K
+// -- in REGISTERS; only pixels stream through LDS (one continuous DMA ring across tile boundaries, STAGES K-steps deep), so the
+// L2 -> LDS traffic is the input itself.  Workgroups b and b + 8 (one XCD under round-robin dispatch) take the same pixel tiles and
+// different cout tiles: the second reads the pixels from that XCD's L2.
+// A tile's results leave through an LDS tile as 16-byte stores issued by the same waves; they sit in the vmcnt queue BEHIND the DMA
+// of the next steps and are accounted for in the counted waits (a wait for K-step g sees the stores of the previous tile as younger
+// operations during the first STAGES - 1 steps of a tile).
+// Same K order and epilogue arithmetic as the other 1x1 kernels: the same bits.
+// Restrictions (conv_cfg_valid): as the persistent kernel, and K NT <= 512 (A fragments: at most 128 VGPRs).
+// ---------------------------------------------------------------------------------------------------------------------
+// NFR = A fragments held per wave (K / 16 x NT <= NFR): 32 = 128 VGPRs
+template <int NT, int STAGES, int NFR>
+__global__ __launch_bounds__(256, 2) void conv1x1_wres_kernel(const ConvK p) {
+    constexpr int BK = 32, MT = 2, TM = 128, TN = 64 * NT;
+    constexpr int CPR = 4, RPI = 16;
+    constexpr int PIW = TM / (RPI * 4);  // 2 pixel DMA wave-instructions per wave per K-step
+    constexpr int STAGE = TM * BK;
+    constexpr int LDT = TN + 8, OT = TM * LDT;
+    constexpr int CPRW = TN / 8, NST = TM * CPRW / 256;  // 16-byte output pieces per thread per tile
+    __shared__ __attribute__((aligned(16))) half_t smem[STAGES * STAGE + OT + 2 * TN];
+    half_t* otile = smem + STAGES * STAGE;
+    float* sbias = reinterpret_cast<float*>(otile + OT);  // this cout tile's biases: no ordinary VMEM load inside the tile loop
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int nk = p.Kpad / BK;
+    // workgroup -> (cout tile, walk over the pixel tiles): blocks b, b + 8, .. b + 8 (ntn - 1) share their pixel tiles
+    // (host: gridDim.x is a multiple of 8 ntn)
+    constexpr int X = 8;
+    const int x = blockIdx.x % X, q = blockIdx.x / X;
+    const int ct = q % p.ntn, slot = q / p.ntn;                   // cout tile, walker index on this XCD
+    const int walkers = (gridDim.x / X) / p.ntn;
+    const int per = p.ntm / X, rem = p.ntm % X;
+    const int pt0 = x * per + (x < rem ? x : rem), ptn = per + (x < rem ? 1 : 0);  // this XCD's range of pixel tiles
+    const int my_tiles = slot < ptn ? (ptn - slot + walkers - 1) / walkers : 0;
+    const int n0 = ct * TN;
+
+    // A fragments of this wave's couts for the whole of K (rows past Cout: the packed matrix is padded to 128 rows with zeros)
+    half8 afr[NFR];
+    const int nfr = nk * 2 * NT;  // (k sub-step of 16, cout tile a)
+#pragma unroll
+    for (int i = 0; i < NFR; ++i) {
+        afr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < nfr) {
+            const int ks = i / NT, a = i - ks * NT;
+            afr[i] = *reinterpret_cast<const half8*>(p.wgt + (size_t)(n0 + (wn * NT + a) * 32 + lrow) * p.Kpad + 16 * ks + 8 * lh);
+        }
+    }
+    if (tid < TN) sbias[tid] = p.bias[n0 + tid];  // bias is padded to CoutPad (a multiple of 128)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights and bias are in: from here on the vector-memory queue holds DMA and stores only
+    __syncthreads();
+
+    const int rsub = lane / CPR, slot4 = lane % CPR;
+    const int kc = slot4 ^ ((rsub >> 2) & 3);
+    const bsy_rsrc_t rs0 = make_rsrc(p.src0, p.span0), rs1 = make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? p.span1 : 0u);
+    const int ohw = p.OH * p.OW;
+    unsigned off0[PIW], off1[PIW];
+    bool rv[PIW];
+    int it = 0, ikt = 0, s_cb = 0;
+    auto setup_tile = [&](int tcount) {
+        const int m0 = (pt0 + slot + tcount * walkers) * TM;
+#pragma unroll
+        for (int i = 0; i < PIW; ++i) {
+            const int m = m0 + (wave * PIW + i) * RPI + rsub;
+            rv[i] = m < p.M;
+            const int mm = rv[i] ? m : 0;
+            if (!(p.up0 | p.up1)) {
+                off0[i] = (unsigned)mm * (unsigned)p.ld0;
+                off1[i] = (unsigned)mm * (unsigned)p.ld1;
+            } else {
+                const int n = mm / ohw, r2 = mm - n * ohw, oh = r2 / p.OW, ow = r2 - oh * p.OW;
+                const int H0 = p.H >> p.up0, W0 = p.W >> p.up0, H1 = p.H >> p.up1, W1 = p.W >> p.up1;
+                off0[i] = (unsigned)((n * H0 + (oh >> p.up0)) * W0 + (ow >> p.up0)) * (unsigned)p.ld0;
+                off1[i] = (unsigned)((n * H1 + (oh >> p.up1)) * W1 + (ow >> p.up1)) * (unsigned)p.ld1;
+            }
+        }
+        s_cb = 0;
+    };
+    auto issue_step = [&](int stage) {
+        if (ikt == 0) setup_tile(it);
+        half_t* sP = smem + stage * STAGE;
+        const bool s1 = s_cb >= p.C0;
+        const unsigned sc = 2u * (unsigned)(s1 ? s_cb - p.C0 : s_cb) + 16u * (unsigned)kc;
+#pragma unroll
+        for (int i = 0; i < PIW; ++i) {
+            const unsigned o = rv[i] ? 2u * (s1 ? off1[i] : off0[i]) + sc : BSY_OOB;
+            if (s1) dma16_buf(rs1, o, 0u, sP + (wave * PIW + i) * RPI * BK);
+            else dma16_buf(rs0, o, 0u, sP + (wave * PIW + i) * RPI * BK);
+        }
+        s_cb += BK;
+        if (++ikt == nk) { ikt = 0; ++it; }
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int total = my_tiles * nk;
+    int ip = 0;
+    for (; ip < STAGES - 1 && ip < total; ++ip) issue_step(ip % STAGES);
+    int ckt = 0, ct_done = 0;
+    half_t* dst = reinterpret_cast<half_t*>(p.dst);
+    for (int cp = 0; cp < total; ++cp) {
+        // wait for K-step cp.  Younger in this thread's vector-memory queue: the DMA of the next min(STAGES - 2, remaining) steps (PIW
+        // each) and, while cp is one of the first STAGES - 1 steps of a tile after the first, the NST stores of the previous tile
+        // (they were issued after the DMA of step cp, which went out STAGES - 1 steps ago)
+        const int later = min(STAGES - 2, total - 1 - cp);
+        const bool st_young = ct_done > 0 && ckt < STAGES - 1;
+        if (later >= STAGES - 2) {
+            if (st_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIW + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (ip < total) { issue_step(ip % STAGES); ++ip; }
+        const half_t* sP = smem + (cp % STAGES) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 2 * ks + lh;
+            half8 bfr[MT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int row = (wm * MT + b) * 32 + lrow;
+                bfr[b] = *reinterpret_cast<const half8*>(sP + row * BK + ((chunk ^ ((row >> 2) & 3)) << 3));
+            }
+            // the A fragment index depends on the K-step: a uniform switch over compile-time register indices
+#pragma unroll
+            for (int kk = 0; kk < NFR / (2 * NT); ++kk)
+                if (kk == ckt) {
+#pragma unroll
+                    for (int a = 0; a < NT; ++a)
+#pragma unroll
+                        for (int b = 0; b < MT; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[(2 * kk + ks) * NT + a], bfr[b], acc[a][b], 0, 0, 0);
+                }
+        }
+        if (++ckt == nk) {
+            ckt = 0;
+            const int m0 = (pt0 + slot + ct_done * walkers) * TM;
+            // bias + SiLU -> fp16 tile in LDS (the previous tile's stores have read it: their LDS reads completed before they were issued,
+            // and every wave passed at least one barrier since)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int prow = (wm * MT + b) * 32 + lrow;
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = (wn * NT + a) * 32 + 8 * g + 4 * lh;
+                        half4 o;
+                        f32x4 tv = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]},
+                                          *reinterpret_cast<const f32x4*>(sbias + c));
+                        if (p.act) tv = silu4_f(tv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = (half_t)tv[e];
+                            acc[a][b][4 * g + e] = 0.f;
+                        }
+                        *reinterpret_cast<half4*>(otile + prow * LDT + c) = o;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // (never __syncthreads(): it would drain the DMA ring)
+            half8 v[NST];
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int id = tid + 256 * i;
+                v[i] = *reinterpret_cast<const half8*>(otile + (id / CPRW) * LDT + (id % CPRW) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int id = tid + 256 * i;
+                const int m = m0 + id / CPRW, c = n0 + (id % CPRW) * 8;
+                // The counted waits assume NST store instructions per wave and tile.  A store whose predicate fails in SOME lanes is
+                // still one instruction; one that fails in all lanes of a wave is skipped -- only possible in a tile that reaches past M,
+                // which is the last tile of its walker (no wait follows it), since a cout tile always starts below Cout.
+                if (m < p.M && c < p.Cout) *reinterpret_cast<half8*>(dst + (size_t)m * p.ldd + c) = v[i];
+            }
+            ++ct_done;
+        }
+    }
+}
+
+template <int NT, int STAGES, int NFR>
+static int launch_wres(const ConvK& k, hipStream_t s) {
+    constexpr int TM = 128, TN = 64 * NT;
+    ConvK p = k;
+    p.ntn = ceil_div(k.Cout, TN);
+    p.ntm = ceil_div(k.M, TM);
+    // two workgroups per CU; a multiple of 8 ntn so that every XCD runs the same number of walkers for every cout tile
+    int grid = 512 / (8 * p.ntn) * (8 * p.ntn);
+    if (grid < 8 * p.ntn) grid = 8 * p.ntn;
+    const int walkers_per_xcd = grid / 8 / p.ntn;
+    if (walkers_per_xcd > ceil_div(p.ntm, 8)) grid = 8 * p.ntn * (ceil_div(p.ntm, 8) > 0 ? ceil_div(p.ntm, 8) : 1);
+    hipLaunchKernelGGL((conv1x1_wres_kernel<NT, STAGES, NFR>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Patch-based 3x3 stride-1 kernel (configuration tiles 10 / 11).
 //
 // The implicit-GEMM kernel above stages every input pixel NINE times (once per tap) through the vector-memory path and
@@ -1452,7 +1663,8 @@ int conv_korder(const ConvArgs& a) {
 //            7 = 256 x 256 (8 waves, wave tile 64 x 128: half the L2->LDS bytes per FLOP of 128 x 128);
 //            8 = 128 x 128, 9 = 128 x 64 persistent 1x1 kernel (4 compute + 4 store waves, tiles walked per workgroup);
 //            10 = 8x16 px x 128 couts (2-stage weight ring), 11 = 8x16 px x 64 couts (variant 1: 3 stages, 2: 2 stages, 3: 4 stages):
-//            patch-based 3x3 stride-1 kernel; 12 / 13 = the same with 6x20-pixel tiles (maps whose width is a multiple of 20)
+//            patch-based 3x3 stride-1 kernel; 12 / 13 = the same with 6x20-pixel tiles (maps whose width is a multiple of 20);
+//            14 / 15 = weights-resident streaming 1x1 kernel, 128 px x 128 / 64 couts (variant 1: 4-stage pixel ring, 2: 3 stages)
 //   variant: 0 = generic (per-lane K bookkeeping, flat DMA, BK 32, 3 stages), 1 = aligned BK 32 / 3 stages,
 //            2 = aligned BK 32 / 2 stages, 3 = aligned BK 64 / 2 stages; + 4 on the implicit-GEMM tiles of a layer whose K walk is
 //            chunk-major (conv_korder != 0): part of the id so that ids recorded before round 3 for the packed order on such a
@@ -1460,7 +1672,7 @@ int conv_korder(const ConvArgs& a) {
 bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     const int Cin = a.C0 + a.C1, tile = cfg >> 4, var = cfg & 3, kbit = (cfg >> 2) & 3;
     const int ko = conv_korder(a);
-    if (cfg < 0 || tile > 13 || kbit > 1) return false;
+    if (cfg < 0 || tile > 15 || kbit > 1) return false;
     // the id's chunk-major bit must say what the layer's shape says (implicit-GEMM tiles; the other kernels have one order each)
     if (tile < 8 && kbit != (ko ? 1 : 0)) return false;
     if (tile >= 8 && kbit) return false;
@@ -1473,6 +1685,12 @@ bool conv_cfg_valid(const ConvArgs& a, int cfg) {
         return a.epi == 3 && a.Cout == 64 && !a.res && conv_cfg_valid(b, cfg);
     }
     if (a.epi && tile >= 8) return false;           // fused decoder: implicit-GEMM kernel only
+    if (tile >= 14) {  // weights-resident streaming 1x1 kernel (14: 128-cout tiles, 15: 64-cout tiles; variant 1: 4-stage pixel ring, 2: 3 stages)
+        const int K = Cin, nt = tile == 14 ? 2 : 1, stages = var == 1 ? 4 : 3;
+        return a.ksize == 1 && a.stride == 1 && (var == 1 || var == 2) && !(Cin & 31) && !(a.C0 & 31) && !a.out_f32 && !a.res && !(a.Cout & 7) &&
+               !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 && nt * (K / 16) <= 32 && K / 32 >= stages - 1 &&
+               (tile == 14 ? a.Cout > 64 : true);
+    }
     if (a.epi == 3 && tile != 1) return false;      // DFL needs all 64 box couts in one wave: the 256 x 64 tile (4 x 1 waves, NT 2)
     if (tile >= 12) {  // 6x20-pixel patch tiles
         ConvArgs b = a;
@@ -1537,6 +1755,7 @@ int conv_candidates(const ConvArgs& a, int* out, int max_out) {
         if (t >= 8 && (M < 65536 || getenv("BSY_NO_PERSIST"))) continue;                      // persistent tiles need several tiles per workgroup
         for (int v = 1; v <= 3; ++v) add(t, v | (t < 8 ? km : 0));
     }
+    if (a.ksize == 1 && M >= 65536 && !getenv("BSY_NO_WRES")) { add(14, 1); add(14, 2); add(15, 1); add(15, 2); }  // HBM-bound 1x1 layers
     if (a.H >= 16 && a.W >= 16 && patch_ok) {  // 3x3 s1 patch kernel
         add(10, 1); add(11, 1); add(11, 2); add(11, 3);
         if (t20) { add(12, 1); add(13, 1); add(13, 2); add(13, 3); }
@@ -1620,6 +1839,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         if (k.tail_wgt && tile == 11 && var == 1) return launch_patch<1, 3, 2, 16, true>(k, s); \
         if (k.tail_wgt && tile == 11 && var == 3) return launch_patch<1, 4, 2, 16, true>(k, s); \
         if (k.tail_wgt) return launch_patch<1, 2, 2, 16, true>(k, s);                     \
+        if (tile >= 14) {                                                                 \
+            const int fr = (tile == 14 ? 2 : 1) * (Cin / 16);                             \
+            if (tile == 14 && var == 1) { if (fr <= 16) return launch_wres<2, 4, 16>(k, s); if (fr <= 24) return launch_wres<2, 4, 24>(k, s); return launch_wres<2, 4, 32>(k, s); } \
+            if (tile == 14) { if (fr <= 16) return launch_wres<2, 3, 16>(k, s); if (fr <= 24) return launch_wres<2, 3, 24>(k, s); return launch_wres<2, 3, 32>(k, s); } \
+            if (var == 1) { if (fr <= 16) return launch_wres<1, 4, 16>(k, s); return launch_wres<1, 4, 32>(k, s); } \
+            if (fr <= 16) return launch_wres<1, 3, 16>(k, s);                             \
+            return launch_wres<1, 3, 32>(k, s);                                           \
+        }                                                                                 \
         if (tile == 12) return launch_patch<2, 2, 2, 20>(k, s);                           \
         if (tile == 13 && var == 1) return launch_patch<1, 3, 2, 20>(k, s);               \
         if (tile == 13 && var == 3) return launch_patch<1, 4, 2, 20>(k, s);               \

@@ -241,13 +241,17 @@ PERSIST_CASES = [
     (70, 40, 40, 64, 128, 0x81), (70, 40, 40, 64, 128, 0x82), (9, 80, 80, 128, 128, 0x83),
     (70, 40, 40, 96, 64, 0x91), (33, 37, 41, 32, 72, 0x92), (9, 80, 80, 192, 64, 0x93),
     (17, 33, 47, 96, 512, 0x82),                                                             # 4 cout tiles per pixel tile
+    # tiles 14 / 15 = weights-resident streaming 1x1 kernel (128 x 128 / 128 x 64 tiles; variant 1: 4-stage pixel ring, 2: 3 stages)
+    (70, 40, 40, 128, 128, 0xe1), (70, 40, 40, 192, 256, 0xe2), (33, 37, 41, 96, 72, 0xe1), (9, 80, 80, 256, 256, 0xe1),
+    (70, 40, 40, 512, 128, 0xf1), (33, 37, 41, 128, 72, 0xf2), (3, 7, 5, 128, 64, 0xf1), (300, 16, 16, 160, 136, 0xe2),
 ]
 
 
 @pytest.mark.parametrize("case", PERSIST_CASES)
 def test_conv_persistent_1x1_matches_one_tile_per_workgroup(case, monkeypatch):
-    """conv1x1_persist_kernel (tiles walked by persistent workgroups, dedicated store waves) against the one-tile-per-workgroup
-    implicit-GEMM kernel -- same K walk, so bit for bit -- and the fp32 reference; more tiles than workgroups, ragged last tile."""
+    """conv1x1_persist_kernel (tiles walked by persistent workgroups, dedicated store waves) and conv1x1_wres_kernel (weights in
+    registers, pixels streamed, stores counted in the DMA waits) against the one-tile-per-workgroup implicit-GEMM kernel -- same K
+    walk, so bit for bit -- and the fp32 reference; more tiles than workgroups, ragged last tiles, fewer tiles than XCDs."""
     B, H, W, cin, cout, cfg = case
     g = torch.Generator().manual_seed(cfg * 7 + cin)
     x = h16(torch.randn(B, cin, H, W, generator=g))
@@ -297,7 +301,7 @@ def test_conv_every_configuration_of_a_layer_is_bit_identical(case, monkeypatch)
     base = O.conv2d_nhwc(xd, wp, bp, cout, k, s, True)  # the heuristic configuration
     np.testing.assert_allclose(nchw(base.float().cpu()).numpy(), y.numpy(), rtol=2e-3, atol=2e-3)
     accepted = []
-    for tile in range(14):
+    for tile in range(16):
         for var in range(8):
             cfg = (tile << 4) | var
             monkeypatch.setenv("BSY_CONV_CFG", str(cfg))
