@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i)
             if (tid + 256 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
-        __syncthreads();  // input patch visible; every wave is done with the previous tile's LDS
+        lds_barrier();  // input patch visible; every wave is done with the previous tile's LDS
         if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
         // ---- conv 1: 180 hidden pixels = 6 MFMA pixel tiles over 4 waves ----------------------------------------------
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
                 }
             }
         }
-        __syncthreads();  // hidden patch complete
+        lds_barrier();  // hidden patch complete
 
         // ---- conv 2 + residual: one MFMA pixel tile (2 rows x 16) per wave ---------------------------------------------
         {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
                 *reinterpret_cast<half4*>(sout + prow * LDO + 8 * g + 4 * lh) = o;
             }
         }
-        __syncthreads();  // output tile complete
+        lds_barrier();  // output tile complete
 
         constexpr int CPRW = C / 8;
 #pragma unroll
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
         for (int i = 0; i < NLOAD; ++i)
             if (tid + 512 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
         half_t* ob = p.dst + ((long long)(n * p.H + oy0) * p.W + ox0) * p.ldd;
-        __syncthreads();  // input patch visible (first iteration: the weights too); the previous tile's output has been read
+        lds_barrier();  // input patch visible (first iteration: the weights too); the previous tile's output has been read
         if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
         // ---- conv 1: 180 hidden pixels = 6 MFMA pixel tiles on waves 0-5 -----------------------------------------------------
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
                 }
             }
         }
-        __syncthreads();  // hidden patch complete
+        lds_barrier();  // hidden patch complete
 
         // ---- conv 2 + shortcut: MFMA pixel tile pt (2 rows x 16), cout tile ct (32 channels) per wave ----------------------------
         {
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
                 *reinterpret_cast<half4*>(obase + 8 * g) = o;
             }
         }
-        __syncthreads();  // output tile complete
+        lds_barrier();  // output tile complete
 #pragma unroll
         for (int j = 0; j < NST; ++j)
             if (oy0 + st_y[j] < p.H && ox0 + st_x[j] < p.W)

@@ -6,9 +6,9 @@
 // Unfused (round 1: cv1 conv + fused Bottleneck + cv2 conv) this block moved 1.36 GB through HBM per batch of 64 for
 // 0.21 GB in and 0.42 GB out and took 0.33 ms of a 3.3 ms forward: the [y0 | y1 | y2] concat buffer is written by three
 // launches and read back by two.  Here a workgroup (4 waves, persistent, two per CU) owns a 4 x 16 output tile:
-//   * the 8 x 20 input patch (halo 2 for the two 3x3 convs; zeros outside the image) is fetched into registers one tile
-//     ahead and parked in LDS (padded entries: every MFMA B fragment is one ds_read_b128 at a compile-time offset from a
-//     per-lane base, conflict-free);
+//   * the 8 x 20 input patch (halo 2 for the two 3x3 convs; zeros outside the image) is fetched one tile ahead straight INTO
+//     THE MFMA B FRAGMENTS of cv1 (round 3: lane = patch pixel, 8 consecutive channels per 16-byte load -- exactly the fragment
+//     layout, so x never passes through LDS; the 23 KiB it used to park there were what held the kernel at two workgroups per CU);
 //   * S1  cv1 on all 160 patch pixels -> y1 patch (zeros outside the MAP: the bottleneck's zero padding applies to y1, not
 //         to x) and the interior y0 tile, both in LDS;
 //   * S2  m.cv1 3x3 on the 6 x 18 hidden patch (zeros outside the map), S3  m.cv2 3x3 + shortcut -> y2 tile: the
@@ -39,30 +39,32 @@ struct C3k2K {
     unsigned magic_x, magic_y;
 };
 
-// 4 waves, TWO workgroups per CU (71 KiB of LDS each): the block is bound by its SiLU evaluations (38 k per 128 output pixels,
-// ~34 VALU cycles per 64 of them) -- two independent workgroups drift apart, so one's MFMA / LDS / memory phases run under the
-// other's VALU phases; a single 8-wave workgroup (first version: 8 x 16 tile, 131 KiB) kept both waves of a SIMD in the same
-// phase and ran at the unfused speed (0.31 ms vs 0.33 ms).
+// 4 waves, THREE workgroups per CU (48 KiB of LDS each, round 3; two of 71 KiB before).  The block's SiLU evaluations (38 k per 128
+// output pixels) make it look VALU-bound on paper, but the SQ counters of the two-workgroup form say its waves WAIT: 50 % of the wave
+// cycles in s_waitcnt / s_barrier, 26 % issuing VALU, i.e. a SIMD's VALU busy half of the time (profiles/r03_pmc_fused_kernels.txt) --
+// the five phases of a tile are separated by workgroup barriers and only other workgroups fill the gaps.  A third resident
+// workgroup per CU is what the LDS diet buys: x patch no longer parked (23 KiB), the output tile aliases the dead [y1 | y0] tiles.
+// (A single 8-wave workgroup -- first version, 8 x 16 tile, 131 KiB -- kept both waves of a SIMD in the same phase and ran at the
+// unfused speed, 0.31 ms vs 0.33 ms.)
 template <int CIN, int C, int C2>
-__global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
+__global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
     constexpr int CH = C / 2;
-    constexpr int XS = CIN + 8, YS = C + 8, MS = CH + 8, OS = C2 + 8;          // padded LDS entries (halves)
-    constexpr int W1S = CIN + 8, WBS = 9 * CH + 8;                             // padded weight rows (halves)
+    constexpr int YS = C + 8, MS = CH + 8, OS = C2 + 8;                       // padded LDS entries (halves)
+    constexpr int WAS = 9 * C + 8, WBS = 9 * CH + 8;                           // padded weight rows (halves)
     constexpr int KS1 = CIN / 16, KSA = 9 * C / 16, KSB = 9 * CH / 16, KSEG = C / 16;  // MFMA K-steps
-    constexpr int XCH = CIN / 8, NITEM = CK_NX * XCH, NLOAD = (NITEM + 255) / 256;
     static_assert(C == 32 && CH == 16 && CIN % 16 == 0 && C2 == 128 && CK_NX == 160 && CK_NPX == 64, "instantiated for the c = 32 C3k2 block");
-    constexpr int SX = CK_NX * XS > CK_NPX * OS ? CK_NX * XS : CK_NPX * OS;    // x patch, later the output tile
     constexpr int SY1 = CK_NX * YS, SY0 = CK_NPX * YS, SM = CK_NM * MS, SY2 = CK_NPX * YS;
-    constexpr int SW1 = 2 * C * W1S, SWB = C * WBS;
-    __shared__ __attribute__((aligned(16))) half_t lds[SX + SY1 + SY0 + SM + SY2 + SW1 + SWB + 2 * (2 * C + CH + C + C2)];
-    half_t* sx = lds;
-    half_t* sout = lds;  // aliases sx: x is dead after S1, the output tile is written in S4
-    half_t* sy1 = sx + SX;
+    constexpr int SOUT = CK_NPX * OS;  // the output tile aliases [y1 patch | y0 tile], dead once cv2's MFMAs have read them (barrier D')
+    static_assert(SOUT <= SY1 + SY0, "output tile must fit the y1 + y0 tiles it aliases");
+    constexpr int SWA = CH * WAS, SWB = C * WBS;
+    __shared__ __attribute__((aligned(16))) half_t lds[SY1 + SY0 + SM + SY2 + SWA + SWB + 2 * (2 * C + CH + C + C2)];
+    half_t* sy1 = lds;
     half_t* sy0 = sy1 + SY1;
+    half_t* sout = lds;
     half_t* smid = sy0 + SY0;
     half_t* sy2 = smid + SM;
-    half_t* sw1 = sy2 + SY2;
-    half_t* swb = sw1 + SW1;
+    half_t* swa = sy2 + SY2;
+    half_t* swb = swa + SWA;
     float* sb1 = reinterpret_cast<float*>(swb + SWB);
     float* sba = sb1 + 2 * C;
     float* sbb = sba + CH;
@@ -76,38 +78,28 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
     if (tid < CH) sba[tid] = p.ba[tid];
     if (tid < C) sbb[tid] = p.bb[tid];
     for (int i = tid; i < C2; i += 256) sb4[i] = p.b4[i];
-    // register-resident MFMA A fragments for the whole launch: m.cv1 (rows >= CH of the packed matrix are zero) and THIS wave's
-    // 32 output channels of cv2 (S4 splits cv2 by cout tile: wave = cout tile)
-    half8 a1[KSA], a4[3 * KSEG];
+    // register-resident MFMA A fragments for the whole launch: cv1 (the y1 rows every wave multiplies with, the y0 rows of waves 1
+    // and 2's second job) and THIS wave's 32 output channels of cv2 (S4 splits cv2 by cout tile: wave = cout tile).  m.cv1's and
+    // m.cv2's weights live in LDS (m.cv1: its CH = 16 real rows; lanes of the zero rows 16..31 read row lrow - 16 instead -- what
+    // they produce are accumulator rows no epilogue reads).
+    half8 w1y1[KS1], w1y0[KS1], a4[3 * KSEG];
 #pragma unroll
-    for (int ks = 0; ks < KSA; ++ks) a1[ks] = *reinterpret_cast<const half8*>(p.wa + (size_t)lrow * p.Ka + 16 * ks + 8 * lh);
+    for (int ks = 0; ks < KS1; ++ks) {
+        w1y1[ks] = *reinterpret_cast<const half8*>(p.w1 + (size_t)(C + lrow) * p.K1 + 16 * ks + 8 * lh);
+        w1y0[ks] = *reinterpret_cast<const half8*>(p.w1 + (size_t)lrow * p.K1 + 16 * ks + 8 * lh);
+    }
 #pragma unroll
     for (int ks = 0; ks < 3 * KSEG; ++ks) a4[ks] = *reinterpret_cast<const half8*>(p.w4 + (size_t)(32 * wave + lrow) * p.K4 + 16 * ks + 8 * lh);
-    for (int i = tid; i < 2 * C * (CIN / 8); i += 256) {
-        const int row = i / (CIN / 8), ch = i - row * (CIN / 8);
-        *reinterpret_cast<half8*>(sw1 + row * W1S + ch * 8) = *reinterpret_cast<const half8*>(p.w1 + (size_t)row * p.K1 + ch * 8);
+    for (int i = tid; i < CH * (9 * C / 8); i += 256) {
+        const int row = i / (9 * C / 8), ch = i - row * (9 * C / 8);
+        *reinterpret_cast<half8*>(swa + row * WAS + ch * 8) = *reinterpret_cast<const half8*>(p.wa + (size_t)row * p.Ka + ch * 8);
     }
     for (int i = tid; i < C * (9 * CH / 8); i += 256) {
         const int row = i / (9 * CH / 8), ch = i - row * (9 * CH / 8);
         *reinterpret_cast<half8*>(swb + row * WBS + ch * 8) = *reinterpret_cast<const half8*>(p.wb + (size_t)row * p.Kb + ch * 8);
     }
 
-    // Tile-independent lane tables (the block is bound by VALU issue: nothing that depends only on the lane is recomputed per
-    // tile).  Prefetch item i of this thread = 16-byte chunk ch of patch entry (r, c): LDS offset, element offset from the
-    // patch origin pixel (a uniform per-tile base pointer is added: `saddr + 32-bit voffset` addressing), and (r, c) for the
-    // bounds test.
-    int it_off[NLOAD], it_r[NLOAD], it_c[NLOAD];
-    unsigned it_rel[NLOAD];
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-        const int idx = tid + 256 * i;
-        const int e = idx / XCH, ch = idx - e * XCH;
-        const int r = e / CK_XC, c = e - r * CK_XC;
-        it_r[i] = idx < NITEM ? r : 0x40000000;  // items past the patch: never in bounds
-        it_c[i] = c;
-        it_off[i] = e * XS + ch * 8;
-        it_rel[i] = (unsigned)((r * p.W + c) * p.lds + ch * 8);
-    }
+    // Tile-independent lane constants: nothing that depends only on the lane is recomputed per tile.
     auto tile_origin = [&](int tile, int& n, int& oy0, int& ox0) {
         const int r = (int)__umulhi((unsigned)tile, p.magic_x);
         const int tx = tile - r * p.tiles_x;
@@ -116,70 +108,56 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
         oy0 = ty * CK_TH;
         ox0 = tx * CK_TW;
     };
-    half8 pre[NLOAD];
+    // S1 jobs of this wave (compile-time job list per wave, lane-constant entries): job A = y1 on patch pixel tile `wave`;
+    // job B = y1 on pixel tile 4 (wave 0) or y0 on output pixel tile wave - 1 (waves 1, 2); wave 3 has no job B
+    const int lty = lrow >> 4, ltx = lrow & 15;
+    const int eA = 32 * wave + lrow, rA = eA / CK_XC, cA = eA - rA * CK_XC;
+    const bool b_y0 = wave == 1 || wave == 2;
+    const int eB = b_y0 ? (2 * (wave - 1) + lty + 2) * CK_XC + ltx + 2 : 128 + lrow, rB = eB / CK_XC, cB = eB - rB * CK_XC;
+    const unsigned relA = (unsigned)((rA * p.W + cA) * p.lds + 8 * lh), relB = (unsigned)((rB * p.W + cB) * p.lds + 8 * lh);
+    // x of the NEXT tile, already in cv1's B-fragment layout (lane = patch pixel, k-step ks = channels 16 ks + 8 lh ..): zeros outside the image
+    half8 xa[KS1], xb[KS1];
     int nn = 0, noy0 = 0, nox0 = 0;
     auto fetch = [&](int tile) {
         tile_origin(tile, nn, noy0, nox0);
         // patch origin pixel (oy0 - 2, ox0 - 2): may lie outside the image -- only a base for pointer arithmetic
         const half_t* tb = p.src + ((long long)(nn * p.H + noy0 - 2) * p.W + (nox0 - 2)) * p.lds;
+        const bool inA = (unsigned)(noy0 - 2 + rA) < (unsigned)p.H && (unsigned)(nox0 - 2 + cA) < (unsigned)p.W;
+        const bool inB = wave < 3 && (unsigned)(noy0 - 2 + rB) < (unsigned)p.H && (unsigned)(nox0 - 2 + cB) < (unsigned)p.W;
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            pre[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if ((unsigned)(noy0 - 2 + it_r[i]) < (unsigned)p.H && (unsigned)(nox0 - 2 + it_c[i]) < (unsigned)p.W)
-                pre[i] = *reinterpret_cast<const half8*>(tb + it_rel[i]);
+        for (int ks = 0; ks < KS1; ++ks) {
+            xa[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            xb[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (inA) xa[ks] = *reinterpret_cast<const half8*>(tb + relA + 16 * ks);
+            if (inB) xb[ks] = *reinterpret_cast<const half8*>(tb + relB + 16 * ks);
         }
     };
-    // output items of this thread: 16-byte piece cc of output pixel pr
-    constexpr int CPRW = C2 / 8, NST = CK_NPX * CPRW / 256;
-    int st_y[NST], st_x[NST], st_off[NST];
-    unsigned st_rel[NST];
-#pragma unroll
-    for (int j = 0; j < NST; ++j) {
-        const int id = tid + 256 * j;
-        const int pr = id / CPRW, cc = (id % CPRW) * 8;
-        st_y[j] = pr / CK_TW;
-        st_x[j] = pr % CK_TW;
-        st_off[j] = pr * OS + cc;
-        st_rel[j] = (unsigned)((st_y[j] * p.W + st_x[j]) * p.ldd + cc);
-    }
-    // S1 jobs of this wave (compile-time job list per wave, lane-constant entries): job A = y1 on patch pixel tile `wave`;
-    // job B = y1 on pixel tile 4 (wave 0) or y0 on output pixel tile wave - 1 (waves 1, 2)
-    const int lty = lrow >> 4, ltx = lrow & 15;
-    const int eA = 32 * wave + lrow, rA = eA / CK_XC, cA = eA - rA * CK_XC;
-    const bool b_y0 = wave == 1 || wave == 2;
-    const int eB = b_y0 ? (2 * (wave - 1) + lty + 2) * CK_XC + ltx + 2 : 128 + lrow, rB = eB / CK_XC, cB = eB - rB * CK_XC;
+    constexpr int CPRW = C2 / 8, NST = CK_NPX * CPRW / 256;  // output items of a thread: 16-byte piece cc of output pixel pr
     // S2: hidden pixel of this lane
     const int mm2 = wave * 32 + lrow, mc2 = mm2 < CK_NM ? mm2 : CK_NM - 1, r2 = mc2 / CK_MC, c2 = mc2 - r2 * CK_MC;
 
     const half_t* a2base = swb + lrow * WBS + 8 * lh;
+    const int a1off = (lrow & (CH - 1)) * WAS + 8 * lh;
 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the weight loads here, not inside the tile loop (bneck_fused.hip)
     const TileWalk tw = xcd_tile_walk(blockIdx.x, gridDim.x, p.ntiles);  // XCD-aware tile order (common.h)
     int tile = tw.tile;
     if (tile < tw.end) fetch(tile);
+    __syncthreads();  // weights and biases visible
     for (; tile < tw.end; tile += tw.step) {
         const int n = nn, oy0 = noy0, ox0 = nox0;
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i)
-            if (tid + 256 * i < NITEM) *reinterpret_cast<half8*>(sx + it_off[i]) = pre[i];
         half_t* ob = p.dst + ((long long)(n * p.H + oy0) * p.W + ox0) * p.ldd;  // output tile origin (uniform)
-        __syncthreads();  // (A) x patch visible (and, first iteration, the weights)
-        if (tile + tw.step < tw.end) fetch(tile + tw.step);
-
         // ---- S1: cv1 (1x1, CIN -> 2C).  Seven jobs of one MFMA tile (32 pixels x 32 channels) over four waves: y1 = channels
         //      C .. 2C-1 on the five pixel tiles of the patch (zero outside the MAP: the Bottleneck's convs pad y1, not x), y0 =
         //      channels 0 .. C-1 on the two pixel tiles of the tile's own pixels (only cv2 reads y0) --------------------------------
-        auto s1_job = [&](const bool is_y0, const int e, const int r, const int c, const int opix) {
+        auto s1_job = [&](const bool is_y0, const half8 (&wf)[KS1], const half8 (&xf)[KS1], const int e, const int r, const int c, const int opix) {
             // e = patch entry of this lane's pixel, (r, c) its patch coordinates; y0 jobs write output pixel opix
-            const half_t* xb = sx + e * XS + 8 * lh;
-            const half_t* ab = sw1 + ((is_y0 ? 0 : C) + lrow) * W1S + 8 * lh;
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(ab + 16 * ks), *reinterpret_cast<const half8*>(xb + 16 * ks),
-                                                             acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf[ks], acc, 0, 0, 0);
             const unsigned keep = (is_y0 || ((unsigned)(oy0 - 2 + r) < (unsigned)p.H && (unsigned)(ox0 - 2 + c) < (unsigned)p.W)) ? 0xffffffffu : 0u;
             half_t* d = is_y0 ? sy0 + opix * YS : sy1 + e * YS;
             const float* bb_ = sb1 + (is_y0 ? 0 : C);
@@ -195,15 +173,19 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
                 *reinterpret_cast<half4*>(d + 8 * g + 4 * lh) = o.h;
             }
         };
-        s1_job(false, eA, rA, cA, 0);
-        if (wave == 0) s1_job(false, eB, rB, cB, 0);
-        else if (wave < 3) s1_job(true, eB, rB, cB, 32 * (wave - 1) + lrow);
-        __syncthreads();  // (B) y1 patch + y0 tile complete
+        s1_job(false, w1y1, xa, eA, rA, cA, 0);
+        if (wave == 0) s1_job(false, w1y1, xb, eB, rB, cB, 0);
+        else if (wave < 3) s1_job(true, w1y0, xb, eB, rB, cB, 32 * (wave - 1) + lrow);
+        if (tile + tw.step < tw.end) fetch(tile + tw.step);  // x of the next tile: its registers are free now, its latency has S2..S4 to pass
+        lds_barrier();  // (B) y1 patch + y0 tile complete
 
         // ---- S2: m.cv1 3x3 (C -> CH) on the 6 x 18 hidden patch: MFMA pixel tile `wave` ------------------------------------------
         {
             const int mm = mm2, r = r2, c = c2;
             const half_t* yb = sy1 + (r * CK_XC + c) * YS + 8 * lh;
+            int ao = a1off;
+            asm volatile("" : "+v"(ao));  // per-tile opaque: keeps the 18 weight fragments in LDS (hoisted out of the tile loop they cost 72 VGPRs)
+            const half_t* a1base = swa + ao;
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -211,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
             for (int ks = 0; ks < KSA; ++ks) {
                 const int k0 = 16 * ks, tap = k0 / C, ch0 = (k0 % C) / 8;  // compile-time
                 const half8 bf = *reinterpret_cast<const half8*>(yb + ((tap / 3) * CK_XC + tap % 3) * YS + ch0 * 8);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks], bf, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(a1base + 16 * ks), bf, acc, 0, 0, 0);
             }
             const unsigned keep = ((unsigned)(oy0 - 1 + r) < (unsigned)p.H && (unsigned)(ox0 - 1 + c) < (unsigned)p.W) ? 0xffffffffu : 0u;
             if (mm < CK_NM) {
@@ -228,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
                 }
             }
         }
-        __syncthreads();  // (C) hidden patch complete
+        lds_barrier();  // (C) hidden patch complete
 
         // ---- S3: m.cv2 3x3 (CH -> C) + shortcut: the two MFMA pixel tiles of the output tile, waves 0 and 1 ------------------------
         if (wave < 2) {
@@ -255,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
                 *reinterpret_cast<half4*>(sy2 + (32 * wave + lrow) * YS + 8 * g + 4 * lh) = o;
             }
         }
-        __syncthreads();  // (D) y2 tile complete
+        lds_barrier();  // (D) y2 tile complete
 
         // ---- S4: cv2 (1x1, 3C -> C2) over [y0 | y1 | y2]: cout tile `wave`, both pixel tiles ----------------------------------------
         {
@@ -274,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
                     acc[q2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a4[ks], *reinterpret_cast<const half8*>(sp + 16 * kk + 8 * lh), acc[q2], 0, 0, 0);
                 }
             }
+            lds_barrier();  // (D') every wave's cv2 MFMAs have read y0 / y1: their tiles become the output tile
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
@@ -287,13 +270,15 @@ __global__ __launch_bounds__(256, 2) void c3k2_fused_kernel(const C3k2K p) {
                     *reinterpret_cast<half4*>(sout + (32 * q2 + lrow) * OS + cc) = o;
                 }
         }
-        __syncthreads();  // (E) output tile complete
+        lds_barrier();  // (E) output tile complete
 
 #pragma unroll
-        for (int j = 0; j < NST; ++j)
-            if (oy0 + st_y[j] < p.H && ox0 + st_x[j] < p.W)
-                *reinterpret_cast<half8*>(ob + st_rel[j]) = *reinterpret_cast<const half8*>(sout + st_off[j]);
-        __syncthreads();  // (F) output tile read: the next iteration overwrites it with the next x patch
+        for (int j = 0; j < NST; ++j) {
+            const int id = tid + 256 * j, pr = id / CPRW, cc = (id % CPRW) * 8, sy = pr / CK_TW, sx_ = pr % CK_TW;
+            if (oy0 + sy < p.H && ox0 + sx_ < p.W)
+                *reinterpret_cast<half8*>(ob + (size_t)(sy * p.W + sx_) * p.ldd + cc) = *reinterpret_cast<const half8*>(sout + pr * OS + cc);
+        }
+        lds_barrier();  // (F) output tile read: the next iteration's S1 overwrites it with the next y1 / y0 tiles
     }
 }
 
@@ -323,7 +308,7 @@ int launch_c3k2_fused(const C3k2Args& a, hipStream_t s) {
     k.ntiles = (int)nt;
     k.magic_x = (unsigned)(((1ULL << 32) + k.tiles_x - 1) / k.tiles_x);
     k.magic_y = (unsigned)(((1ULL << 32) + k.tiles_y - 1) / k.tiles_y);
-    const int grid = k.ntiles < 512 ? k.ntiles : 512;  // two 256-thread workgroups (71 KiB of LDS each) per CU
+    const int grid = k.ntiles < 768 ? k.ntiles : 768;  // three 256-thread workgroups (48 KiB of LDS each) per CU
     hipLaunchKernelGGL((c3k2_fused_kernel<64, 32, 128>), dim3(grid), dim3(256), 0, s, k);
     HIP_TRY(hipGetLastError());
     return BSY_OK;

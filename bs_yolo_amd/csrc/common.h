@@ -318,6 +318,16 @@ __device__ __forceinline__ void fma_mix8(float (&a)[8], const half8& v, const f3
     a[6] = fma_mix_lo(x.u[3], w1[2], a[6]); a[7] = fma_mix_hi(x.u[3], w1[3], a[7]);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0) -- every global load and STORE the
+// wave has in flight -- so in a persistent tile loop each barrier after a prefetch or behind the tile's output stores exposed a
+// full HBM round trip (round 3, SQ counters of the fused kernels: 44-60 % of the wave cycles spent waiting).  Registers filled
+// by a prefetch are still safe to use: the compiler places its own counted vmcnt wait in front of their first use.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Tile walk of a persistent workgroup, XCD-aware.  Workgroup b of a grid of G lands on XCD b % 8 (round-robin dispatch): with the
 // plain walk (tile = b, b + G, ...) the four / eight spatial neighbours of a tile run on OTHER XCDs, so the halo every fused kernel
 // re-reads (the C3k2 block reads its input 2.5 times) misses the XCD's L2 each time: PMC traffic of the block 927 MB for 629 MB.

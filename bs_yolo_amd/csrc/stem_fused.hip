@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
 #pragma unroll
         for (int i = 0; i < ST_NLOAD; ++i)
             if (tid + 256 * i < ST_NITEM) img_item_park<T>(pre[i], simg + (it_r[i] * ST_ROWPX + 4 * it_j[i]) * 4);
-        __syncthreads();  // image patch visible; every wave is done with the previous tile's LDS
+        lds_barrier();  // image patch visible; every wave is done with the previous tile's LDS
         if (tile + tw.step < tw.end) fetch(tile + tw.step);
 
         // ---- layer 0: 297 patch pixels = 10 MFMA pixel tiles, dealt round-robin to the 4 waves ----------------------
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
                 }
             }
         }
-        __syncthreads();  // layer-0 patch complete
+        lds_barrier();  // layer-0 patch complete
 
         // ---- layer 1: wave = (pixel tile of 2 rows x 16, cout tile of 32) --------------------------------------------
         if (l1) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
                 *reinterpret_cast<half4*>(sout + prow * LDO + c) = o;
             }
         }
-        __syncthreads();  // output tile complete
+        lds_barrier();  // output tile complete
 
         constexpr int CPRW = C1 / 8;
 #pragma unroll
@@ -209,7 +209,7 @@ bool stem_fused_supported(int C0, int C1, int H, int W) {
 
 template <typename T>
 static int launch_t(const StemArgs& a, const StemK& k, hipStream_t s) {
-    const int grid = k.ntiles < 768 ? k.ntiles : 768;  // 3 workgroups per CU (register-limited), tiles dealt round-robin
+    const int grid = k.ntiles < 768 ? k.ntiles : 768;  // 3 workgroups per CU (register-limited: a fourth needs <= 128 VGPRs and spills 61), tiles dealt round-robin
     if (a.C0 == 32) hipLaunchKernelGGL((stem_fused_kernel<T, 32, 64>), dim3(grid), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((stem_fused_kernel<T, 16, 32>), dim3(grid), dim3(256), 0, s, k);
     HIP_TRY(hipGetLastError());
