@@ -76,6 +76,14 @@ class YoloEngine:
         self.graph_ring = max(1, int(graph_ring))
         self._rings: Dict[Tuple, dict] = {}
         self._gstream = None
+        # All plans of an engine share ONE activation arena (liveness-packed): two forwards must never be in flight at once.  The
+        # reference serialises predict() with a lock (engine/predictor.py:113,229); here a host lock covers the enqueue and an event
+        # recorded behind every forward makes a forward enqueued on ANOTHER stream wait for the previous one (same stream: ordered
+        # anyway, no event wait is issued).
+        import threading
+        self._lock = threading.RLock()
+        self._last_done = None
+        self._last_stream = None
         self.graph_stats = {"captures": 0, "replays": 0, "eager": 0}
         self.autotune = ((os.environ.get("BSY_AUTOTUNE", "1") != "0") if autotune is None else bool(autotune)) and precision == "fp16"
         # pack once with a throw-away plan (op list structure does not depend on the input size)
@@ -255,6 +263,10 @@ class YoloEngine:
                 raws = [torch.cat([o[1][0][l] for o in outs]) for l in range(3)] if want_raw else [None] * 3
                 return y, (raws, y[:, 4 + self.meta["nc"]:], torch.cat([o[1][2] for o in outs]))
             return y, ([torch.cat([o[1][l] for o in outs]) for l in range(3)] if want_raw else [None] * 3)
+        with self._lock:  # plan table, arena and launch order are shared state
+            return self._forward_one(im, want_raw, B, H, W)
+
+    def _forward_one(self, im, want_raw, B, H, W):
         plan, h = self.plan_for(B, H, W, im.dtype, im.dtype)
         m = plan.meta
 
@@ -278,7 +290,10 @@ class YoloEngine:
         else:
             y, raws, proto = outputs()
         ext, n = self._ext(im, y, raws, proto)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        cur_stream = torch.cuda.current_stream(self.device)
+        stream = cur_stream.cuda_stream
+        if self._last_done is not None and self._last_stream != stream:
+            cur_stream.wait_event(self._last_done)  # the arena is still owned by a forward on another stream
         if self.autotune and (B, H, W, im.dtype) not in self._tuned:
             # first call for this shape: pick the fastest kernel configuration per conv op (runs the plan once)
             self._tuned.add((B, H, W, im.dtype))
@@ -300,6 +315,10 @@ class YoloEngine:
             self.graph_stats[{1: "captures", 0: "replays"}.get(how.value, "eager")] += 1
         else:
             L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
+        if self._last_done is None:
+            self._last_done = torch.cuda.Event()
+        self._last_done.record(cur_stream)
+        self._last_stream = stream
         if m["nm"]:  # Segment.forward (head.py:197): (cat(y, mc), (raw, mc, proto)); y already carries the mc rows
             return y, (raws, y[:, 4 + m["nc"]:], proto)
         return y, raws

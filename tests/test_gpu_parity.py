@@ -917,6 +917,40 @@ def test_engine_graph_mode_equals_eager(fam, scale, nc, task, shape, own_stream)
     graph.close()
 
 
+def test_engine_serialises_forwards_across_streams_and_threads():
+    """All plans of an engine share one liveness-packed arena (round 2), so two forwards must never overlap: forwards
+    enqueued on different torch streams, of different shapes (different plans aliasing the same memory), and from two host threads
+    return what the same calls return one after the other."""
+    import threading
+    m = R.Model("yolo11", "s", 80, "detect")
+    P = R.synth_params(m, 4)
+    eng = YoloEngine(stock_cfg("yolo11", "s"), P, autotune=False)
+    shapes = [(6, 320, 320), (2, 640, 480), (9, 256, 256)]
+    xs = [torch.rand(*((b, 3, h, w)), generator=torch.Generator().manual_seed(i)).half().to(DEV) for i, (b, h, w) in enumerate(shapes)]
+    ref = [eng(x)[0].clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(3)]
+    outs = []
+    for rep in range(4):  # back to back on three streams, no host synchronisation in between
+        for i, x in enumerate(xs):
+            with torch.cuda.stream(streams[(i + rep) % 3]):
+                outs.append((i, eng(x)[0]))
+    torch.cuda.synchronize()
+    assert all(torch.equal(y, ref[i]) for i, y in outs)
+    got = {}
+
+    def worker(i):
+        with torch.cuda.stream(streams[i]):
+            for _ in range(5):
+                got[i] = eng(xs[i])[0]
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert all(torch.equal(got[i], ref[i]) for i in range(3))
+    eng.close()
+
+
 @pytest.mark.parametrize("scale,shape", [("n", (1, 32, 32)), ("s", (3, 96, 224)), ("s", (2, 160, 32)), ("n", (5, 64, 416))])
 def test_engine_fused_equals_plain_on_odd_shapes(scale, shape):
     """Every fusion against the plain plan (one launch per layer) on small, narrow and wide inputs, both with the heuristic
