@@ -126,8 +126,7 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
             const int r = mc / BN_MC, c = mc - r * BN_MC;
             const half_t* xb = sx + (r * BN_XC + c) * XS + 8 * lh;  // input entry of tap (0, 0), this lane half's chunk
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sb1, lh);  // accumulators start at the bias (common.h acc_bias)
 #pragma unroll
             for (int ks = 0; ks < KSA; ++ks) {
                 const int k0 = 16 * ks, tap = k0 / C, ch0 = (k0 % C) / 8;  // compile-time; lane half 1 = next chunk
@@ -138,9 +137,8 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
             if (mm < BN_NM) {
 #pragma unroll
                 for (int g = 0; g < CH / 8; ++g) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + 8 * g + 4 * lh);
                     union { half4 h; unsigned u[2]; } o;
-                    f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                    f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     if (p.act) t = silu4_f(t);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
@@ -155,8 +153,7 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
         // ---- conv 2 + residual: one MFMA pixel tile (2 rows x 16) per wave ---------------------------------------------
         {
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sb2, lh);
 #pragma unroll
             for (int ks = 0; ks < KSB; ++ks) {
                 const int k0 = 16 * ks, tap = k0 / CH, ch0 = (k0 % CH) / 8;
@@ -166,10 +163,9 @@ __global__ __launch_bounds__(256, 3) void bneck_fused_kernel(const BneckK p) {
             const int prow = wave * 32 + lrow;
 #pragma unroll
             for (int g = 0; g < C / 8; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sb2 + 8 * g + 4 * lh);
                 const half4 rv = *reinterpret_cast<const half4*>(rbase + 8 * g);
                 half4 o;
-                f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                 if (p.act) t = silu4_f(t);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)t[q] + (float)rv[q]);
@@ -307,8 +303,7 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
         // ---- conv 1: 180 hidden pixels = 6 MFMA pixel tiles on waves 0-5 -----------------------------------------------------
         if (wave < BN_NMT) {
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sb1, lh);
 #pragma unroll
             for (int ks = 0; ks < KSA; ++ks) {
                 // the layer's K walk (conv_mfma.hip conv_korder: 3x3, Cin % 32 == 0 -> chunk-major, 32-channel chunks): chunk, tap, 16-wide half
@@ -320,9 +315,8 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
             if (mm1 < BN_NM) {
 #pragma unroll
                 for (int g = 0; g < CH / 8; ++g) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + 8 * g + 4 * lh);
                     union { half4 h; unsigned u[2]; } o;
-                    f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                    f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     if (p.act) t = silu4_f(t);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
@@ -337,8 +331,7 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
         // ---- conv 2 + shortcut: MFMA pixel tile pt (2 rows x 16), cout tile ct (32 channels) per wave ----------------------------
         {
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sb2 + 32 * ct, lh);
 #pragma unroll
             for (int ks = 0; ks < KSB; ++ks) {
                 const int k0 = 16 * ks, tap = k0 / CH, ch0 = (k0 % CH) / 8;
@@ -347,10 +340,9 @@ __global__ __launch_bounds__(512) void bneck_fused_wide_kernel(const BneckK p) {
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sb2 + 32 * ct + 8 * g + 4 * lh);
                 const half4 rv = *reinterpret_cast<const half4*>(rbase + 8 * g);
                 half4 o;
-                f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                 if (p.act) t = silu4_f(t);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)t[q] + (float)rv[q]);

@@ -153,19 +153,16 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
         auto s1_job = [&](const bool is_y0, const half8 (&wf)[KS1], const half8 (&xf)[KS1], const int e, const int r, const int c, const int opix) {
             // e = patch entry of this lane's pixel, (r, c) its patch coordinates; y0 jobs write output pixel opix
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sb1 + (is_y0 ? 0 : C), lh);  // accumulators start at the bias (common.h acc_bias)
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf[ks], acc, 0, 0, 0);
             const unsigned keep = (is_y0 || ((unsigned)(oy0 - 2 + r) < (unsigned)p.H && (unsigned)(ox0 - 2 + c) < (unsigned)p.W)) ? 0xffffffffu : 0u;
             half_t* d = is_y0 ? sy0 + opix * YS : sy1 + e * YS;
-            const float* bb_ = sb1 + (is_y0 ? 0 : C);
 #pragma unroll
             for (int g = 0; g < C / 8; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bb_ + 8 * g + 4 * lh);
                 union { half4 h; unsigned u[2]; } o;
-                const f32x4 tv = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
+                const f32x4 tv = silu4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]});
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o.h[q] = (half_t)tv[q];
                 o.u[0] &= keep;
@@ -187,8 +184,7 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
             asm volatile("" : "+v"(ao));  // per-tile opaque: keeps the 18 weight fragments in LDS (hoisted out of the tile loop they cost 72 VGPRs)
             const half_t* a1base = swa + ao;
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sba, lh);  // (rows >= CH read into the next bias array: accumulator rows no epilogue uses)
 #pragma unroll
             for (int ks = 0; ks < KSA; ++ks) {
                 const int k0 = 16 * ks, tap = k0 / C, ch0 = (k0 % C) / 8;  // compile-time
@@ -199,9 +195,8 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
             if (mm < CK_NM) {
 #pragma unroll
                 for (int g = 0; g < CH / 8; ++g) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sba + 8 * g + 4 * lh);
                     union { half4 h; unsigned u[2]; } o;
-                    const f32x4 tv = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
+                    const f32x4 tv = silu4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]});
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o.h[q] = (half_t)tv[q];
                     o.u[0] &= keep;  // outside the map: m.cv2's zero padding
@@ -218,8 +213,7 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
             const half_t* b2base = smid + (ty2 * CK_MC + ltx) * MS + 8 * lh;       // hidden entry of tap (0, 0)
             const half_t* y1own = sy1 + ((ty2 + 2) * CK_XC + ltx + 2) * YS;        // the pixel's own y1 entry (the shortcut)
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sbb, lh);
 #pragma unroll
             for (int ks = 0; ks < KSB; ++ks) {
                 const int k0 = 16 * ks, tap = k0 / CH, ch0 = (k0 % CH) / 8;
@@ -228,10 +222,9 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
             }
 #pragma unroll
             for (int g = 0; g < C / 8; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbb + 8 * g + 4 * lh);
                 const half4 rv = *reinterpret_cast<const half4*>(y1own + 8 * g + 4 * lh);
                 half4 o;
-                const f32x4 tv = silu4_f(add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv));
+                const f32x4 tv = silu4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]});
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)((float)(half_t)tv[q] + (float)rv[q]);
                 *reinterpret_cast<half4*>(sy2 + (32 * wave + lrow) * YS + 8 * g + 4 * lh) = o;
@@ -243,9 +236,7 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
         {
             f32x16 acc[2];
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q2][q] = 0.f;
+            for (int q2 = 0; q2 < 2; ++q2) acc_bias(acc[q2], sb4 + 32 * wave, lh);
 #pragma unroll
             for (int ks = 0; ks < 3 * KSEG; ++ks) {
                 const int seg = ks / KSEG, kk = ks - seg * KSEG;  // compile-time: 0 = y0, 1 = y1, 2 = y2
@@ -262,9 +253,8 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cc = 32 * wave + 8 * g + 4 * lh;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb4 + cc);
                     half4 o;
-                    const f32x4 tv = silu4_f(add4_f(f32x4{acc[q2][4 * g], acc[q2][4 * g + 1], acc[q2][4 * g + 2], acc[q2][4 * g + 3]}, bv));
+                    const f32x4 tv = silu4_f(f32x4{acc[q2][4 * g], acc[q2][4 * g + 1], acc[q2][4 * g + 2], acc[q2][4 * g + 3]});
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = (half_t)tv[q];
                     *reinterpret_cast<half4*>(sout + (32 * q2 + lrow) * OS + cc) = o;

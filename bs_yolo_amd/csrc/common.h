@@ -345,6 +345,20 @@ __device__ __forceinline__ TileWalk xcd_tile_walk(int b, int G, int ntiles) {
     return TileWalk{start + i, gx, start + q + (x < r ? 1 : 0)};
 }
 
+// An MFMA accumulator tile (32 couts x 32 pixels, lane = pixel) that STARTS at the bias of its rows (round 3: every conv kernel of the
+// fp16 path accumulates bias + sum instead of adding the bias in its epilogue -- one VALU instruction less per activation in
+// kernels whose SIMDs are ~80 % busy issuing SiLU; all kernels do it alike, so fused and un-fused launches still agree bit for bit).
+// Register r of lane half lh is cout (r & 3) + 8 (r >> 2) + 4 lh of the tile; `bias` points at the tile's first cout (f32, 16-byte
+// aligned, 32 readable values: the packed bias vectors are padded to a multiple of 128).
+__device__ __forceinline__ void acc_bias(f32x16& acc, const float* bias, int lh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = bv[e];
+    }
+}
+
 // SiLU in fp32: x * sigmoid(x) = x / (1 + 2^(-x*log2 e)); v_exp_f32 + v_rcp_f32 (1 ulp each) -- the result is rounded
 // to fp16 right after, so the IEEE-division expansion (~10 VALU) would buy nothing.  exp2 overflow -> inf -> rcp -> 0.
 // The product passes through an empty asm: where a conversion to f16 follows directly, the compiler otherwise folds the final

@@ -52,13 +52,11 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
             afr[a][s] = *reinterpret_cast<const half8*>(wgt + (size_t)(a * 32 + lrow) * IMGC_KROW + 16 * s + 8 * lh);
     __syncthreads();
 
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][2];  // start at the bias of their couts (common.h acc_bias; the packed bias is padded to 128 values)
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int b = 0; b < 2; ++b) acc_bias(acc[a][b], bias + a * 32, lh);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         // output pixel (row `wave`, column x = 32 b + lrow): its window starts at patch pixel (2 wave, 2 x + 3)
@@ -84,11 +82,10 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const T* __restric
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = a * 32 + 8 * g + 4 * lh;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[a][b][4 * g + e] + bv[e];
+                    float t = acc[a][b][4 * g + e];
                     o[e] = (half_t)(act ? silu_f(t) : t);
                 }
                 *reinterpret_cast<half4*>(tile + prow * LDT + c) = o;

@@ -132,10 +132,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[NT][
                     const int c = cbase + 8 * g + 4 * lh;
                     float v[4] = {0.f, 0.f, 0.f, 0.f};
                     if (c < p.Cout) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = acc[a][b][4 * g + e] + bv[e];
+                            float t = acc[a][b][4 * g + e];  // (the accumulators started at the bias)
                             v[e] = p.act ? silu_f(t) : t;
                         }
                         if (p.res && mvalid) {
@@ -166,11 +165,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[NT][
             for (int g = 0; g < 4; ++g) {
                 const int c = cbase + 8 * g + 4 * lh;
                 if (c >= p.Cout) continue;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);  // bias is padded to CoutPad
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[a][b][4 * g + e] + bv[e];
+                    float t = acc[a][b][4 * g + e];
                     if (p.act) t = silu_f(t);
                     v[e] = t;
                 }
@@ -229,7 +227,7 @@ __device__ __forceinline__ void head_store(void* base, size_t idx, float v) { re
 // DFL + dist2bbox of one pixel per lane pair (head.py:141-146, block.py:58-77): lo / hi = the 32 x 32 accumulators of couts 0..31 /
 // 32..63 of this lane's pixel; side sd's 16 bins sit in 8 registers of this lane and 8 of lane ^ 32.  Writes rows 0..3 of y (and the
 // raw logits when a raw map is bound).
-__device__ __forceinline__ void dfl_decode_store(const ConvK& p, const float* __restrict__ bias, const f32x16& lo, const f32x16& hi, bool mv,
+__device__ __forceinline__ void dfl_decode_store(const ConvK& p, const f32x16& lo, const f32x16& hi, bool mv,
                                                  size_t ybase, size_t rbase, int pix, int lh) {
     const int hw = p.OH * p.OW;
     float dist[4];
@@ -238,11 +236,9 @@ __device__ __forceinline__ void dfl_decode_store(const ConvK& p, const float* __
         const int rb = 8 * (sd & 1);
         float v[8];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * sd + 8 * g + 4 * lh);
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * g + e] = ((sd >> 1) ? hi : lo)[rb + 4 * g + e] + bv[e];
-        }
+            for (int e = 0; e < 4; ++e) v[4 * g + e] = ((sd >> 1) ? hi : lo)[rb + 4 * g + e];  // logits incl. bias (accumulator start)
         if (p.raw && mv) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -299,12 +295,11 @@ __device__ __forceinline__ void conv_epilogue_head(const ConvK& p, f32x16 (&acc)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c0 = cl + 8 * g + 4 * lh;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c0);  // bias is padded to CoutPad
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int c = c0 + e;
                         if (!mv || c >= p.Cout) continue;
-                        const float v = acc[a][b][4 * g + e] + bv[e];
+                        const float v = acc[a][b][4 * g + e];
                         const float sg = 1.0f / (1.0f + __expf(-v));
                         const size_t yi = ybase + (size_t)(4 + c) * p.A;
                         if (p.y_f32) head_store<float>(p.y, yi, sg); else head_store<half_t>(p.y, yi, sg);
@@ -316,7 +311,7 @@ __device__ __forceinline__ void conv_epilogue_head(const ConvK& p, f32x16 (&acc)
                 }
             }
         } else if (NT == 2) {  // epi 3; host guarantees WAVES_N == 1, n0 == 0, Cout == 64
-            dfl_decode_store(p, p.bias, acc[0][b], acc[NT - 1][b], mv, ybase, rbase, pix, lh);
+            dfl_decode_store(p, acc[0][b], acc[NT - 1][b], mv, ybase, rbase, pix, lh);
         }
     }
 }
@@ -339,10 +334,9 @@ __device__ __forceinline__ void conv_epilogue_cls_lds(const ConvK& p, f32x16 (&a
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = cl + 8 * g + 4 * lh;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = acc[a][b][4 * g + e] + bv[e];
+                    const float v = acc[a][b][4 * g + e];
                     stile[(c + e) * LDP + prow] = (half_t)(1.0f / (1.0f + __expf(-v)));
                 }
             }
@@ -387,9 +381,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvK& p, f32x16 (&acc)[
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = cl + 8 * g + 4 * lh;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
                 half4 o;
-                f32x4 t = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]}, bv);
+                f32x4 t = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
                 if (p.act) t = silu4_f(t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (half_t)t[e];
@@ -591,17 +584,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
         }                                                                                                \
     } while (0)
 
-    f32x16 acc[NT][MT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
     const int lrow = lane & 31;
     const int lh = lane >> 5;
     const int nk = p.Kpad / BK;
+    f32x16 acc[NT][MT];  // start at the bias of their couts (common.h acc_bias)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc_bias(acc[a][b], p.bias + n0 + (wn * NT + a) * 32, lh);
 
     // prologue: STAGES-1 K-steps in flight
 #pragma unroll
@@ -810,14 +800,12 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
         if (++ikt == nk) { ikt = 0; ++it; }
     };
 
-    f32x16 acc[NT][MT];
+    const int lrow = lane & 31, lh = lane >> 5;
+    f32x16 acc[NT][MT];  // start at the bias of the tile's couts (common.h acc_bias), from the LDS copy of the bias vector
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < MT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int lrow = lane & 31, lh = lane >> 5;
+        for (int b = 0; b < MT; ++b) acc_bias(acc[a][b], sbias + (T0 % p.ntn) * TN + (wn * NT + a) * 32, lh);
     const int total = my_tiles * nk;
     int ip = 0;
     for (; ip < STAGES - 1 && ip < total; ++ip) issue_step(ip % STAGES);
@@ -859,8 +847,8 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks][a], bfr[ks][b], acc[a][b], 0, 0, 0);
         if (++ckt == nk) {
             ckt = 0;
-            const int n0 = ((T0 + ct * G) % p.ntn) * TN;
-            // park bias + SiLU as fp16 (the store waves finished reading the previous tile before B(ct, 0))
+            const int n1 = ((T0 + (ct + 1) * G) % p.ntn) * TN;  // cout tile of the NEXT tile: its biases restart the accumulators
+            // park SiLU(acc) as fp16 (the store waves finished reading the previous tile before B(ct, 0))
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 const int prow = (wm * MT + b) * 32 + lrow;
@@ -870,14 +858,14 @@ __global__ __launch_bounds__(512) void conv1x1_persist_kernel(const ConvK p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int c = cl + 8 * g + 4 * lh;
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + n0 + c);
+                        const f32x4 bn = *reinterpret_cast<const f32x4*>(sbias + n1 + c);
                         half4 o;
-                        f32x4 tv = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]}, bv);
+                        f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
                         if (p.act) tv = silu4_f(tv);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             o[e] = (half_t)tv[e];
-                            acc[a][b][4 * g + e] = 0.f;
+                            acc[a][b][4 * g + e] = bn[e];
                         }
                         *reinterpret_cast<half4*>(otile + prow * LDT + c) = o;
                     }
@@ -1007,13 +995,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wres_kernel(const ConvK p) {
         if (++ikt == nk) { ikt = 0; ++it; }
     };
 
-    f32x16 acc[NT][MT];
+    f32x16 acc[NT][MT];  // start at the bias of this cout tile (common.h acc_bias)
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < MT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int b = 0; b < MT; ++b) acc_bias(acc[a][b], sbias + (wn * NT + a) * 32, lh);
     const int total = my_tiles * nk;
     int ip = 0;
     for (; ip < STAGES - 1 && ip < total; ++ip) issue_step(ip % STAGES);
@@ -1068,13 +1054,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wres_kernel(const ConvK p) {
                     for (int g = 0; g < 4; ++g) {
                         const int c = (wn * NT + a) * 32 + 8 * g + 4 * lh;
                         half4 o;
-                        f32x4 tv = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]},
-                                          *reinterpret_cast<const f32x4*>(sbias + c));
+                        const f32x4 bn = *reinterpret_cast<const f32x4*>(sbias + c);  // the next tile's accumulators restart at the bias
+                        f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
                         if (p.act) tv = silu4_f(tv);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             o[e] = (half_t)tv[e];
-                            acc[a][b][4 * g + e] = 0.f;
+                            acc[a][b][4 * g + e] = bn[e];
                         }
                         *reinterpret_cast<half4*>(otile + prow * LDT + c) = o;
                     }
@@ -1229,13 +1215,11 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
         if (++w_kh == 3) { w_kh = 0; ++w_chunk; }
     };
 
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][2];  // start at the bias of their couts (common.h acc_bias)
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int b = 0; b < 2; ++b) acc_bias(acc[a][b], p.bias + n0 + (wn * NT + a) * 32, lh);
     // lane pixel of MFMA tile b: tile row wm*4 + 2b + (lrow >> 4), column lrow & 15 -> patch entry of tap (0, 0)
     int lq[2];
 #pragma unroll
@@ -1327,9 +1311,8 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = cl + 8 * g + 4 * lh;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);  // bias is padded to CoutPad
                 half4 o;
-                f32x4 tv = add4_f(f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]}, bv);
+                f32x4 tv = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
                 if (p.act) tv = silu4_f(tv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (half_t)tv[e];
@@ -1341,9 +1324,9 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
     if (TAIL) {
         static_assert(!TAIL || (NT == 1 && WM == 2), "tail: 64-cout tiles, four waves");
         const int slot = wave * 32 + lrow;
-        f32x16 t0, t1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { t0[r] = 0.f; t1[r] = 0.f; }
+        f32x16 t0, t1;  // box logits 0..31 / 32..63 of this lane's pixel, starting at the 1x1 conv's bias
+        acc_bias(t0, p.tail_bias, lh);
+        acc_bias(t1, p.tail_bias + 32, lh);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const half8 tb = *reinterpret_cast<const half8*>(smem + slot * LDT + 16 * ks + 8 * lh);
@@ -1354,7 +1337,7 @@ __global__ __launch_bounds__(128 * WM) void conv3x3_patch_kernel(const ConvK p) 
         const bool mv = slot < NVALID && oy < p.H && ox < p.W;
         const int pix = mv ? oy * p.W + ox : 0;
         const int hw = p.H * p.W;
-        dfl_decode_store(p, p.tail_bias, t0, t1, mv, (size_t)n * p.nrows * p.A + p.a0 + pix, (size_t)n * p.rawC * hw + pix, pix, lh);
+        dfl_decode_store(p, t0, t1, mv, (size_t)n * p.nrows * p.A + p.a0 + pix, (size_t)n * p.rawC * hw + pix, pix, lh);
         return;
     }
     constexpr int CPRW = TN / 8, ITER = TM * CPRW / NTHR;
@@ -1472,13 +1455,11 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
         for (int j = 0; j < WIW; ++j) dma16_buf(rsw, woff[j], 64u * (unsigned)c, sW + (4 * j + wave) * 512);
     };
 
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][2];  // the 1x1 conv's accumulators start at its bias (common.h acc_bias)
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int b = 0; b < 2; ++b) acc_bias(acc[a][b], p.bias + n0 + (wn * NT + a) * 32, lh);
     // depthwise stage: this thread's two items = pixels (tid >> 2) and (tid >> 2) + 64 (4 tile rows apart), 8-channel
     // piece (tid & 3).  LDS offsets (halves) of the item's nine taps, swizzle included, are chunk-independent.
     const int ch8 = tid & 3;
@@ -1574,9 +1555,8 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void dwpw_fused_kernel(const 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cc = cl + 8 * g + 4 * lh;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + cc);
                 half4 o;
-                f32x4 tv = add4_f(f32x4{acc[a_][b][4 * g], acc[a_][b][4 * g + 1], acc[a_][b][4 * g + 2], acc[a_][b][4 * g + 3]}, bv);
+                f32x4 tv = f32x4{acc[a_][b][4 * g], acc[a_][b][4 * g + 1], acc[a_][b][4 * g + 2], acc[a_][b][4 * g + 3]};
                 if (p.act) tv = silu4_f(tv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (half_t)tv[e];

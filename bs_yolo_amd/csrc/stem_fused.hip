@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
             const int r = pc / ST_C0W, c = pc - r * ST_C0W;
             const int win = (2 * r * ST_ROWPX + 2 * c + 1) * 4;  // window origin: image-patch pixel (2r, 2c + 1)
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sb0, lh);  // accumulators start at the bias (common.h acc_bias)
 #pragma unroll
             for (int s = 0; s < IMGC_KSUB; ++s)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], img_frag<ST_ROWPX>(simg, win, s, lh), acc, 0, 0, 0);
@@ -143,9 +142,8 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
             if (pp < ST_NE) {
 #pragma unroll
                 for (int g = 0; g < NCH; ++g) {  // couts 8g + 4lh .. +3  (C0 = 16: g < 2 only)
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb0 + 8 * g + 4 * lh);
                     union { half4 h; unsigned u[2]; } o;
-                    f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                    f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     if (p.act) t = silu4_f(t);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o.h[q] = (half_t)t[q];
@@ -160,8 +158,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
         // ---- layer 1: wave = (pixel tile of 2 rows x 16, cout tile of 32) --------------------------------------------
         if (l1) {
             f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc_bias(acc, sb1 + nh1 * 32, lh);
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 // k = 16 ks + 8 lh + (0..7) = tap * C0 + channel: one tap and one 8-channel chunk per lane half
@@ -180,9 +177,8 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = nh1 * 32 + 8 * g + 4 * lh;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1 + c);
                 half4 o;
-                f32x4 t = add4_f(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, bv);
+                f32x4 t = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                 if (p.act) t = silu4_f(t);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)t[q];
