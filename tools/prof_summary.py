@@ -4,7 +4,7 @@ steps (the timed region; earlier dispatches include warm-up and the autotuner's 
 
     python tools/prof_summary.py <kernel_trace.csv> <steps> <conv launches per step: roofline.launches_per_step of bench.py>
 
-"conv family" = every kernel that does dense-conv MFMA work -- conv_mfma_kernel (implicit GEMM), conv1x1_persist_kernel,
+"conv family" = every kernel that does dense-conv MFMA work -- conv_mfma_kernel (implicit GEMM), conv1x1_persist_kernel, conv1x1_wres_kernel,
 conv3x3_patch_kernel and the fused conv kernels (stem, Bottleneck, C3k2 block, DWConv+1x1, first conv) -- the set bench.py's
 `roofline` object prices since round 2 (round 1 priced the first three only).
 """
@@ -14,7 +14,7 @@ from collections import defaultdict
 
 path, steps = sys.argv[1], int(sys.argv[2])
 per_step = int(sys.argv[3])
-CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")
+CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 conv = [r for r in rows if any(k in r["Kernel_Name"] for k in CONV)]
