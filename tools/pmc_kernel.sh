@@ -16,10 +16,17 @@ for nm in names:
     ds = [d for d in disp.values() if nm in d["name"]]
     if not ds:
         print(nm, "not found"); continue
-    d = ds[-1]
-    wc = d.get("SQ_WAVE_CYCLES", 0) or 1
-    print(f"{nm}: {d['dur'] / 1e3:.1f} us, grid {d['grid']} wg {d['wg']} vgpr {d['vgpr']} lds {d['lds']}")
-    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
-        print(f"   {k:22s} {100 * d.get(k, 0) / wc:6.1f} % of wave cycles")
-    print(f"   VALU insts {d.get('SQ_INSTS_VALU', 0):.3e}  LDS insts {d.get('SQ_INSTS_LDS', 0):.3e}  MFMA busy cycles {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.3e}  wave cycles (quad) {wc:.3e}")
+    # one line per distinct instantiation (template arguments) of the last forward's dispatches: aggregate of its launches
+    groups = {}
+    for d in ds[-400:]:
+        groups.setdefault(d["name"], []).append(d)
+    for name, g in sorted(groups.items(), key=lambda kv: -sum(x["dur"] for x in kv[1])):
+        wc = sum(x.get("SQ_WAVE_CYCLES", 0) for x in g) or 1
+        short = name[name.find(nm):][:110]
+        print(f"{short}: {len(g)} launches, {sum(x['dur'] for x in g) / len(g) / 1e3:.1f} us avg, wg {g[0]['wg']} vgpr {g[0]['vgpr']} lds {g[0]['lds']}")
+        line = "   "
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+            line += f"{k[3:]} {100 * sum(x.get(k, 0) for x in g) / wc:5.1f} %  "
+        busy = sum(x.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for x in g)
+        print(line + f"MFMA busy / (4 x wave quad-cycles) {100 * busy / (4 * wc):5.1f} %")
 PY
