@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
     constexpr int SOUT = CK_NPX * OS;  // the output tile aliases [y1 patch | y0 tile], dead once cv2's MFMAs have read them (barrier D')
     static_assert(SOUT <= SY1 + SY0, "output tile must fit the y1 + y0 tiles it aliases");
     constexpr int SWA = CH * WAS, SWB = C * WBS;
-    __shared__ __attribute__((aligned(16))) half_t lds[SY1 + SY0 + SM + SY2 + SWA + SWB + 2 * (2 * C + CH + C + C2)];
+    constexpr int W0S = CIN + 8, SW0 = C * W0S;                                // cv1's y0 rows (waves 1 and 2 only): LDS, not registers
+    __shared__ __attribute__((aligned(16))) half_t lds[SY1 + SY0 + SM + SY2 + SWA + SWB + SW0 + 2 * (2 * C + CH + C + C2)];
     half_t* sy1 = lds;
     half_t* sy0 = sy1 + SY1;
     half_t* sout = lds;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
     half_t* sy2 = smid + SM;
     half_t* swa = sy2 + SY2;
     half_t* swb = swa + SWA;
-    float* sb1 = reinterpret_cast<float*>(swb + SWB);
+    half_t* sw0 = swb + SWB;
+    float* sb1 = reinterpret_cast<float*>(sw0 + SW0);
     float* sba = sb1 + 2 * C;
     float* sbb = sba + CH;
     float* sb4 = sbb + C;
@@ -78,15 +80,17 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
     if (tid < CH) sba[tid] = p.ba[tid];
     if (tid < C) sbb[tid] = p.bb[tid];
     for (int i = tid; i < C2; i += 256) sb4[i] = p.b4[i];
-    // register-resident MFMA A fragments for the whole launch: cv1 (the y1 rows every wave multiplies with, the y0 rows of waves 1
-    // and 2's second job) and THIS wave's 32 output channels of cv2 (S4 splits cv2 by cout tile: wave = cout tile).  m.cv1's and
-    // m.cv2's weights live in LDS (m.cv1: its CH = 16 real rows; lanes of the zero rows 16..31 read row lrow - 16 instead -- what
-    // they produce are accumulator rows no epilogue reads).
-    half8 w1y1[KS1], w1y0[KS1], a4[3 * KSEG];
+    // register-resident MFMA A fragments for the whole launch: cv1's y1 rows (every wave multiplies with them) and THIS wave's 32
+    // output channels of cv2 (S4 splits cv2 by cout tile: wave = cout tile).  cv1's y0 rows (second job of waves 1 and 2), m.cv1's
+    // and m.cv2's weights live in LDS (m.cv1: its CH = 16 real rows; lanes of the zero rows 16..31 read row lrow - 16 instead --
+    // what they produce are accumulator rows no epilogue reads).  With the y0 rows in registers too the kernel spilled 12 VGPRs at
+    // three workgroups per CU (168 registers).
+    half8 w1y1[KS1], a4[3 * KSEG];
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) {
-        w1y1[ks] = *reinterpret_cast<const half8*>(p.w1 + (size_t)(C + lrow) * p.K1 + 16 * ks + 8 * lh);
-        w1y0[ks] = *reinterpret_cast<const half8*>(p.w1 + (size_t)lrow * p.K1 + 16 * ks + 8 * lh);
+    for (int ks = 0; ks < KS1; ++ks) w1y1[ks] = *reinterpret_cast<const half8*>(p.w1 + (size_t)(C + lrow) * p.K1 + 16 * ks + 8 * lh);
+    for (int i = tid; i < C * (CIN / 8); i += 256) {
+        const int row = i / (CIN / 8), ch = i - row * (CIN / 8);
+        *reinterpret_cast<half8*>(sw0 + row * W0S + ch * 8) = *reinterpret_cast<const half8*>(p.w1 + (size_t)row * p.K1 + ch * 8);
     }
 #pragma unroll
     for (int ks = 0; ks < 3 * KSEG; ++ks) a4[ks] = *reinterpret_cast<const half8*>(p.w4 + (size_t)(32 * wave + lrow) * p.K4 + 16 * ks + 8 * lh);
@@ -172,7 +176,14 @@ __global__ __launch_bounds__(256, 3) void c3k2_fused_kernel(const C3k2K p) {
         };
         s1_job(false, w1y1, xa, eA, rA, cA, 0);
         if (wave == 0) s1_job(false, w1y1, xb, eB, rB, cB, 0);
-        else if (wave < 3) s1_job(true, w1y0, xb, eB, rB, cB, 32 * (wave - 1) + lrow);
+        else if (wave < 3) {
+            int wo = lrow * W0S + 8 * lh;
+            asm volatile("" : "+v"(wo));  // per-tile opaque, as for m.cv1's weights below: the fragments stay in LDS
+            half8 w1y0[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) w1y0[ks] = *reinterpret_cast<const half8*>(sw0 + wo + 16 * ks);
+            s1_job(true, w1y0, xb, eB, rB, cB, 32 * (wave - 1) + lrow);
+        }
         if (tile + tw.step < tw.end) fetch(tile + tw.step);  // x of the next tile: its registers are free now, its latency has S2..S4 to pass
         lds_barrier();  // (B) y1 patch + y0 tile complete
 

@@ -786,6 +786,23 @@ extern "C" int bsy_plan_set_tuning(bsy_plan* p, const int32_t* cfg, int n) {
     return BSY_OK;
 }
 
+// HOST array valid[n_ops]: 1 = the configuration preset for op i (bsy_plan_set_tuning) can run the op's shape, 0 = it cannot (a launch
+// would fall back to the heuristic configuration: a stale or foreign tune cache), -1 = not a conv op or not preset.  Launches nothing.
+extern "C" int bsy_plan_check_tuning(bsy_plan* p, void* const* ext, int n_ext, int32_t* valid, int n) {
+    if (!p || !valid || (n_ext && !ext) || n != (int)p->ops.size()) BSY_FAIL(BSY_ERR_ARG, "plan_check_tuning: bad argument");
+    Resolver R{p, ext, n_ext};
+    for (int i = 0; i < n; ++i) {
+        const bsy_op& op = p->ops[i];
+        valid[i] = -1;
+        if (op.kind != BSY_OP_CONV || op.tuned_cfg <= 0 || op.prec != 0) continue;
+        ConvArgs a;
+        const int rc = run_op(p, op, R, nullptr, &a);  // arguments only: nothing is launched when `cargs` is given
+        if (rc != BSY_OK) return rc;
+        valid[i] = conv_cfg_valid(a, op.tuned_cfg - 1) ? 1 : 0;
+    }
+    return BSY_OK;
+}
+
 extern "C" int bsy_plan_copy_buffer(bsy_plan* p, int buf, void* host_dst, size_t bytes) {
     if (!p || !host_dst || buf < 0 || (size_t)buf >= p->buf_off.size()) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: bad argument");
     if (bytes > p->buf_size[buf]) BSY_FAIL(BSY_ERR_ARG, "copy_buffer: %zu > buffer size %zu", bytes, p->buf_size[buf]);

@@ -161,6 +161,22 @@ class YoloEngine:
     def _autotune(self, plan, h, ext, n, stream):
         """First forward of a shape: time the candidate configurations of the conv ops whose shape has not been tuned yet
         (bsy_plan_autotune skips preset ops) and remember the winners by conv shape."""
+        # presets that came from the tune file or from a similar-sized shape's entry may not fit this shape (another library version,
+        # another alignment): drop them from the caches and from the plan, so that they are timed below instead of being persisted
+        nops = len(plan.ops)
+        valid = (C.c_int32 * nops)()
+        L.check(L.lib.bsy_plan_check_tuning(h, ext, n, valid, nops))
+        bad = [i for i in range(nops) if valid[i] == 0]
+        if bad:
+            clear = (C.c_int32 * nops)(*([-1] * nops))
+            for i in bad:
+                sg = plan.conv_sigs[i]
+                cfg = self._tune_cache.pop(sg, None)
+                if cfg is not None and self._tune_family.get(self._family(sg)) == cfg:
+                    del self._tune_family[self._family(sg)]
+                clear[i] = -2
+            L.check(L.lib.bsy_plan_set_tuning(h, clear, nops))
+            self.tune_stats["invalid_presets"] = self.tune_stats.get("invalid_presets", 0) + len(bad)
         todo = sum(1 for sg in plan.conv_sigs if sg is not None and sg not in self._tune_cache)
         self.tune_stats["autotune_calls"] += 1
         self.tune_stats["timed_ops"] += todo

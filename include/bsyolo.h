@@ -171,6 +171,10 @@ int bsy_plan_autotune(bsy_plan* p, void* const* ext, int n_ext, bsy_stream strea
 int bsy_plan_set_tuning(bsy_plan* p, const int32_t* cfg, int n_ops);
 /* HOST out[n_ops]: configuration id per op (tile << 4 | variant), -1 for non-conv / untuned ops. */
 int bsy_plan_get_tuning(bsy_plan* p, int32_t* out, int n_ops);
+/* HOST array valid[n_ops]: 1 = the configuration preset for op i can run the op's shape, 0 = it cannot (bsy_plan_run would fall back to
+ * the heuristic configuration -- an id from a stale or foreign tune cache), -1 = not a conv op or not preset.  Launches nothing; `ext` as
+ * for bsy_plan_run.  bs_yolo_amd/engine.py drops the entries reported 0 from its tune cache before timing. */
+int bsy_plan_check_tuning(bsy_plan* p, void* const* ext, int n_ext, int32_t* valid, int n_ops);
 /* HOST array out[n_ops]: the rank-th runner-up (1 or 2) of the last bsy_plan_autotune per op (-1: none within 12 % of the winner).  The
  * host side re-times winner and runners-up in place with bsy_plan_profile and keeps the fastest (bs_yolo_amd/engine.py). */
 int bsy_plan_get_tuning_alt(bsy_plan* p, int rank, int32_t* out, int n_ops);

@@ -1591,6 +1591,41 @@ def test_engine_memory_and_tuning_stay_bounded_over_rect_shapes():
     eng.close()
 
 
+def test_engine_drops_presets_that_do_not_fit_the_shape(tmp_path, monkeypatch):
+    """configuration ids that reach a plan from the tune file (or the similar-size family cache) and cannot run the
+    op's shape are removed from the caches and timed afresh -- they must not be persisted.  A patch-kernel id (3x3 only) is written
+    for every conv shape of a YOLO11n forward; the 1x1 / stride-2 layers cannot take it."""
+    import json
+    cfg = stock_cfg("yolo11", "n", 80, "detect")
+    P = R.synth_params(R.Model("yolo11", "n", 80, "detect"), 0)
+    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(3)).half().to(DEV)
+    ref = YoloEngine(cfg, P, autotune=False)
+    y_ref, _ = ref(x)
+    plan, _ = ref.plan_for(2, 96, 128, torch.float16, torch.float16)
+    sigs = sorted({sg for sg in plan.conv_sigs if sg is not None})
+    ref.close()
+    f = tmp_path / "tune.json"
+    json.dump([[list(sg), 0xb2] for sg in sigs], open(f, "w"))
+    monkeypatch.setenv("BSY_TUNE_CACHE", str(f))
+    eng = YoloEngine(cfg, P)
+    y, _ = eng(x)
+    assert torch.equal(y, y_ref)
+    bad = eng.tune_stats.get("invalid_presets", 0)
+    assert 0 < bad, eng.tune_stats
+    assert eng.tune_stats["timed_ops"] >= 1
+    plan, h = eng.plan_for(2, 96, 128, torch.float16, torch.float16)
+    import ctypes as C
+    from bs_yolo_amd import lib as L
+    ext, n = eng._ext(x, y, [None, None, None], None)
+    valid = (C.c_int32 * len(plan.ops))()
+    L.check(L.lib.bsy_plan_check_tuning(h, ext, n, valid, len(plan.ops)))
+    assert 0 not in list(valid) and 1 in list(valid)
+    stored = {tuple(k): v for k, v in json.load(open(f))}
+    kept = [sg for sg in sigs if stored.get(sg) == 0xb2]
+    assert len(kept) < len(sigs)  # the ids that did not fit were replaced by timed winners in the file too
+    eng.close()
+
+
 def test_engine_splits_batches_by_the_largest_view():
     """the automatic batch split must size by the largest activation view (YOLOv8 C2f concat buffers), not by the
     first conv's output."""
