@@ -65,6 +65,8 @@ class WRec:
     coef: Tuple[float, float, float] = (0.0, 0.0, 0.0)  # ela: sigmoid(ch_weight / sp_weight / res_weight), set when packed
     real_cout: int = 0                 # the module's own output / input channels where the op runs on a width padded to a multiple of 8
     real_cin: int = 0                  # (Detect's class branch with nc-dependent widths, head.py:39): zero weights in the padding; 0 = as cout / cin
+    rows: Optional[List[int]] = None   # op output channel i takes the module's output channel rows[i] (-1: a zero channel, weights and bias 0);
+    cols: Optional[List[int]] = None   # op input channel j is the module's input channel cols[j] (-1: zero weights) -- PMSFA on padded pieces
     w_off: int = -1
     b_off: int = -1
 
@@ -158,7 +160,8 @@ class Plan:
     def conv(self, name: str, src: Union[T, Sequence[T]], cout: int, k: int = 1, s: int = 1, act: bool = True,
              dst: Optional[T] = None, res: Optional[T] = None, plain: bool = False, out_f32: bool = False,
              perm: Optional[List[int]] = None, name2: Optional[str] = None, wkind: Optional[str] = None,
-             wshape: Optional[Tuple[int, int, int]] = None, real: Tuple[int, int] = (0, 0)) -> T:
+             wshape: Optional[Tuple[int, int, int]] = None, real: Tuple[int, int] = (0, 0),
+             rows: Optional[List[int]] = None, cols: Optional[List[int]] = None) -> T:
         """name2: a second Conv module of the same input and kernel whose output channels follow this one's (weights.py
         kind "conv2": the two folded weight matrices stacked along cout) -- one launch for both, cout = the total."""
         srcs = [src] if isinstance(src, T) else list(src)
@@ -179,7 +182,7 @@ class Plan:
         else:
             wc, wi, wk = wshape or (cout, cin, k)  # wshape: the module's own weight shape where the op runs a re-laid-out copy
             key = self._wrec(name, name=name, kind=wkind or ("plain" if plain else "conv"), cout=wc, cin=wi, k=wk, perm=perm,
-                             real_cout=real[0], real_cin=real[1])
+                             real_cout=real[0], real_cin=real[1], rows=rows, cols=cols)
         self.ops.append(dict(kind=L.OP_CONV, H=H, W=W, OH=OH, OW=OW, src0=srcs[0],
                              src1=srcs[1] if len(srcs) > 1 else None, dst=dst, res=res, ksize=k, stride=s, pad=p,
                              act=int(act), out_f32=int(out_f32), wkey=key, dst_scale=1, name=name, lane=self._lane, cout=cout,
@@ -219,7 +222,7 @@ class Plan:
         return dst
 
     def dwconv_g(self, name: str, src: T, kh: int, kw: int, s: int, act_c: int, dst: Optional[T] = None, kind: str = "dwg",
-                 post: Optional[str] = None) -> T:
+                 post: Optional[str] = None, rows: Optional[List[int]] = None, real_c: int = 0) -> T:
         """Depthwise kh x kw conv with "same" padding (csrc/bsyolo_ops.hip); SiLU on the first act_c channels.
         kind: "dwg" (Conv + BN), "dwg_plain" (bare nn.Conv2d with bias), "dwg_ext" (PMSFA.conv3, see pmsfa())."""
         assert not src.up and src.f32 == self.f32_mode
@@ -227,7 +230,7 @@ class Plan:
         if dst is None:
             dst = self.alloc(src.C, OH, OW)
         assert dst.C == src.C and dst.H == OH and dst.W == OW
-        key = self._wrec(name, name=name, kind=kind, cout=src.C, cin=1, k=kh, kw=kw, post=post)
+        key = self._wrec(name, name=name, kind=kind, cout=src.C, cin=1, k=kh, kw=kw, post=post, rows=rows, real_cout=real_c)
         self.ops.append(dict(kind=L.OP_DWCONV_G, H=src.H, W=src.W, OH=OH, OW=OW, src0=src, dst=dst, ksize=kh, pad=kw, stride=s,
                              act=int(act_c), wkey=key, heads=src.C, key_dim=0, name=name, lane=self._lane))
         self.flops += 2 * self.B * OH * OW * src.C * kh * kw
@@ -329,12 +332,32 @@ class Plan:
         cat([conv3_out, conv2_out_2, conv1_out_2]) and adds x."""
         c = x.C
         assert dst.C == c
+        if c % 4:  # the reference's constructor needs it too (Conv(inc // 4, inc // 4, 7, g=inc // 4) on half of a half)
+            raise NotImplementedError(f"PMSFA width {c}: must be a multiple of 4")
+        if c % 8 and not self.f32_mode:  # the fp16 conv kernels read their sources in 8-channel pieces (so do the blocks around a PMSFA)
+            raise NotImplementedError(f"PMSFA width {c}: must be a multiple of 8 on the fp16 path")
         if c % 16:
-            raise NotImplementedError(f"PMSFA width {c}: must be a multiple of 16 (8-channel pieces of its halves)")
+            return self._pmsfa_padded(name, x, dst)
         P = self.conv(name + ".conv1", x, c, 3, 1)
         Q = self.dwconv_g(name + ".conv2", P.slice(0, c // 2), 5, 5, 1, c // 2)
         S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, c // 4, kind="dwg_ext")
         self.conv(name + ".conv4", [S, P.slice(c // 2, c // 2)], c, 1, 1, dst=dst, res=x)
+
+    def _pmsfa_padded(self, name: str, x: T, dst: T):
+        """PMSFA on a width that is not a multiple of 16: the depthwise kernels work on 8-channel pieces, so the three pieces of
+        conv1's output -- p1a, p1b (the halves of the depthwise 5x5's input) and p2 -- each start at a multiple of 8: conv1 writes
+        P' = [p1a 0.. | p1b 0.. | p2 0..] (weights.py `rows`: zero weights and bias in the padding, so the padding channels are
+        SiLU(0) = 0 and stay 0 through the depthwise convs), and conv4 reads [S' | p2'] with zero weights on the padding (`cols`).
+        The real channels see exactly the reference's arithmetic."""
+        c = x.C
+        q, h = c // 4, c // 2
+        Q8, H8 = make_divisible(q, 8), make_divisible(h, 8)
+        pad = lambda real, width, base: [base + i if i < real else -1 for i in range(width)]
+        lay = pad(q, Q8, 0) + pad(q, Q8, q) + pad(h, H8, h)           # P' channel -> conv1 output channel
+        P = self.conv(name + ".conv1", x, len(lay), 3, 1, rows=lay, real=(c, 0))
+        Q = self.dwconv_g(name + ".conv2", P.slice(0, 2 * Q8), 5, 5, 1, 2 * Q8, rows=pad(q, Q8, 0) + pad(q, Q8, q), real_c=h)
+        S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, Q8, kind="dwg_ext", rows=pad(q, Q8, 0), real_c=q)
+        self.conv(name + ".conv4", [S, P.slice(2 * Q8, H8)], c, 1, 1, dst=dst, res=x, cols=lay, real=(0, c))
 
     def c3k_gai(self, name: str, x: T, dst: T, n: int):
         """block.py:3079-3086: C3 (cv3(cat(m(cv1 x), cv2 x))) with m = n x PMSFA(c_)."""

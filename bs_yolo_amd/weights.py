@@ -69,7 +69,22 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f3
         w, b = torch.cat([w, w2]), torch.cat([b, b2])
     else:
         w, b = fold_conv_bn(sd, r.name, eps)
-    if r.real_cout or r.real_cin:
+    if r.rows is not None or r.cols is not None:
+        # the op's channels are a re-laid-out, zero-padded copy of the module's (plan.py _pmsfa_padded)
+        dw = w.shape[1] == 1 and r.kind in ("dw", "dwg", "dwg_plain", "dwg_ext")
+        if r.rows is not None:
+            idx = torch.as_tensor(r.rows, dtype=torch.long)
+            assert int(idx.max()) < w.shape[0], (r.name, tuple(w.shape), int(idx.max()))
+            w2, b2 = torch.zeros(len(idx), *w.shape[1:]), torch.zeros(len(idx))
+            w2[idx >= 0], b2[idx >= 0] = w[idx[idx >= 0]], b[idx[idx >= 0]]
+            w, b = w2, b2
+        if r.cols is not None and not dw:
+            idx = torch.as_tensor(r.cols, dtype=torch.long)
+            assert int(idx.max()) < w.shape[1], (r.name, tuple(w.shape), int(idx.max()))
+            w2 = torch.zeros(w.shape[0], len(idx), *w.shape[2:])
+            w2[:, idx >= 0] = w[:, idx[idx >= 0]]
+            w = w2
+    elif r.real_cout or r.real_cin:
         # the op runs wider than the module (plan.py detect(): widths padded to a multiple of 8): zero weights and biases in the padding
         dw = w.shape[1] == 1 and r.kind in ("dw", "dwg", "dwg_plain", "dwg_ext")
         co, ci = r.real_cout or r.cout, (1 if dw else (r.real_cin or r.cin))
@@ -191,7 +206,7 @@ def synth_state_dict(plan: Plan, seed: int = 0, cls_gain: float = 0.1, cls_bias:
             continue
         if r.kind in ("dwg", "dwg_ext"):
             kh, kw = r.k, r.kw or r.k
-            co = r.cout // 2 if r.kind == "dwg_ext" else r.cout
+            co = r.real_cout or (r.cout // 2 if r.kind == "dwg_ext" else r.cout)
             sd[r.name + ".conv.weight"] = torch.randn(co, 1, kh, kw, generator=g) * (2.0 / (kh * kw)) ** 0.5
             sd[r.name + ".bn.weight"] = torch.rand(co, generator=g) * 0.6 + 0.7
             sd[r.name + ".bn.bias"] = torch.rand(co, generator=g) * 0.6 - 0.3

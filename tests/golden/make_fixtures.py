@@ -278,6 +278,13 @@ def bsyolo_module_fixtures():
     # widths that are not multiples of 16 (round 2): GroupNorm(max(1, c // 16), c) -> 2 groups of 20, 1 group of 24
     add("ela40", RefELA(40), rnd(2, 40, 7, 9), ["ELA", 40])
     add("ela24", RefELA(24), rnd(1, 24, 6, 5), ["ELA", 24])
+    # PMSFA widths that are not multiples of 16 (round 3): halves of 12 / 6 / 4, quarters of 6 / 3 / 2 channels; C3k2_gai with c3k=True
+    # nests PMSFA(c / 2) inside C3k_gai
+    add("pmsfa24", rb.PMSFA(24), rnd(2, 24, 9, 11), ["PMSFA", 24])
+    add("pmsfa12", rb.PMSFA(12), rnd(1, 12, 7, 8), ["PMSFA", 12])
+    add("pmsfa8", rb.PMSFA(8), rnd(2, 8, 6, 6), ["PMSFA", 8])
+    add("c3k2_gai_f24", rb.C3k2_gai(24, 48, 1, False, 0.5), rnd(1, 24, 10, 8), ["C3k2_gai", 24, 48, 1, False, 0.5])
+    add("c3k2_gai_t24", rb.C3k2_gai(48, 48, 1, True), rnd(1, 48, 8, 8), ["C3k2_gai", 48, 48, 1, True])
     out["cases"] = json.dumps(cases)
     np.savez_compressed(HERE / "modules_bsyolo.npz", **out)
     print("wrote bsyolo modules", len(cases), "cases")

@@ -1889,6 +1889,51 @@ def test_engine_top_level_dwconv_layers_match_oracle():
             d_.pop(fam, None)
 
 
+def test_engine_pmsfa_on_widths_that_are_not_multiples_of_16():
+    """`PMSFA` (block.py:3035-3054) on 24 and 8 channels -- halves of 12 / 4, quarters of 6 / 2 -- inside C3k2_gai blocks (c3k False:
+    PMSFA(c); c3k True: C3k_gai with two PMSFA(c / 2), block.py:3079-3095) in a graph of its own through the engine, both precisions,
+    against the oracle (pinned for these widths by modules_bsyolo.npz: pmsfa24 / pmsfa12 / pmsfa8 / c3k2_gai_f24 / _t24).  The plan lays
+    conv1's output out in 8-channel-aligned zero-padded pieces (plan.py _pmsfa_padded).  Width 12 (a C3k_gai of 24 channels) runs in
+    the fp32 mode only: the fp16 conv kernels read 8-channel pieces, so the blocks around such a PMSFA are not on the fp16 path either."""
+    fam = "t_pmsfa"
+
+    def graphs(c3k_width):
+        rows = [(-1, 1, "Conv", (24, 3, 2)), (-1, 1, "C3k2_gai", (48, False, 0.5)), (-1, 1, "Conv", (48, 3, 2)),
+                (-1, 1, "C3k2_gai", (c3k_width, True)), (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "C3k2_gai", (32, False, 0.25))]
+        cfg = {"nc": 12, "scale": "n", "scales": {"n": [1.0, 1.0, 1024]}, "backbone": [[f, n, t, list(a)] for f, n, t, a in rows],
+               "head": [[[1, 3, 5], 1, "Detect", ["nc"]]]}
+        return rows, cfg
+
+    R.SCALES[fam] = {"n": (1.0, 1.0, 1024)}
+    R.HEAD_FROM[fam] = (1, 3, 5)
+    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(7))
+    try:
+        for c3k_width, fp16 in ((48, False), (96, True)):  # C3k_gai(24) -> PMSFA(12): fp32 mode only; C3k_gai(48) -> PMSFA(24)
+            R.GRAPHS[fam], cfg = graphs(c3k_width)
+            m = R.Model(fam, "n", 12, "detect")
+            P = R.synth_params(m, 7)
+            with torch.inference_mode():
+                yref, rref = m.forward(P, x)
+            e32 = YoloEngine(cfg, P, precision="fp32")
+            y32, r32 = e32(x.to(DEV))
+            assert float((y32.cpu()[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3 and float((y32.cpu()[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 128
+            e32.close()
+            if not fp16:
+                with pytest.raises(NotImplementedError):
+                    YoloEngine(cfg, P)(x.half().to(DEV))
+                continue
+            e16 = YoloEngine(cfg, P)
+            y16, _ = e16(x.half().to(DEV))
+            d = (y16.float().cpu() - yref).abs()
+            assert float(d[:, 4:].max()) < 1e-2 and float(d[:, :4].max()) < 1.0, (float(d[:, 4:].max()), float(d[:, :4].max()))
+            plan = e16.plan_for(2, 96, 128, torch.float16, torch.float16)[0]
+            assert sum(1 for r in plan.wrecs.values() if r.rows is not None) == 12 and sum(1 for r in plan.wrecs.values() if r.cols is not None) == 4
+            e16.close()
+    finally:
+        for d_ in (R.GRAPHS, R.SCALES, R.HEAD_FROM):
+            d_.pop(fam, None)
+
+
 def test_engine_ela_on_widths_that_are_not_multiples_of_16():
     """`ELA` (nn/Addmodules/ELA.py:33-101) on 24 and 40 channels -- GroupNorm(max(1, c // 16), c) = one group of 24, two of 20 -- in a
     graph of its own through the engine, both precisions, against the oracle (pinned for these widths by modules_bsyolo.npz)."""
