@@ -169,6 +169,10 @@ class Plan:
         H, W = srcs[0].H, srcs[0].W
         assert all(t.H == H and t.W == W and (t.f32 == self.f32_mode) for t in srcs)
         cin = sum(t.C for t in srcs)
+        if not self.f32_mode and any(t.C % 8 or t.coff % 8 for t in srcs):
+            # csrc/conv_mfma.hip reads its sources in 16-byte (8-channel) pieces; a block whose hidden width is 12 or 20 channels
+            # (a C2f / C3k2 of 24 or 40) is refused here rather than at the first launch
+            raise NotImplementedError(f"{name}: source channels / offsets {[(t.C, t.coff) for t in srcs]} are not multiples of 8 (fp16 path)")
         p = k // 2
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         if dst is None:
@@ -270,8 +274,17 @@ class Plan:
                                  mfma_flops=2 * self.B * x.H * x.W * 9 * 2 * c_ * x.C))
             self.flops += 2 * self.B * x.H * x.W * 9 * 2 * c_ * x.C
             return
+        res = x if (shortcut and x.C == dst.C) else None
+        if c_ % 8 and not self.f32_mode:
+            # hidden width 4 / 12 / 20 (a C3k2 of 16 / 48 / 80 channels with e = 0.25 x 0.5, e.g. YOLO11 at width 0.125 / 0.375): the
+            # hidden map is carried on the next multiple of 8 with zero weights and bias in the padding (weights.py real_cout /
+            # real_cin, as Detect's class branch does for nc-dependent widths) -- SiLU(0) = 0 there, the real channels are unchanged
+            c8 = make_divisible(c_, 8)
+            t = self.conv(name + ".cv1", x, c8, k[0], 1, real=(c_, 0))
+            self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=res, real=(0, c_))
+            return
         t = self.conv(name + ".cv1", x, c_, k[0], 1)
-        self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=x if (shortcut and x.C == dst.C) else None)
+        self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=res)
 
     def c3k(self, name: str, x, dst: T, n: int, shortcut: bool, k=(3, 3)):
         """block.py:3320-3334 + :3807-3815: cv3(cat(m(cv1 x), cv2 x)), m = n x Bottleneck(c_, c_, k=(3,3), e=1); C3 itself
