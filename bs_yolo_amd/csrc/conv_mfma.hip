@@ -908,7 +908,7 @@ static int launch_persist(const ConvK& k, hipStream_t s) {
 // of the next steps and are accounted for in the counted waits (a wait for K-step g sees the stores of the previous tile as younger
 // operations during the first STAGES - 1 steps of a tile).
 // Same K order and epilogue arithmetic as the other 1x1 kernels: the same bits.
-// Restrictions (conv_cfg_valid): as the persistent kernel, and K NT <= 512 (A fragments: at most 128 VGPRs).
+// Restrictions (conv_cfg_valid): as the persistent kernel, and K / 16 x NT <= 32 fragments at NT = 1, 24 at NT = 2 (more spills).
 // ---------------------------------------------------------------------------------------------------------------------
 // NFR = A fragments held per wave (K / 16 x NT <= NFR): 32 = 128 VGPRs
 template <int NT, int STAGES, int NFR>
@@ -1668,7 +1668,8 @@ bool conv_cfg_valid(const ConvArgs& a, int cfg) {
     if (tile >= 14) {  // weights-resident streaming 1x1 kernel (14: 128-cout tiles, 15: 64-cout tiles; variant 1: 4-stage pixel ring, 2: 3 stages)
         const int K = Cin, nt = tile == 14 ? 2 : 1, stages = var == 1 ? 4 : 3;
         return a.ksize == 1 && a.stride == 1 && (var == 1 || var == 2) && !(Cin & 31) && !(a.C0 & 31) && !a.out_f32 && !a.res && !(a.Cout & 7) &&
-               !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 && nt * (K / 16) <= 32 && K / 32 >= stages - 1 &&
+               !(a.ldd & 7) && !((uintptr_t)a.dst & 15) && a.dst_scale <= 1 && nt * (K / 16) <= (nt == 2 ? 24 : 32) && K / 32 >= stages - 1 &&  // (128-cout tiles with 32 fragments spill: not built)
+              
                (tile == 14 ? a.Cout > 64 : true);
     }
     if (a.epi == 3 && tile != 1) return false;      // DFL needs all 64 box couts in one wave: the 256 x 64 tile (4 x 1 waves, NT 2)
@@ -1821,8 +1822,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         if (k.tail_wgt) return launch_patch<1, 2, 2, 16, true>(k, s);                     \
         if (tile >= 14) {                                                                 \
             const int fr = (tile == 14 ? 2 : 1) * (Cin / 16);                             \
-            if (tile == 14 && var == 1) { if (fr <= 16) return launch_wres<2, 4, 16>(k, s); if (fr <= 24) return launch_wres<2, 4, 24>(k, s); return launch_wres<2, 4, 32>(k, s); } \
-            if (tile == 14) { if (fr <= 16) return launch_wres<2, 3, 16>(k, s); if (fr <= 24) return launch_wres<2, 3, 24>(k, s); return launch_wres<2, 3, 32>(k, s); } \
+            if (tile == 14 && var == 1) { if (fr <= 16) return launch_wres<2, 4, 16>(k, s); return launch_wres<2, 4, 24>(k, s); } \
+            if (tile == 14) { if (fr <= 16) return launch_wres<2, 3, 16>(k, s); return launch_wres<2, 3, 24>(k, s); } \
             if (var == 1) { if (fr <= 16) return launch_wres<1, 4, 16>(k, s); return launch_wres<1, 4, 32>(k, s); } \
             if (fr <= 16) return launch_wres<1, 3, 16>(k, s);                             \
             return launch_wres<1, 3, 32>(k, s);                                           \

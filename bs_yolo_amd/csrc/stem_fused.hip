@@ -43,8 +43,9 @@ struct StemK {
     unsigned magic_x, magic_y;  // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y): exact quotients for tile < 2^32 / divisor
 };
 
+// f32 images: the prefetched patch items are twice as wide; at three workgroups per CU (168 VGPRs) the kernel spilled 13 registers -> two
 template <typename T, int C0, int C1>
-__global__ __launch_bounds__(256, 3) void stem_fused_kernel(const StemK p) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 3) void stem_fused_kernel(const StemK p) {
     constexpr int NCH = C0 / 8;               // 16-byte chunks per layer-0 patch entry
     constexpr int KS1 = (9 * C0 + 15) / 16;   // layer-1 K sub-steps (16 wide)
     constexpr int NH = C1 / 32;               // layer-1 cout tiles; waves 0 .. 2*NH-1 compute layer 1
@@ -205,7 +206,8 @@ bool stem_fused_supported(int C0, int C1, int H, int W) {
 
 template <typename T>
 static int launch_t(const StemArgs& a, const StemK& k, hipStream_t s) {
-    const int grid = k.ntiles < 768 ? k.ntiles : 768;  // 3 workgroups per CU (register-limited: a fourth needs <= 128 VGPRs and spills 61), tiles dealt round-robin
+    const int slots = sizeof(T) == 4 ? 512 : 768;      // 3 workgroups per CU (register-limited: a fourth needs <= 128 VGPRs and spills 61; f32 images: 2), tiles dealt round-robin
+    const int grid = k.ntiles < slots ? k.ntiles : slots;
     if (a.C0 == 32) hipLaunchKernelGGL((stem_fused_kernel<T, 32, 64>), dim3(grid), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((stem_fused_kernel<T, 16, 32>), dim3(grid), dim3(256), 0, s, k);
     HIP_TRY(hipGetLastError());

@@ -242,7 +242,7 @@ PERSIST_CASES = [
     (70, 40, 40, 96, 64, 0x91), (33, 37, 41, 32, 72, 0x92), (9, 80, 80, 192, 64, 0x93),
     (17, 33, 47, 96, 512, 0x82),                                                             # 4 cout tiles per pixel tile
     # tiles 14 / 15 = weights-resident streaming 1x1 kernel (128 x 128 / 128 x 64 tiles; variant 1: 4-stage pixel ring, 2: 3 stages)
-    (70, 40, 40, 128, 128, 0xe1), (70, 40, 40, 192, 256, 0xe2), (33, 37, 41, 96, 72, 0xe1), (9, 80, 80, 256, 256, 0xe1),
+    (70, 40, 40, 128, 128, 0xe1), (70, 40, 40, 192, 256, 0xe2), (33, 37, 41, 96, 72, 0xe1), (9, 80, 80, 256, 256, 0xf1),           # (K = 256 on the 128-cout tile would need 32 fragments: not built)
     (70, 40, 40, 512, 128, 0xf1), (33, 37, 41, 128, 72, 0xf2), (3, 7, 5, 128, 64, 0xf1), (300, 16, 16, 160, 136, 0xe2),
 ]
 

@@ -487,7 +487,8 @@ def test_isa_has_no_packed_f32():
     bad, n, scratch = isa_scan.scan()
     assert n >= 130, f"only {n} kernels found: the disassembly failed"
     assert not bad, f"packed f32 arithmetic in {bad}"
-    conv_scratch = [k for k in scratch if "conv_mfma_kernel" in k or "conv3x3_patch" in k or "conv1x1_persist" in k or "c3k2_fused" in k or "bneck_fused" in k]
+    fam = ("conv_mfma_kernel", "conv3x3_patch", "conv1x1_persist", "conv1x1_wres", "c3k2_fused", "bneck_fused", "stem_fused", "dwpw_fused", "conv_first_mfma")
+    conv_scratch = [k for k in scratch if any(f in k for f in fam)]
     assert not conv_scratch, f"scratch frames in {conv_scratch}"
 
 
