@@ -388,62 +388,77 @@ __device__ __forceinline__ f32x2 msca_round2(f32x2 a, half2_t& o) {  // f16 roun
 #define MSCA_NTAP 113
 __device__ __constant__ const int MSCA_TAP0[9] = {0, 25, 30, 35, 42, 49, 60, 71, 92};
 
-// (Measured alternatives, same results, all slower than this form's 0.23 ms at 20 x 20 x 512, B = 64: zero-bordered slabs
-// without bounds tests -- 72 KiB of LDS, two workgroups per CU instead of three: 0.25 ms; 512 threads with two pixels in
-// flight per thread: 0.29 ms; eight channels per thread on f16 slabs: 0.26 ms.  The kernel is bound by its ~50 barriers
-// and the dependent FMA chains of the reference's summation order, not by instruction count.)
+// (Round-2 alternatives of the one-output-per-thread form, same results, all slower than its 0.23 ms at 20 x 20 x 512, B = 64:
+// zero-bordered slabs without bounds tests -- 72 KiB of LDS, two workgroups per CU instead of three: 0.25 ms; 512 threads with two
+// pixels in flight per thread: 0.29 ms; eight channels per thread on f16 slabs: 0.26 ms.)
 #define MSCA_SP_MAXPIX 1890  // (16 + 32 + 32) B x H*W + 8 KiB of reduction scratch + 4 KiB of weights <= 160 KiB of LDS
 
-// One strip-conv branch: st = rows(sa) (1 x K), branch = cols(st) (K x 1) -> HBM; gs[m] = this thread's share of
-// gap_kernel's partial sum number slot + 64 m (pixels q with q % 256 == slot + 64 m, ascending).
+// One strip-conv branch: st = rows(sa) (1 x K), branch = cols(st) (K x 1) -> HBM and, as f16, into the dead x slab (the mean
+// reads it back).  Round 3: a thread computes MSCA_RUN consecutive outputs along the conv's axis from a register window of
+// MSCA_RUN + K - 1 inputs -- 6 LDS reads and 6 bounds tests per output of the 21-tap strips instead of 21 of each (the one-output
+// form took 0.24 ms at 20 x 20 x 512, B = 64, 6 x its FMA issue time).  Each output still sums bias first, then its taps in
+// ascending order, one FMA per tap (taps outside the map multiply a zero, as before): the same bits.
+#define MSCA_RUN 7
 template <int K, int T0>
-__device__ __forceinline__ void msca_branch(const MscaSpK& p, int bi, const f32x2* sa, f32x2* st, const f32x2* sw, int c2,
-                                            int n, int slot, int pr, int y0, int x0, int sy, int sx_, f32x2 (&gs)[4]) {
-    constexpr int R = K / 2;
-    const int H = p.H, W = p.W, HW = p.HW;
-    {
+__device__ __forceinline__ void msca_branch(const MscaSpK& p, int bi, const f32x2* sa, f32x2* st, const f32x2* sw, half2_t* sx, int c2,
+                                            int n, int tid) {
+    constexpr int R = K / 2, NWIN = MSCA_RUN + K - 1;
+    const int H = p.H, W = p.W, HW = p.HW, pr = tid & 3;
+    {   // rows: task = (y, run of MSCA_RUN columns); consecutive threads = consecutive runs of a row
         f32x2 wr[K];
 #pragma unroll
         for (int t = 0; t < K; ++t) wr[t] = sw[(T0 + t) * 4 + pr];
         const f32x2 br = sw[(MSCA_NTAP + 1 + 2 * bi) * 4 + pr];
-        int y = y0, x = x0;
-        for (int q = slot; q < HW; q += 64) {
-            f32x2 acc = br;
+        const int runs = (W + MSCA_RUN - 1) / MSCA_RUN, ntask = H * runs;
+        for (int t = tid >> 2; t < ntask; t += 64) {
+            const int y = t / runs, x0 = (t - y * runs) * MSCA_RUN;
+            const f32x2* row = sa + (size_t)(y * W) * 4 + pr;
+            f32x2 win[NWIN];
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) {
-                const int ix = x + dx - R;
-                const f32x2 v = (unsigned)ix < (unsigned)W ? sa[(q + dx - R) * 4 + pr] : f32x2{0.f, 0.f};
-                acc = msca_fma2(v, wr[dx], acc);
+            for (int jx = 0; jx < NWIN; ++jx) {
+                const int ix = x0 + jx - R;
+                win[jx] = (unsigned)ix < (unsigned)W ? row[ix * 4] : f32x2{0.f, 0.f};
             }
-            half2_t o;
-            st[q * 4 + pr] = msca_round2(acc, o);
-            x += sx_; y += sy;
-            if (x >= W) { x -= W; ++y; }
+#pragma unroll
+            for (int o = 0; o < MSCA_RUN; ++o) {
+                f32x2 acc = br;
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) acc = msca_fma2(win[o + dx], wr[dx], acc);
+                half2_t h;
+                const f32x2 r = msca_round2(acc, h);
+                if (x0 + o < W) st[(size_t)(y * W + x0 + o) * 4 + pr] = r;
+            }
         }
     }
     __syncthreads();
-    {
+    {   // columns: task = (run of MSCA_RUN rows, x); consecutive threads = consecutive columns
         f32x2 wc[K];
 #pragma unroll
         for (int t = 0; t < K; ++t) wc[t] = sw[(T0 + K + t) * 4 + pr];
         const f32x2 bc = sw[(MSCA_NTAP + 2 + 2 * bi) * 4 + pr];
-        int y = y0, x = x0, m = 0;
-        for (int q = slot; q < HW; q += 64, m = (m + 1) & 3) {
-            f32x2 acc = bc;
+        const int runs = (H + MSCA_RUN - 1) / MSCA_RUN, ntask = runs * W;
+        for (int t = tid >> 2; t < ntask; t += 64) {
+            const int yr = t / W, x = t - yr * W, y0 = yr * MSCA_RUN;
+            const f32x2* col = st + (size_t)x * 4 + pr;
+            f32x2 win[NWIN];
 #pragma unroll
-            for (int dy = 0; dy < K; ++dy) {
-                const int iy = y + dy - R;
-                const f32x2 v = (unsigned)iy < (unsigned)H ? st[(q + (dy - R) * W) * 4 + pr] : f32x2{0.f, 0.f};
-                acc = msca_fma2(v, wc[dy], acc);
+            for (int jy = 0; jy < NWIN; ++jy) {
+                const int iy = y0 + jy - R;
+                win[jy] = (unsigned)iy < (unsigned)H ? col[(size_t)iy * W * 4] : f32x2{0.f, 0.f};
             }
-            half2_t o;
-            const f32x2 r = msca_round2(acc, o);
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm)  // (m is not a compile-time index)
-                if (mm == m) { gs[mm][0] += r[0]; gs[mm][1] += r[1]; }
-            *reinterpret_cast<half2_t*>(p.br[bi] + ((size_t)n * HW + q) * p.ldb[bi] + c2) = o;
-            x += sx_; y += sy;
-            if (x >= W) { x -= W; ++y; }
+            for (int o = 0; o < MSCA_RUN; ++o) {
+                f32x2 acc = bc;
+#pragma unroll
+                for (int dy = 0; dy < K; ++dy) acc = msca_fma2(win[o + dy], wc[dy], acc);
+                half2_t h;
+                msca_round2(acc, h);
+                if (y0 + o < H) {
+                    const int q = (y0 + o) * W + x;
+                    sx[(size_t)q * 4 + pr] = h;
+                    *reinterpret_cast<half2_t*>(p.br[bi] + ((size_t)n * HW + q) * p.ldb[bi] + c2) = h;
+                }
+            }
         }
     }
 }
@@ -452,14 +467,12 @@ __global__ __launch_bounds__(256) void msca_spatial_kernel(const MscaSpK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char msca_smem[];
     f32x2* sa = reinterpret_cast<f32x2*>(msca_smem);                  // attn  [HW][4 pairs]
     f32x2* st = sa + (size_t)p.HW * 4;                                 // row-conv output
-    half2_t* sx = reinterpret_cast<half2_t*>(st + (size_t)p.HW * 4);  // x [HW][4 pairs]
+    half2_t* sx = reinterpret_cast<half2_t*>(st + (size_t)p.HW * 4);  // x [HW][4 pairs]; after conv0: the current branch map (f16)
     float(*red)[8] = reinterpret_cast<float(*)[8]>(sx + (size_t)p.HW * 4);
     f32x2* sw = reinterpret_cast<f32x2*>(red + 256);                   // weight table [122][4 pairs]
     const int c = blockIdx.x * 8, n = blockIdx.y, tid = threadIdx.x;
     const int pr = tid & 3, slot = tid >> 2, c2 = c + 2 * pr;
     const int H = p.H, W = p.W, HW = p.HW, C = p.C;
-    // pixel walk of this thread: q = slot, slot + 64, ..  (one division per thread instead of one per pixel and phase)
-    const int y0 = slot / W, x0 = slot - y0 * W, sy = 64 / W, sx_ = 64 - sy * W;
 
     for (int q = tid; q < HW; q += 256)
         *reinterpret_cast<half8*>(sx + (size_t)q * 4) = *reinterpret_cast<const half8*>(p.src + ((size_t)n * HW + q) * p.lds + c);
@@ -477,54 +490,83 @@ __global__ __launch_bounds__(256) void msca_spatial_kernel(const MscaSpK p) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(sw) + row * 8 + h4) = *reinterpret_cast<const f32x4*>(g);
     }
     __syncthreads();
-    {   // attn = conv0(x): 5 x 5
+    {   // attn = conv0(x): 5 x 5; task = (y, run of MSCA_RUN columns), a 5 x (MSCA_RUN + 4) register window of f16 pairs
         f32x2 w0[25];
 #pragma unroll
         for (int t = 0; t < 25; ++t) w0[t] = sw[t * 4 + pr];
         const f32x2 b0 = sw[MSCA_NTAP * 4 + pr];
-        int y = y0, x = x0;
-        for (int q = slot; q < HW; q += 64) {
-            f32x2 acc = b0;
+        const int runs = (W + MSCA_RUN - 1) / MSCA_RUN, ntask = H * runs;
+        for (int t = slot; t < ntask; t += 64) {
+            const int y = t / runs, x0 = (t - y * runs) * MSCA_RUN;
+            f32x2 acc[MSCA_RUN];
+#pragma unroll
+            for (int o = 0; o < MSCA_RUN; ++o) acc[o] = b0;
 #pragma unroll
             for (int dy = 0; dy < 5; ++dy) {
                 const int iy = y + dy - 2;
+                const bool rowin = (unsigned)iy < (unsigned)H;
+                unsigned win[MSCA_RUN + 4];
 #pragma unroll
-                for (int dx = 0; dx < 5; ++dx) {
-                    const int ix = x + dx - 2;
+                for (int jx = 0; jx < MSCA_RUN + 4; ++jx) {
+                    const int ix = x0 + jx - 2;
                     union { half2_t h; unsigned u; } hv;
                     hv.u = 0u;
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv.h = sx[(q + (dy - 2) * W + dx - 2) * 4 + pr];
-                    acc[0] = fma_mix_lo(hv.u, w0[dy * 5 + dx][0], acc[0]);  // no convert + packed FMA here (common.h)
-                    acc[1] = fma_mix_hi(hv.u, w0[dy * 5 + dx][1], acc[1]);
+                    if (rowin && (unsigned)ix < (unsigned)W) hv.h = sx[(size_t)(iy * W + ix) * 4 + pr];
+                    win[jx] = hv.u;
                 }
+#pragma unroll
+                for (int o = 0; o < MSCA_RUN; ++o)
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx) {
+                        acc[o][0] = fma_mix_lo(win[o + dx], w0[dy * 5 + dx][0], acc[o][0]);  // no convert + packed FMA here (common.h)
+                        acc[o][1] = fma_mix_hi(win[o + dx], w0[dy * 5 + dx][1], acc[o][1]);
+                    }
             }
-            half2_t o;
-            sa[q * 4 + pr] = msca_round2(acc, o);
-            x += sx_; y += sy;
-            if (x >= W) { x -= W; ++y; }
+#pragma unroll
+            for (int o = 0; o < MSCA_RUN; ++o) {
+                half2_t h;
+                const f32x2 r = msca_round2(acc[o], h);
+                if (x0 + o < W) sa[(size_t)(y * W + x0 + o) * 4 + pr] = r;
+            }
         }
     }
-    __syncthreads();
+    __syncthreads();  // attn complete; x is dead: its slab takes the branch maps
     for (int i = 0; i < 4; ++i) {
+        if (i == 0) msca_branch<5, 25>(p, 0, sa, st, sw, sx, c2, n, tid);
+        else if (i == 1) msca_branch<7, 35>(p, 1, sa, st, sw, sx, c2, n, tid);
+        else if (i == 2) msca_branch<11, 49>(p, 2, sa, st, sw, sx, c2, n, tid);
+        else msca_branch<21, 71>(p, 3, sa, st, sw, sx, c2, n, tid);
+        __syncthreads();  // branch map complete in sx; every thread is done reading st
+        // gap_kernel's 256 strided partial sums (pixels q with q % 256 == slot + 64 m, ascending), then its pairwise tree
+        // red[t] += red[t + s], s = 128 .. 1, with the same operands in the same order but without its eight barriers: partial sums
+        // slot + 64 m of one thread meet in registers (s = 128: m with m + 2; s = 64: 0 with 1), s = 32 and 16 pair slots of different
+        // waves (one LDS exchange, read by wave 0), s = 8 .. 1 pair lanes of wave 0 (lane = 4 slot + pair).
         f32x2 gs[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-        if (i == 0) msca_branch<5, 25>(p, 0, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
-        else if (i == 1) msca_branch<7, 35>(p, 1, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
-        else if (i == 2) msca_branch<11, 49>(p, 2, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
-        else msca_branch<21, 71>(p, 3, sa, st, sw, c2, n, slot, pr, y0, x0, sy, sx_, gs);
+        int m = 0;
+        for (int q = slot; q < HW; q += 64, m = (m + 1) & 3) {
+            const half2_t h = sx[(size_t)q * 4 + pr];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {  // gap_kernel's 256 strided partial sums, then its tree
-            red[slot + 64 * m][2 * pr] = gs[m][0];
-            red[slot + 64 * m][2 * pr + 1] = gs[m][1];
+            for (int mm = 0; mm < 4; ++mm)  // (m is not a compile-time index)
+                if (mm == m) { gs[mm][0] += (float)h[0]; gs[mm][1] += (float)h[1]; }
         }
-        __syncthreads();  // also: every thread is done reading st
-        for (int s2 = 128; s2 > 0; s2 >>= 1) {
-            if (tid < s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) red[tid][j] += red[tid + s2][j];
-            __syncthreads();
-        }
-        if (tid < 8) p.gap[i][(size_t)n * p.ldg[i] + c + tid] = (half_t)(red[0][tid] / (float)HW);
+        float v0 = (gs[0][0] + gs[2][0]) + (gs[1][0] + gs[3][0]), v1 = (gs[0][1] + gs[2][1]) + (gs[1][1] + gs[3][1]);
+        red[slot][2 * pr] = v0;
+        red[slot][2 * pr + 1] = v1;
         __syncthreads();
+        if (tid < 64) {  // slots 0 .. 15
+            v0 = (red[slot][2 * pr] + red[slot + 32][2 * pr]) + (red[slot + 16][2 * pr] + red[slot + 48][2 * pr]);
+            v1 = (red[slot][2 * pr + 1] + red[slot + 32][2 * pr + 1]) + (red[slot + 16][2 * pr + 1] + red[slot + 48][2 * pr + 1]);
+#pragma unroll
+            for (int d = 32; d >= 4; d >>= 1) {
+                v0 += __shfl_down(v0, d, 64);
+                v1 += __shfl_down(v1, d, 64);
+            }
+            if (tid < 4) {
+                p.gap[i][(size_t)n * p.ldg[i] + c2] = (half_t)(v0 / (float)HW);
+                p.gap[i][(size_t)n * p.ldg[i] + c2 + 1] = (half_t)(v1 / (float)HW);
+            }
+        }
+        __syncthreads();  // red and sx are free for the next branch
     }
 }
 
