@@ -148,13 +148,13 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const half_t* __restric
 // 4 + K - 1 LDS reads per kernel row.  Arithmetic = dwconv_win_kernel's, step for step (bias first, taps in (dy, dx) order as
 // f32 FMAs on the f16 inputs): the same bits.
 // ---------------------------------------------------------------------------------------------------------------------
-#define DWT_TH 8
-template <int K, int NCH>
+// TH = tile rows: 8 (TW = 128 / NCH pixels wide), or 16 for a single chunk (16 x 64 instead of 8 x 128: a 160-wide map is 3 tiles of 64, not 2 of 128)
+template <int K, int NCH, int DWT_TH>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const half_t* __restrict__ src, int lds_, int H, int W, int C,
                                                           const float* __restrict__ w, int wld, const float* __restrict__ bias,
                                                           half_t* __restrict__ dst, int ldd, int act_c, unsigned span, int tiles_x,
-                                                          int tiles_y, int ncg) {
-    constexpr int TW = 128 / NCH, PH = DWT_TH + K - 1, PW = TW + K - 1;
+                                                          int tiles_y, int ncg, int ident_c0) {
+    constexpr int TW = 1024 / (DWT_TH * NCH), PH = DWT_TH + K - 1, PW = TW + K - 1;
     constexpr int PXS = NCH * 8 + 8;            // halves per patch pixel: one 16-byte piece of padding spreads the window reads over the banks
     constexpr int NPIECE = PH * PW * NCH;
     constexpr int NWIN = 4 + K - 1;
@@ -181,8 +181,25 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const half_t* __restri
         const half8 v = bo_load16(rs, ok ? 2u * ((unsigned)((n * H + y) * W + x) * (unsigned)lds_ + (unsigned)(c0 + ch * 8)) : BO_OOB);
         *reinterpret_cast<half8*>(sp + (py * PW + px) * PXS + ch * 8) = v;
     }
+    if (ident_c0 > 0) {
+        // pass-through half (identity kernel: bias 0, centre tap 1): the tap loop returns fma(x, 1, +0) = x + 0, every other tap adds a
+        // signed zero to it -- written directly for this tile's pixels of the identity chunks ident_c0 / 8 + (this workgroup's chunks),
+        // pixel-contiguous across the threads (the launch's tiles cover the conv half's channels only)
+        for (int i = tid; i < DWT_TH * TW * NCH; i += 256) {
+            const int ch = i % NCH, px = (i / NCH) % TW, py = i / (NCH * TW);
+            const int y = oy0 + py, x = ox0 + px;
+            if (ch >= nch || y >= H || x >= W) continue;
+            const size_t pix = (size_t)(n * H + y) * W + x;
+            const int ci = ident_c0 + c0 + ch * 8;
+            const half8 v = *reinterpret_cast<const half8*>(src + pix * lds_ + ci);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)v[j] + 0.0f);
+            *reinterpret_cast<half8*>(dst + pix * ldd + ci) = o;
+        }
+    }
     __syncthreads();
-    // item = (tile row, group of 4 pixels, chunk): 8 x (TW / 4) x NCH = 256 items, one per thread
+    // item = (tile row, group of 4 pixels, chunk): TH x (TW / 4) x NCH = 256 items, one per thread
     const int ch = tid % NCH, gx = (tid / NCH) % (TW / 4), gy = tid / (NCH * (TW / 4));
     if (ch >= nch) return;
     float acc[4][8];
@@ -222,17 +239,19 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const half_t* __restri
 
 template <int K>
 static void launch_dw_tile(const DwGenArgs& a, unsigned span, hipStream_t s) {
-    const int nchunks = a.C / 8;
+    // identity-kernel half (ident_c0 = C / 2): tiles cover the conv half's chunks; each thread also copies its pixels of the other half
+    const bool ident = a.ident_c0 > 0 && 2 * a.ident_c0 == a.C && !(a.ident_c0 & 7) && a.act_c <= a.ident_c0;
+    const int nchunks = (ident ? a.ident_c0 : a.C) / 8;
     const int NCH = nchunks >= 4 ? 4 : (nchunks >= 2 ? 2 : 1);
-    const int TW = 128 / NCH;
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + DWT_TH - 1) / DWT_TH, ncg = (nchunks + NCH - 1) / NCH;
+    const int TH = NCH == 1 ? 16 : 8, TW = 1024 / (TH * NCH);
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH, ncg = (nchunks + NCH - 1) / NCH;
     const unsigned grid = (unsigned)((long long)a.B * tiles_y * tiles_x * ncg);
-#define DWT_GO(NCH_)                                                                                                          \
-    hipLaunchKernelGGL((dwconv_tile_kernel<K, NCH_>), dim3(grid), dim3(256), 0, s, a.src, a.lds, a.H, a.W, a.C, a.w, a.wld, a.b, \
-                       a.dst, a.ldd, a.act_c, span, tiles_x, tiles_y, ncg)
-    if (NCH == 4) DWT_GO(4);
-    else if (NCH == 2) DWT_GO(2);
-    else DWT_GO(1);
+#define DWT_GO(NCH_, TH_)                                                                                                        \
+    hipLaunchKernelGGL((dwconv_tile_kernel<K, NCH_, TH_>), dim3(grid), dim3(256), 0, s, a.src, a.lds, a.H, a.W, ident ? a.ident_c0 : a.C, a.w, a.wld, a.b, \
+                       a.dst, a.ldd, a.act_c, span, tiles_x, tiles_y, ncg, ident ? a.ident_c0 : 0)
+    if (NCH == 4) DWT_GO(4, 8);
+    else if (NCH == 2) DWT_GO(2, 8);
+    else DWT_GO(1, 16);
 #undef DWT_GO
 }
 

@@ -137,6 +137,8 @@ struct DwGenArgs {       // depthwise kh x kw, stride 1 / 2, "same" padding, + b
     const float* b;
     half_t* dst;
     int ldd, act_c;      // SiLU on channels [0, act_c) of this launch, identity on the rest
+    int ident_c0 = 0;    // > 0: channels [ident_c0, C) carry an identity kernel (centre tap 1, bias 0: PMSFA.conv3's pass-through half,
+                         // weights.py "dwg_ext") -- the tiled kernels write x + 0 for them, which is what the full tap loop returns
 };
 int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s);
 int launch_copy_view(const half_t* src, int lds_, int up, int B, int H, int W, int C, half_t* dst, int ldd, hipStream_t s);

@@ -439,6 +439,7 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             a.OH = op.OH; a.OW = op.OW; a.kh = op.ksize; a.kw = op.pad; a.stride = op.stride;
             a.wld = op.heads; a.w = (const float*)(wb + op.w_off) + op.key_dim; a.b = (const float*)(wb + op.b_off) + op.key_dim;
             a.dst = R.h(op.dst); a.ldd = op.dst.ld; a.act_c = op.act;  // act = number of leading channels with SiLU
+            a.ident_c0 = op.mid_c;  // first channel of an identity-kernel half (plan.py dwconv_g kind "dwg_ext"), 0 = none
             if (!R.ok) return BSY_ERR_ARG;
             return launch_dwconv_generic(a, s);
         }

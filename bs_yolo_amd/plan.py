@@ -236,7 +236,8 @@ class Plan:
         assert dst.C == src.C and dst.H == OH and dst.W == OW
         key = self._wrec(name, name=name, kind=kind, cout=src.C, cin=1, k=kh, kw=kw, post=post, rows=rows, real_cout=real_c)
         self.ops.append(dict(kind=L.OP_DWCONV_G, H=src.H, W=src.W, OH=OH, OW=OW, src0=src, dst=dst, ksize=kh, pad=kw, stride=s,
-                             act=int(act_c), wkey=key, heads=src.C, key_dim=0, name=name, lane=self._lane))
+                             act=int(act_c), wkey=key, heads=src.C, key_dim=0, name=name, lane=self._lane,
+                             mid_c=src.C // 2 if kind == "dwg_ext" else 0))  # first channel of the identity-kernel half
         self.flops += 2 * self.B * OH * OW * src.C * kh * kw
         return dst
 

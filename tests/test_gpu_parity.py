@@ -1157,6 +1157,31 @@ def test_engine_bsyolo_large_input_matches_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("scale,shape", [("n", (2, 96, 160)), ("s", (1, 160, 128)), ("n", (1, 640, 640))])
+def test_engine_pmsfa_pass_through_half_is_bit_identical(scale, shape, monkeypatch):
+    """PMSFA.conv3 (block.py:3042) runs as a depthwise 7 x 7 over [q1 | q2] whose q2 half carries an identity kernel; the tiled
+    depthwise kernel writes x + 0 for that half instead of walking 49 taps (csrc/bsyolo_ops.hip dwconv_tile_kernel, ident_c0).  The
+    window kernel (BSY_NO_DWTILE=1) walks them all: the two forwards must agree bit for bit."""
+    m = R.Model("bsyolo11", scale, 12, "detect")
+    P = R.synth_params(m, 5)
+    cfg = stock_cfg("bsyolo11", scale, 12)
+    B, H, W = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV)
+    eng = YoloEngine(cfg, P, autotune=False)
+    plan, _ = eng.plan_for(B, H, W, torch.float16, torch.float16)
+    assert sum(1 for o in plan.ops if o["kind"] == L.OP_DWCONV_G and o.get("mid_c", 0) > 0) >= 6
+    y1, r1 = eng(x)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("BSY_NO_DWTILE", "1")
+    y2, r2 = eng(x)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("BSY_NO_DWTILE")
+    assert torch.equal(y1, y2)
+    for a, b in zip(r1, r2):
+        assert torch.equal(a, b)
+    eng.close()
+
+
 @pytest.mark.parametrize("shape", [(2, 96, 160), (1, 640, 640), (3, 64, 64), (1, 1280, 1280)])
 def test_engine_msca_spatial_fusion_is_bit_identical(shape):
     """BS-YOLO: the one-launch MSCAAttention spatial part (nine depthwise convs + four global means out of LDS) returns
