@@ -354,8 +354,10 @@ class Plan:
             return self._pmsfa_padded(name, x, dst)
         P = self.conv(name + ".conv1", x, c, 3, 1)
         Q = self.dwconv_g(name + ".conv2", P.slice(0, c // 2), 5, 5, 1, c // 2)
-        S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, c // 4, kind="dwg_ext")
-        self.conv(name + ".conv4", [S, P.slice(c // 2, c // 2)], c, 1, 1, dst=dst, res=x)
+        # S overwrites p1 (dead once conv2 has read it): conv4 then reads ONE contiguous source [S | p2] = P -- at c = 32 two 16-channel
+        # sources put it on the unaligned configuration (0.10 ms at 160 x 160, B = 64); same K order, same bits
+        S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, c // 4, kind="dwg_ext", dst=P.slice(0, c // 2))
+        self.conv(name + ".conv4", P, c, 1, 1, dst=dst, res=x)
 
     def _pmsfa_padded(self, name: str, x: T, dst: T):
         """PMSFA on a width that is not a multiple of 16: the depthwise kernels work on 8-channel pieces, so the three pieces of
@@ -370,8 +372,8 @@ class Plan:
         lay = pad(q, Q8, 0) + pad(q, Q8, q) + pad(h, H8, h)           # P' channel -> conv1 output channel
         P = self.conv(name + ".conv1", x, len(lay), 3, 1, rows=lay, real=(c, 0))
         Q = self.dwconv_g(name + ".conv2", P.slice(0, 2 * Q8), 5, 5, 1, 2 * Q8, rows=pad(q, Q8, 0) + pad(q, Q8, q), real_c=h)
-        S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, Q8, kind="dwg_ext", rows=pad(q, Q8, 0), real_c=q)
-        self.conv(name + ".conv4", [S, P.slice(2 * Q8, H8)], c, 1, 1, dst=dst, res=x, cols=lay, real=(0, c))
+        S = self.dwconv_g(name + ".conv3", Q, 7, 7, 1, Q8, kind="dwg_ext", rows=pad(q, Q8, 0), real_c=q, dst=P.slice(0, 2 * Q8))
+        self.conv(name + ".conv4", P, c, 1, 1, dst=dst, res=x, cols=lay, real=(0, c))
 
     def c3k_gai(self, name: str, x: T, dst: T, n: int):
         """block.py:3079-3086: C3 (cv3(cat(m(cv1 x), cv2 x))) with m = n x PMSFA(c_)."""
