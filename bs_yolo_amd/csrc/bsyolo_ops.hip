@@ -624,14 +624,16 @@ struct MixK {
     const float* lg[4];
     int ldl[4];
 };
+// grid (pixel blocks, B): a thread keeps ONE 8-channel chunk of one image and walks pixels, so the branch weights (4 x 8 sigmoids,
+// exponentials and quotients) are computed once per thread instead of once per pixel (round 3: 52 -> see docs/experiments.md; the
+// per-pixel form spent half its time on them).  Same expressions, same order: the same bits.
+#define MIX_PIX 8  // pixels per thread
 __global__ __launch_bounds__(256) void msca_mix_kernel(const MixK k, int B, int HW, int C, half_t* __restrict__ dst, int ldd) {
-    const int C8 = C >> 3;
-    const long long total = (long long)B * HW * C8;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)(idx % C8) * 8;
-    const long long pix = idx / C8;
-    const int n = (int)(pix / HW);
+    const int C8 = C >> 3, n = blockIdx.y;
+    const int per = 256 / C8 > 0 ? 256 / C8 : 1;            // pixels in flight per pass of the workgroup (C8 <= 256)
+    const int c8 = threadIdx.x % C8, slot = threadIdx.x / C8;
+    if (slot >= per) return;
+    const int c = c8 * 8;
     float w[4][8], den[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) den[j] = 0.f;
@@ -643,17 +645,28 @@ __global__ __launch_bounds__(256) void msca_mix_kernel(const MixK k, int B, int 
             w[i][j] = __expf(sg);  // sigmoid output is in (0, 1): no max subtraction needed
             den[j] += w[i][j];
         }
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const half8 v = *reinterpret_cast<const half8*>(k.br[i] + (size_t)pix * k.ldb[i] + c);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[i][j] / den[j], (float)v[j], acc[j]);
+        for (int j = 0; j < 8; ++j) w[i][j] = w[i][j] / den[j];
+    const int q0 = blockIdx.x * per * MIX_PIX + slot;
+#pragma unroll 2
+    for (int t = 0; t < MIX_PIX; ++t) {
+        const int q = q0 + t * per;
+        if (q >= HW) break;
+        const size_t pix = (size_t)n * HW + q;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const half8 v = *reinterpret_cast<const half8*>(k.br[i] + pix * k.ldb[i] + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[i][j], (float)v[j], acc[j]);
+        }
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+        *reinterpret_cast<half8*>(dst + pix * ldd + c) = o;
     }
-    half8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-    *reinterpret_cast<half8*>(dst + (size_t)pix * ldd + c) = o;
 }
 
 int launch_msca_mix(const MixArgs& a, hipStream_t s) {
@@ -662,9 +675,10 @@ int launch_msca_mix(const MixArgs& a, hipStream_t s) {
         if (!a.br[i] || !a.lg[i] || (a.ldb[i] & 7) || ((uintptr_t)a.br[i] & 15)) BSY_FAIL(BSY_ERR_ARG, "msca_mix: branch %d bad layout", i);
         k.br[i] = a.br[i]; k.ldb[i] = a.ldb[i]; k.lg[i] = a.lg[i]; k.ldl[i] = a.ldl[i];
     }
-    if (!a.dst || (a.C & 7) || (a.ldd & 7) || ((uintptr_t)a.dst & 15) || a.B <= 0 || a.HW <= 0) BSY_FAIL(BSY_ERR_ARG, "msca_mix: bad layout");
-    const long long total = (long long)a.B * a.HW * (a.C / 8);
-    hipLaunchKernelGGL(msca_mix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, a.B, a.HW, a.C, a.dst, a.ldd);
+    if (!a.dst || (a.C & 7) || (a.ldd & 7) || ((uintptr_t)a.dst & 15) || a.B <= 0 || a.HW <= 0 || a.C > 2048) BSY_FAIL(BSY_ERR_ARG, "msca_mix: bad layout");
+    const int C8 = a.C / 8, per = 256 / C8 > 0 ? 256 / C8 : 1;
+    const int nblk = (a.HW + per * MIX_PIX - 1) / (per * MIX_PIX);
+    hipLaunchKernelGGL(msca_mix_kernel, dim3((unsigned)nblk, (unsigned)a.B), dim3(256), 0, s, k, a.B, a.HW, a.C, a.dst, a.ldd);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
