@@ -790,12 +790,24 @@ __global__ __launch_bounds__(256) void ela_gate_kernel(float* __restrict__ scrat
         const float z = (sv[i] - mu) * rstd * gnw[c] + gnb[c];
         gate[(size_t)l * C + c] = 1.0f / (1.0f + __expf(-z));
     }
-    if (dir == 0 && tid < gsz) {  // channel gate: the Conv1d sees a length-1 sequence -> only its centre tap contributes
-        const int c = c0 + tid;
-        float gmv = 0.f;  // global mean = mean of the row means (rows have equal length)
-        for (int l = 0; l < H; ++l) gmv += base[(size_t)l * C + c];
-        gmv /= (float)H;
-        base[(size_t)(2 * (H + W) + 1) * C + c] = 1.0f / (1.0f + __expf(-(wch[(size_t)c * k + (k - 1) / 2] * gmv)));
+    if (dir == 0) {  // channel gate: the Conv1d sees a length-1 sequence -> only its centre tap contributes
+        // global mean = mean of the row means (rows have equal length).  Round 3: the sum over the rows is dealt to 256 / gsz slots per
+        // channel and folded in slot order (fixed: the same bits on every run) -- one thread per channel walking H dependent loads
+        // made this the longest path of the launch (14 us per ELA at 80 x 80)
+        __syncthreads();  // sv / red are free again
+        const int nsl = 256 / gsz > 0 ? 256 / gsz : 1, cc = tid % gsz, sl = tid / gsz;
+        float part = 0.f;
+        if (sl < nsl)
+            for (int l = sl; l < H; l += nsl) part += base[(size_t)l * C + c0 + cc];
+        if (sl < nsl) sv[sl * gsz + cc] = part;
+        __syncthreads();
+        if (tid < gsz) {
+            const int c = c0 + tid;
+            float gmv = 0.f;
+            for (int q = 0; q < nsl; ++q) gmv += sv[q * gsz + tid];
+            gmv /= (float)H;
+            base[(size_t)(2 * (H + W) + 1) * C + c] = 1.0f / (1.0f + __expf(-(wch[(size_t)c * k + (k - 1) / 2] * gmv)));
+        }
     }
 }
 
