@@ -28,16 +28,21 @@ __device__ __forceinline__ float silu32m(float x) { return x / (1.0f + expf(-x))
 // FIRST: the image conv (BCHW image, f16 or f32, 3 channels).  Every tap is widened to 8 k values (3 real channels + 5 zeros, in
 // the pixel operand AND in the weight rows fetched for them), so K = 8 k^2 and the real products still arrive in ascending
 // (kh, kw, c) order -- the zero products leave the chain's value unchanged.
-template <int NT, bool FIRST>
+// THIN (NT == 1): 128 pixels x 32 couts, wave grid 4 x 1 (a wave = 32 pixels x 32 couts, one accumulator tile) -- layers of 16 / 32
+// output channels (the image conv, the Bottlenecks inside C3k2 at 1/4 and 1/8 resolution) spent half or three quarters of their
+// 64-cycle MFMAs on cout padding in the 64-cout tile.
+template <int NT, bool FIRST, bool THIN = false>
 __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a, const int M, const int ntn) {
-    constexpr int TM = 128, TN = 64 * NT, BK = 32, LDP = 36;
+    static_assert(!THIN || NT == 1, "thin tile: one 32-cout accumulator tile per wave");
+    constexpr int TM = 128, TN = THIN ? 32 : 64 * NT, BK = 32, LDP = 36, PB = THIN ? 1 : 2;
     constexpr int WPT = BK * TN / 4 / 256;  // 16-byte weight pieces per thread per K-step (2 NT)
     __shared__ __attribute__((aligned(16))) float sP[2][TM * LDP];
     __shared__ __attribute__((aligned(16))) float sW[2][BK * TN];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = THIN ? wave : wave >> 1, wn = THIN ? 0 : wave & 1;
+    const int prow0 = THIN ? wm * 32 : wm * 64;  // first pixel row of this wave's accumulator tiles
     const int lj = lane & 31, lh = lane >> 5;
     const int tn_idx = blockIdx.x % ntn, tm_idx = blockIdx.x / ntn;
     const int m0 = tm_idx * TM, n0 = tn_idx * TN;
@@ -119,15 +124,15 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
     };
 
     // accumulators start at the bias (conv32_kernel: acc = bias, then the fmaf chain)
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][PB];
 #pragma unroll
     for (int an = 0; an < NT; ++an)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = n0 + (wn * NT + an) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float bv = c < a.Cout ? a.bias[c] : 0.f;
-            acc[an][0][r] = bv;
-            acc[an][1][r] = bv;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) acc[an][b][r] = bv;
         }
 
     load_step(0);
@@ -138,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
         if (kt + 1 < nk) load_step(kt + 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 pb[2];
+            f32x4 pb[PB];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) pb[b] = *reinterpret_cast<const f32x4*>(&sP[st][(wm * 64 + b * 32 + lj) * LDP + 8 * g + 4 * lh]);
+            for (int b = 0; b < PB; ++b) pb[b] = *reinterpret_cast<const f32x4*>(&sP[st][(prow0 + b * 32 + lj) * LDP + 8 * g + 4 * lh]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float af[NT];
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
 #pragma unroll
                 for (int an = 0; an < NT; ++an)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[an], pb[b][r], acc[an][b], 0, 0, 0);
+                    for (int b = 0; b < PB; ++b) acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[an], pb[b][r], acc[an][b], 0, 0, 0);
             }
         }
         if (kt + 1 < nk) store_step(st ^ 1);  // stage st ^ 1 was last read in step kt - 1, behind that step's barrier
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
 
     // ---- epilogue: lane = pixel, registers 4 q .. 4 q + 3 = couts 8 q + 4 lh + {0..3} of the 32-cout tile ----
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int m = m0 + wm * 64 + b * 32 + lj;
+    for (int b = 0; b < PB; ++b) {
+        const int m = m0 + prow0 + b * 32 + lj;
         if (m >= M) continue;
         const int n = m / ohw, rem = m - n * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
         const size_t pix = (size_t)(n * a.OH + oh) * a.OW + ow;
@@ -203,11 +208,13 @@ int launch_conv32_mfma(const Conv32Args& a, hipStream_t s) {
     if (!conv32_mfma_supported(a)) BSY_FAIL(BSY_ERR_ARG, "conv32_mfma: unsupported shape / alignment");
     const long long M = (long long)a.B * a.OH * a.OW;
     if (M <= 0 || M > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv32_mfma: M out of range");
-    const bool wide = a.Cout > 64;
-    const int ntn = ceil_div(a.Cout, wide ? 128 : 64);
+    const bool wide = a.Cout > 64, thin = a.Cout <= 32 && !getenv("BSY_CONV32_NO_THIN");
+    const int ntn = ceil_div(a.Cout, wide ? 128 : (thin ? 32 : 64));
     const long long nblk = (long long)ceil_div((int)M, 128) * ntn;
     if (nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv32_mfma: grid out of range");
-    if (a.first && wide) hipLaunchKernelGGL((conv32_mfma_kernel<2, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, (int)M, ntn);
+    if (a.first && thin) hipLaunchKernelGGL((conv32_mfma_kernel<1, true, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, (int)M, ntn);
+    else if (thin) hipLaunchKernelGGL((conv32_mfma_kernel<1, false, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, (int)M, ntn);
+    else if (a.first && wide) hipLaunchKernelGGL((conv32_mfma_kernel<2, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, (int)M, ntn);
     else if (a.first) hipLaunchKernelGGL((conv32_mfma_kernel<1, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, (int)M, ntn);
     else if (wide) hipLaunchKernelGGL((conv32_mfma_kernel<2, false>), dim3((unsigned)nblk), dim3(256), 0, s, a, (int)M, ntn);
     else hipLaunchKernelGGL((conv32_mfma_kernel<1, false>), dim3((unsigned)nblk), dim3(256), 0, s, a, (int)M, ntn);

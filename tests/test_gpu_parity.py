@@ -99,6 +99,8 @@ CONV32_CASES = [
     (1, 7, 5, 256, 512, 1, 1, True, False, 0),       # M = 35: one partial pixel tile
     (2, 33, 31, 40, 68, 3, 1, True, True, 0),        # Cin = 40 (a K-step straddles taps), cout 68
     (1, 20, 20, 512, 256, 3, 1, True, True, 0),      # K = 4608
+    (3, 33, 47, 64, 32, 3, 1, True, True, 0),        # 32-cout (thin) tile with shortcut, ragged last pixel tile
+    (2, 24, 24, 32, 16, 3, 1, True, False, 0),       # 16 couts on the thin tile
 ]
 
 
