@@ -25,9 +25,9 @@
 namespace {
 __device__ __forceinline__ float silu32m(float x) { return x / (1.0f + expf(-x)); }  // = ref32.hip silu32
 
-// FIRST: the image conv (BCHW image, f16 or f32, 3 channels).  Every tap is widened to 8 k values (3 real channels + 5 zeros, in
-// the pixel operand AND in the weight rows fetched for them), so K = 8 k^2 and the real products still arrive in ascending
-// (kh, kw, c) order -- the zero products leave the chain's value unchanged.
+// FIRST: the image conv (BCHW image, f16 or f32, 3 channels).  Every tap is widened to 4 k values (3 real channels + 1 zero, in
+// the pixel operand AND in the weight rows fetched for them; an 8-k piece = two taps), so K = 8 ceil(k^2 / 2) and the real products
+// still arrive in ascending (kh, kw, c) order -- the zero products leave the chain's value unchanged.
 // THIN (NT == 1): 128 pixels x 32 couts, wave grid 4 x 1 (a wave = 32 pixels x 32 couts, one accumulator tile) -- layers of 16 / 32
 // output channels (the image conv, the Bottlenecks inside C3k2 at 1/4 and 1/8 resolution) spent half or three quarters of their
 // 64-cycle MFMAs on cout padding in the 64-cout tile.
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
     const int lj = lane & 31, lh = lane >> 5;
     const int tn_idx = blockIdx.x % ntn, tm_idx = blockIdx.x / ntn;
     const int m0 = tm_idx * TM, n0 = tn_idx * TN;
-    const int Cin = FIRST ? 8 : a.C0 + a.C1, Cin8 = Cin >> 3, K = a.ks * a.ks * Cin, nk = (K + BK - 1) / BK;
+    const int Cin = FIRST ? 8 : a.C0 + a.C1, Cin8 = Cin >> 3;
+    const int K = FIRST ? 8 * ((a.ks * a.ks + 1) / 2) : a.ks * a.ks * Cin, nk = (K + BK - 1) / BK;  // FIRST: `tap` below counts tap PAIRS
     const int ohw = a.OH * a.OW;
 
     // ---- pixel items of this thread: pixels (tid >> 2) and (tid >> 2) + 64, k group (tid & 3) of every K-step ----
@@ -82,12 +83,17 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
             pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (FIRST) {
-                if (ok) {
-                    const size_t hw = (size_t)a.H * a.W, ii = (size_t)pn[it] * 3 * hw + (size_t)iy * a.W + ix;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch)
-                        pv[it][0][ch] = a.src_dtype == BSY_F16 ? (float)reinterpret_cast<const half_t*>(a.src0)[ii + ch * hw]
-                                                               : reinterpret_cast<const float*>(a.src0)[ii + ch * hw];
+                for (int hf = 0; hf < 2; ++hf) {  // taps 2 tap, 2 tap + 1 -> k 0..3 / 4..7 of this piece
+                    const int t = 2 * tap + hf, th = t / a.ks, tw = t - th * a.ks;
+                    const int jy = piy[it] + th, jx = pix_[it] + tw;
+                    if (t < a.ks * a.ks && pok[it] && (unsigned)jy < (unsigned)a.H && (unsigned)jx < (unsigned)a.W) {
+                        const size_t hw = (size_t)a.H * a.W, ii = (size_t)pn[it] * 3 * hw + (size_t)jy * a.W + jx;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch)
+                            pv[it][hf][ch] = a.src_dtype == BSY_F16 ? (float)reinterpret_cast<const half_t*>(a.src0)[ii + ch * hw]
+                                                                    : reinterpret_cast<const float*>(a.src0)[ii + ch * hw];
+                    }
                 }
             } else if (ok) {
                 const float* p = s1 ? src1 + ((size_t)(pn[it] * H1 + (iy >> a.up1)) * W1 + (ix >> a.up1)) * a.ld1 + (c - a.C0)
@@ -102,8 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
             const int kr = id / (TN / 4), col = (id % (TN / 4)) * 4;
             const int k = kt * BK + kr;
             wv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (FIRST) {  // k = (tap, c8): rows of the packed [k^2 * 3][Cout] matrix for c8 < 3, zeros for the padding
-                if (k < K && (k & 7) < 3 && n0 + col < a.Cout) wv[j] = *reinterpret_cast<const f32x4*>(a.w + (size_t)((k >> 3) * 3 + (k & 7)) * a.Cout + n0 + col);
+            if (FIRST) {  // k = (tap = k / 4, channel = k % 4): rows of the packed [k^2 * 3][Cout] matrix for channel < 3, zeros for the padding
+                if (k < K && (k & 3) < 3 && (k >> 2) < a.ks * a.ks && n0 + col < a.Cout)
+                    wv[j] = *reinterpret_cast<const f32x4*>(a.w + (size_t)((k >> 2) * 3 + (k & 3)) * a.Cout + n0 + col);
             } else if (k < K && n0 + col < a.Cout) wv[j] = *reinterpret_cast<const f32x4*>(a.w + (size_t)k * a.Cout + n0 + col);
         }
         c8 += 4;
