@@ -32,12 +32,15 @@ __device__ __forceinline__ float silu32m(float x) { return x / (1.0f + expf(-x))
 // output channels (the image conv, the Bottlenecks inside C3k2 at 1/4 and 1/8 resolution) spent half or three quarters of their
 // 64-cycle MFMAs on cout padding in the 64-cout tile.
 template <int NT, bool FIRST, bool THIN = false>
-__global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a, const int M, const int ntn) {
+__global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void conv32_mfma_kernel(const Conv32Args a, const int M, const int ntn) {
     static_assert(!THIN || NT == 1, "thin tile: one 32-cout accumulator tile per wave");
     constexpr int TM = 128, TN = THIN ? 32 : 64 * NT, BK = 32, LDP = 36, PB = THIN ? 1 : 2;
     constexpr int WPT = BK * TN / 4 / 256;  // 16-byte weight pieces per thread per K-step (2 NT)
     __shared__ __attribute__((aligned(16))) float sP[2][TM * LDP];
-    __shared__ __attribute__((aligned(16))) float sW[2][BK * TN];
+    // 128-cout tile: ONE weight stage (53 KiB of LDS in all = three workgroups per CU instead of two; the stage is rewritten behind a
+    // second barrier per K-step, 1-2 % of a step's 64 x 64-cycle MFMAs)
+    constexpr int NWS = NT == 2 ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) float sW[NWS][BK * TN];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
             const int id = tid + 256 * j;
-            *reinterpret_cast<f32x4*>(&sW[st][(id / (TN / 4)) * TN + (id % (TN / 4)) * 4]) = wv[j];
+            *reinterpret_cast<f32x4*>(&sW[st & (NWS - 1)][(id / (TN / 4)) * TN + (id % (TN / 4)) * 4]) = wv[j];
         }
     };
 
@@ -157,13 +160,14 @@ __global__ __launch_bounds__(256, 2) void conv32_mfma_kernel(const Conv32Args a,
             for (int r = 0; r < 4; ++r) {
                 float af[NT];
 #pragma unroll
-                for (int an = 0; an < NT; ++an) af[an] = sW[st][(8 * g + 2 * r + lh) * TN + (wn * NT + an) * 32 + lj];
+                for (int an = 0; an < NT; ++an) af[an] = sW[st & (NWS - 1)][(8 * g + 2 * r + lh) * TN + (wn * NT + an) * 32 + lj];
 #pragma unroll
                 for (int an = 0; an < NT; ++an)
 #pragma unroll
                     for (int b = 0; b < PB; ++b) acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[an], pb[b][r], acc[an][b], 0, 0, 0);
             }
         }
+        if (NWS == 1) __syncthreads();         // every wave is done reading the single weight stage
         if (kt + 1 < nk) store_step(st ^ 1);  // stage st ^ 1 was last read in step kt - 1, behind that step's barrier
         __syncthreads();
     }
