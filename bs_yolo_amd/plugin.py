@@ -86,7 +86,7 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
     applied to fp32 callers silently:
       ``"engine_fp32"`` (default)  the engine's fp32 mode: fp32 storage, convs on the fp32 matrix pipe (csrc/conv32_mfma.hip,
                                    exact f32 products and sums; |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz against the fp32
-                                   reference; ~76 TFLOP/s, 3.4 k images/s for YOLO11s 640 x 640 -- 1/6 of the fp16 path; a
+                                   reference; ~83 TFLOP/s, 3.6 k images/s for YOLO11s 640 x 640 -- 1/6 of the fp16 path; a
                                    one-time log line says so);
       ``"engine"``                 opt in to the fast fp16-storage path for fp32 inputs (outputs come back as fp32);
       ``"reference"``              leave fp32 inputs to the original forward.
@@ -134,7 +134,7 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
             import logging
             logging.getLogger("bs_yolo_amd").warning(
                 "fp32 images run in the engine's fp32 mode (fp32 storage, fp32 matrix pipe: the fp32 model's numbers, about 1/6 of the "
-                "fp16 path's throughput -- YOLO11s 640x640: ~3.4 k vs ~21 k images/s per MI355X).  For the fp16 product path call "
+                "fp16 path's throughput -- YOLO11s 640x640: ~3.6 k vs ~21 k images/s per MI355X).  For the fp16 product path call "
                 "predict(half=True) or accelerate(model, fp32_inputs='engine'); fp32_inputs='reference' keeps fp32 inputs on the "
                 "original forward.")
         try:
