@@ -1,9 +1,9 @@
 #!/bin/bash
 # SQ counters of named kernels in one bench forward: where a kernel's wave cycles go (waiting / issuing VALU / LDS / MFMA).
-# usage: tools/pmc_kernel.sh <kernel name substring> [more substrings ...]   -> gpurun_out/pmc_kernel.txt
+# usage: [BSY_BENCH_ARGS="--precision fp32"] tools/pmc_kernel.sh <kernel name substring> [more substrings ...]   -> gpurun_out/pmc_kernel.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_kernel -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "rc=$?"
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_kernel -- python3 $R/bench.py $BSY_BENCH_ARGS --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "rc=$?"
 python3 - $R "$@" <<'PY' | tee $R/gpurun_out/pmc_kernel.txt
 import csv, glob, os, sys
 R, names = sys.argv[1], sys.argv[2:]
