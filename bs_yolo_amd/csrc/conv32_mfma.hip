@@ -25,6 +25,27 @@
 namespace {
 __device__ __forceinline__ float silu32m(float x) { return x / (1.0f + expf(-x)); }  // = ref32.hip silu32
 
+// Staging loads go through buffer descriptors (round 3): an offset past the view's range returns zeros, so padding taps, pixels
+// past M, couts past Cout and the K tail need neither a branch around the load nor a zero-initialised destination -- the K-step's
+// address arithmetic (32-bit offsets, no per-step division) shrank from ~150 to ~60 VALU instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t c32_rsrc_t;
+__device__ __forceinline__ c32_rsrc_t c32_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 c32_load(c32_rsrc_t r, unsigned voff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    union { u32x4 u; f32x4 f; } v;
+    v.u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return v.f;
+}
+#else
+typedef int c32_rsrc_t;
+__device__ __forceinline__ c32_rsrc_t c32_rsrc(const void*, unsigned) { return 0; }
+__device__ __forceinline__ f32x4 c32_load(c32_rsrc_t, unsigned) { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+#endif
+#define C32_OOB 0xFFFFFFE0u  // (+16 for the second half of a piece stays out of range)
+
 // FIRST: the image conv (BCHW image, f16 or f32, 3 channels).  Every tap is widened to 4 k values (3 real channels + 1 zero, in
 // the pixel operand AND in the weight rows fetched for them; an 8-k piece = two taps), so K = 8 ceil(k^2 / 2) and the real products
 // still arrive in ascending (kh, kw, c) order -- the zero products leave the chain's value unchanged.
@@ -68,24 +89,24 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void conv32_mfma_kernel(const
         piy[it] = oh * a.stride - a.pad;
         pix_[it] = (rem - oh * a.OW) * a.stride - a.pad;
     }
-    int tap = 0, c8 = gq;  // this thread's 8-channel piece of the current K-step: k = (tap, 8 c8 ..)
-    while (c8 >= Cin8) { c8 -= Cin8; ++tap; }
-    const float* src0 = reinterpret_cast<const float*>(a.src0);
-    const float* src1 = reinterpret_cast<const float*>(a.src1);
+    int tap = 0, c8 = gq, tkh = 0, tkw = 0;  // this thread's 8-channel piece of the current K-step: k = (tap = (tkh, tkw), 8 c8 ..)
+    while (c8 >= Cin8) { c8 -= Cin8; ++tap; if (++tkw == a.ks) { tkw = 0; ++tkh; } }
     const int H0 = a.H >> a.up0, W0 = a.W >> a.up0, H1 = a.H >> a.up1, W1 = a.W >> a.up1;
+    const c32_rsrc_t rs0 = c32_rsrc(a.src0, FIRST ? 0u : (unsigned)((((long long)a.B * H0 * W0 - 1) * a.ld0 + a.C0) * 4));
+    const c32_rsrc_t rsw = c32_rsrc(a.w, (unsigned)((long long)(FIRST ? a.ks * a.ks * 3 : K) * a.Cout * 4));
 
     f32x4 pv[2][2], wv[WPT];
     auto load_step = [&](int kt) {
-        const int kh = tap / a.ks, kw = tap - kh * a.ks;
+        const int kh = tkh, kw = tkw;
         const int c = c8 * 8;
         const bool s1 = c >= a.C0, kvalid = tap < a.ks * a.ks;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int iy = piy[it] + kh, ix = pix_[it] + kw;
             const bool ok = kvalid && pok[it] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (FIRST) {
+                pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {  // taps 2 tap, 2 tap + 1 -> k 0..3 / 4..7 of this piece
                     const int t = 2 * tap + hf, th = t / a.ks, tw = t - th * a.ks;
@@ -98,11 +119,21 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void conv32_mfma_kernel(const
                                                                     : reinterpret_cast<const float*>(a.src0)[ii + ch * hw];
                     }
                 }
-            } else if (ok) {
-                const float* p = s1 ? src1 + ((size_t)(pn[it] * H1 + (iy >> a.up1)) * W1 + (ix >> a.up1)) * a.ld1 + (c - a.C0)
-                                    : src0 + ((size_t)(pn[it] * H0 + (iy >> a.up0)) * W0 + (ix >> a.up0)) * a.ld0 + c;
-                pv[it][0] = *reinterpret_cast<const f32x4*>(p);
-                pv[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            } else {
+                if (a.C1) {  // (uniform) two concat operands: the piece's source differs from lane to lane -> plain pointers
+                    pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok) {
+                        const float* p = s1 ? reinterpret_cast<const float*>(a.src1) + ((size_t)(pn[it] * H1 + (iy >> a.up1)) * W1 + (ix >> a.up1)) * a.ld1 + (c - a.C0)
+                                            : reinterpret_cast<const float*>(a.src0) + ((size_t)(pn[it] * H0 + (iy >> a.up0)) * W0 + (ix >> a.up0)) * a.ld0 + c;
+                        pv[it][0] = *reinterpret_cast<const f32x4*>(p);
+                        pv[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+                    }
+                } else {
+                    const unsigned o0 = ok ? 4u * ((unsigned)((pn[it] * H0 + (iy >> a.up0)) * W0 + (ix >> a.up0)) * (unsigned)a.ld0 + (unsigned)c) : C32_OOB;
+                    pv[it][0] = c32_load(rs0, o0);
+                    pv[it][1] = c32_load(rs0, o0 + 16u);
+                }
             }
         }
 #pragma unroll
@@ -110,14 +141,16 @@ __global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void conv32_mfma_kernel(const
             const int id = tid + 256 * j;
             const int kr = id / (TN / 4), col = (id % (TN / 4)) * 4;
             const int k = kt * BK + kr;
-            wv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (FIRST) {  // k = (tap = k / 4, channel = k % 4): rows of the packed [k^2 * 3][Cout] matrix for channel < 3, zeros for the padding
+            if (FIRST) {
+                wv[j] = f32x4{0.f, 0.f, 0.f, 0.f};  // k = (tap = k / 4, channel = k % 4): rows of the packed [k^2 * 3][Cout] matrix for channel < 3, zeros for the padding
                 if (k < K && (k & 3) < 3 && (k >> 2) < a.ks * a.ks && n0 + col < a.Cout)
                     wv[j] = *reinterpret_cast<const f32x4*>(a.w + (size_t)((k >> 2) * 3 + (k & 3)) * a.Cout + n0 + col);
-            } else if (k < K && n0 + col < a.Cout) wv[j] = *reinterpret_cast<const f32x4*>(a.w + (size_t)k * a.Cout + n0 + col);
+            } else {
+                wv[j] = c32_load(rsw, (k < K && n0 + col < a.Cout) ? 4u * ((unsigned)k * (unsigned)a.Cout + (unsigned)(n0 + col)) : C32_OOB);
+            }
         }
         c8 += 4;
-        while (c8 >= Cin8) { c8 -= Cin8; ++tap; }
+        while (c8 >= Cin8) { c8 -= Cin8; ++tap; if (++tkw == a.ks) { tkw = 0; ++tkh; } }
     };
     auto store_step = [&](int st) {
 #pragma unroll
@@ -212,6 +245,11 @@ bool conv32_mfma_supported(const Conv32Args& a) {
     if ((a.C0 & 7) || (a.C1 & 7) || a.C0 <= 0 || (a.ld0 & 3) || (a.C1 && (a.ld1 & 3))) return false;
     if (((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) return false;
     if ((a.up0 && ((a.H | a.W) & 1)) || (a.up1 && ((a.H | a.W) & 1))) return false;
+    // buffer descriptors: every view and the weight matrix below 4 GiB - 64 bytes (32-bit byte offsets)
+    const long long lim = 0xFFFFFFC0LL;
+    if (((long long)a.B * (a.H >> a.up0) * (a.W >> a.up0) * a.ld0) * 4 >= lim) return false;
+    if (a.C1 && ((long long)a.B * (a.H >> a.up1) * (a.W >> a.up1) * a.ld1) * 4 >= lim) return false;
+    if ((long long)a.ks * a.ks * (a.C0 + a.C1) * a.Cout * 4 >= lim) return false;
     return true;
 }
 
