@@ -56,7 +56,12 @@ def cfg_of(model) -> dict:
     cfg = getattr(model, "yaml", None)
     if not isinstance(cfg, dict) or "backbone" not in cfg or "head" not in cfg:
         raise NotImplementedError("model has no yaml graph description")
-    Plan(cfg, 1, 64, 64)  # raises NotImplementedError / AssertionError on unsupported graphs
+    try:
+        Plan(cfg, 1, 64, 64)  # raises NotImplementedError / AssertionError on unsupported graphs
+    except NotImplementedError:
+        # widths only the fp32 mode takes (concat pieces that are not multiples of 8 channels, e.g. a width multiple of 0.1875): fp32
+        # callers still get the engine, fp16 calls fall back to the reference forward when their engine is built
+        Plan(cfg, 1, 64, 64, precision="fp32")
     return cfg
 
 
