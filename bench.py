@@ -30,6 +30,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_MFMA_F32_TFLOPS = 157.3   # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate (same table)
+PEAK_MFMA_F32X_TFLOPS = 2500.0 / 3.0  # fp32x mode: three fp16 MFMAs (hi*hi, hi*lo, lo*hi) per useful product
 
 
 def parse():
@@ -44,9 +45,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling) or in all (strong scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch images per GPU; strong: --batch images in all, split contiguously over the ranks")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"],
-                    help="fp16: the product path (NHWC fp16 activations, the headline); fp32: the engine's fp32 mode -- fp32 storage and "
-                         "arithmetic on the fp32 matrix pipe, what plugin.accelerate gives callers of predict(half=False)")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "fp32x"],
+                    help="fp16: the product path (NHWC fp16 activations, the headline); fp32: the engine's exact fp32 mode -- fp32 storage and "
+                         "arithmetic on the fp32 matrix pipe; fp32x: fp32 storage, dense convs on the fp16 matrix pipe with split-f16 operands "
+                         "(~2^-21 operand error; what plugin.accelerate gives callers of predict(half=False))")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="replay the forward as ONE captured hipGraph launch (engine graph mode).  Off by default: measured SLOWER than the "
                          "eager replay at every batch size on ROCm 7.2 (8 images: 1.17 vs 0.92 ms per forward + NMS; DESIGN.md section 6)")
@@ -157,8 +159,9 @@ def main():
     cfg = stock_cfg(args.family, args.scale, 12 if args.family == "bsyolo11" else 80, "detect")
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), seed=0)
     S = args.imgsz
-    f32 = args.precision == "fp32"
-    peak = PEAK_MFMA_F32_TFLOPS if f32 else PEAK_MFMA_F16_TFLOPS
+    f32 = args.precision in ("fp32", "fp32x")
+    f32x = args.precision == "fp32x"
+    peak = PEAK_MFMA_F32X_TFLOPS if f32x else (PEAK_MFMA_F32_TFLOPS if f32 else PEAK_MFMA_F16_TFLOPS)
     if args.scaling == "strong":  # the global batch is fixed: this rank's contiguous share of it (parallel.shard_bounds)
         from bs_yolo_amd.parallel import shard_bounds
         lo, hi = shard_bounds(args.batch, world)[rank]
@@ -296,7 +299,8 @@ def main():
                 break
         fwd_ms = sum(t for (_, _, t) in prof)
         out = {
-            "metric": f"images/sec {NAMES[args.family]}{args.scale} {S}x{S} bs={B if args.scaling == 'weak' else global_batch} (forward + NMS)" + (", fp32 engine mode" if f32 else ""),
+            "metric": f"images/sec {NAMES[args.family]}{args.scale} {S}x{S} bs={B if args.scaling == 'weak' else global_batch} (forward + NMS)"
+                      + (", fp32x engine mode" if f32x else (", fp32 engine mode" if f32 else "")),
             "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f16", "data": "synthetic",
@@ -315,7 +319,10 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (PMC, profiles/{tsrc})" if tsrc else tnote,
                          "algorithmic_bytes_per_launch_avg": round(fam_bytes / n_fam),
-                         "kernel": ("dense-conv family of the fp32 mode: every conv launch of one forward (conv32_mfma_kernel, v_mfma_f32_32x32x2_f32; "
+                         "kernel": ("dense-conv family of the fp32x mode: every conv launch of one forward (conv32x_mfma_kernel: fp32 storage, operands "
+                                    "split into f16 pairs, three v_mfma_f32_32x32x16_f16 per product; peak = the fp16 matrix rate / 3; the image "
+                                    "conv stays on the exact fp32 kernel)") if f32x else
+                                   ("dense-conv family of the fp32 mode: every conv launch of one forward (conv32_mfma_kernel, v_mfma_f32_32x32x2_f32; "
                                     "peak = the fp32 matrix rate)") if f32 else
                                    ("dense-conv family: every MFMA conv launch of one forward (conv_mfma_kernel, conv3x3_patch_kernel, "
                                     "conv1x1_persist_kernel and the fused stem / Bottleneck / C3k2 / DWConv+1x1 kernels)"),

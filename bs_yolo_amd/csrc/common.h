@@ -193,8 +193,15 @@ struct Conv32Args {
     int ldd, Cout;
     const float* res;
     int ldr, act, dst_scale, dst_dy, dst_dx;
+    // fp32x mode (conv32x_mfma.hip): the same weights split into two f16 planes [Cout][wx_kpad], w = hi + lo, K padded to 32
+    // with zeros; nullptr = the exact fp32 kernels only
+    const half_t* wx_hi;
+    const half_t* wx_lo;
+    int wx_kpad;
 };
 int launch_conv32(const Conv32Args& a, hipStream_t s);          // routes to the MFMA kernel where it applies, else the scalar one
+bool conv32x_mfma_supported(const Conv32Args& a);               // conv32x_mfma.hip: split-f16 operands, three f16 MFMAs per product
+int launch_conv32x_mfma(const Conv32Args& a, hipStream_t s);
 int launch_conv32_scalar(const Conv32Args& a, hipStream_t s);   // ref32.hip: one thread per output, sequential fmaf chain
 bool conv32_mfma_supported(const Conv32Args& a);                // conv32_mfma.hip: v_mfma_f32_32x32x2_f32, the same chain bit for bit
 int launch_conv32_mfma(const Conv32Args& a, hipStream_t s);

@@ -252,6 +252,10 @@ struct Resolver {
 
 // fp32 correctness mode (bsy_op.prec == 1): same op records, f32 views, kernels of ref32.hip.  DECODE and RAW_NCHW consume f32
 // logit maps in both modes and fall through to the common path.
+// Byte offsets of the two f16 weight planes an fp32x plan's conv record carries behind its f32 matrix (weights.py pack_record):
+// [f32 K x Cout][pad to 256][hi: Cout x Kpad f16][pad to 256][lo: Cout x Kpad f16], Kpad = K rounded up to 32.
+static inline size_t fp32x_align(size_t n) { return (n + 255) & ~(size_t)255; }
+
 int run_op_f32(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, bool& handled) {
     const char* wb = (const char*)p->eng->weights;
     handled = true;
@@ -274,6 +278,14 @@ int run_op_f32(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, 
             a.act = op.act; a.dst_scale = op.dst_scale > 0 ? op.dst_scale : 1; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
             if (op.out_f32 >= 2) BSY_FAIL(BSY_ERR_ARG, "fp32 mode: fused Detect decoder ops are not part of fp32 plans");
             if (!R.ok) return BSY_ERR_ARG;
+            if (op.prec == 2 && !a.first) {  // fp32x: split-f16 planes behind the f32 matrix; shapes the kernel does not take stay exact
+                const size_t K = (size_t)a.ks * a.ks * (a.C0 + a.C1), kpad = (K + 31) & ~(size_t)31;
+                const size_t hi_off = fp32x_align(K * a.Cout * 4), lo_off = hi_off + fp32x_align((size_t)a.Cout * kpad * 2);
+                a.wx_hi = (const half_t*)(wb + op.w_off + hi_off);
+                a.wx_lo = (const half_t*)(wb + op.w_off + lo_off);
+                a.wx_kpad = (int)kpad;
+                if (conv32x_mfma_supported(a)) return launch_conv32x_mfma(a, s);
+            }
             return launch_conv32(a, s);
         }
         case BSY_OP_DWCONV:
@@ -362,7 +374,7 @@ int run_op_f32(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, 
 
 int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, ConvArgs* cargs = nullptr) {
     const char* wb = (const char*)p->eng->weights;
-    if (op.prec == 1) {
+    if (op.prec == 1 || op.prec == 2) {
         bool handled = false;
         const int rc = run_op_f32(p, op, R, s, handled);
         if (rc != BSY_OK || handled) return rc;
@@ -941,6 +953,24 @@ extern "C" int bsy_conv2d_f32(const float* x, int ldx, int B, int H, int W, int 
     if (impl == 1) return launch_conv32_scalar(a, (hipStream_t)stream);
     if (impl == 2) return launch_conv32_mfma(a, (hipStream_t)stream);
     return launch_conv32(a, (hipStream_t)stream);
+}
+
+extern "C" int bsy_conv2d_f32x(const float* x, int ldx, int B, int H, int W, int C1, const void* w_hi, const void* w_lo, int k_pad,
+                               const float* b, float* y, int ldy, int C2, int ksize, int stride, int act, const float* res, int ldr,
+                               bsy_stream stream) {
+    if (!x || !w_hi || !w_lo || !b || !y) BSY_FAIL(BSY_ERR_ARG, "conv2d_f32x: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 <= 0 || ksize < 1 || !(ksize & 1) || (stride != 1 && stride != 2) || ldx < C1 || ldy < C2 ||
+        (res && ldr < C2) || k_pad < ksize * ksize * C1 || (k_pad & 31))
+        BSY_FAIL(BSY_ERR_ARG, "conv2d_f32x: bad shape");
+    Conv32Args a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = x; a.src_dtype = BSY_F32; a.ld0 = ldx; a.C0 = C1; a.B = B; a.H = H; a.W = W;
+    a.ks = ksize; a.stride = stride; a.pad = ksize / 2;
+    a.OH = (H + 2 * a.pad - ksize) / stride + 1; a.OW = (W + 2 * a.pad - ksize) / stride + 1;
+    a.w = (const float*)w_hi;  // only its alignment is looked at (conv32_mfma_supported); this entry point never runs the exact kernels
+    a.bias = b; a.dst = y; a.ldd = ldy; a.Cout = C2; a.res = res; a.ldr = ldr; a.act = act; a.dst_scale = 1;
+    a.wx_hi = (const half_t*)w_hi; a.wx_lo = (const half_t*)w_lo; a.wx_kpad = k_pad;
+    return launch_conv32x_mfma(a, (hipStream_t)stream);
 }
 
 extern "C" int bsy_conv_first_f32(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b, float* y, int ldy,

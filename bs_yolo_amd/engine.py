@@ -30,8 +30,10 @@ class YoloEngine:
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
-        # "fp32": the correctness mode -- fp32 activation storage and arithmetic (csrc/ref32.hip), for callers that expect the
-        # fp32 model's numbers (|dscore| <= 1e-3 against the fp32 reference).  Slow by design; "fp16" is the product path.
+        # "fp32": the correctness mode -- fp32 activation storage and arithmetic (csrc/ref32.hip, conv32_mfma.hip), for callers that
+        # expect the fp32 model's numbers bit-reproducibly (|dscore| <= 1e-5 against the fp32 reference).  "fp32x": the same storage
+        # and non-conv kernels, dense convs on the fp16 matrix pipe with split-f16 operands (csrc/conv32x_mfma.hip): the
+        # north-star's 1e-3 at several times the fp32 mode's throughput.  "fp16" is the product path.
         self.precision = precision
         self.device = torch.device("cuda", device)
         self._h = C.c_void_p()

@@ -21,7 +21,7 @@ BSY_EXT_BASE = 0x100000
 
 SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_create_arena", "bsy_engine_arena_bytes", "bsy_plan_set_tuning", "bsy_plan_destroy",
-    "bsy_plan_run", "bsy_plan_graph_launch", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_check_guards", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_plan_get_tuning_alt", "bsy_plan_check_tuning", "bsy_plan_autotune_in_place", "bsy_conv2d", "bsy_conv2d_f32", "bsy_conv_first_f32", "bsy_attention_f32", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_c3k2_fused", "bsy_c3k2_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
+    "bsy_plan_run", "bsy_plan_graph_launch", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_check_guards", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_plan_get_tuning_alt", "bsy_plan_check_tuning", "bsy_plan_autotune_in_place", "bsy_conv2d", "bsy_conv2d_f32", "bsy_conv2d_f32x", "bsy_conv_first_f32", "bsy_attention_f32", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_c3k2_fused", "bsy_c3k2_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
     "bsy_sppf_pool", "bsy_attention", "bsy_detect_decode", "bsy_nms_workspace_bytes", "bsy_nms", "bsy_scale_boxes",
     "bsy_letterbox", "bsy_process_mask", "bsy_process_mask_native", "bsy_scale_masks", "bsy_val_match", "bsy_slice_tiles", "bsy_sahi_merge_workspace_bytes",
     "bsy_sahi_merge", "bsy_ap_workspace_bytes", "bsy_ap_per_class", "bsy_last_error", "bsy_version",
@@ -101,6 +101,7 @@ def _load() -> C.CDLL:
     lib.bsy_plan_profile.argtypes = [vp, C.POINTER(vp), i32, vp, C.POINTER(f32)]
     lib.bsy_conv2d.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
     lib.bsy_conv2d_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]
+    lib.bsy_conv2d_f32x.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]
     lib.bsy_conv_first_f32.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.bsy_attention_f32.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, i32, i32, vp]
     lib.bsy_conv_packed_dims.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]

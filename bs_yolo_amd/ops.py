@@ -76,6 +76,28 @@ def conv2d_nhwc_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int, s
     return out
 
 
+def conv2d_nhwc_f32x(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int, s: int = 1, act: bool = True,
+                     res: Optional[torch.Tensor] = None, cin: Optional[int] = None) -> torch.Tensor:
+    """fp32x engine mode's conv (bsy_conv2d_f32x): fp32 NHWC in / out, operands split into f16 pairs, three f16 MFMAs per product.
+    x (B,H,W,ld) f32 (first `cin` channels), w (Cout,Cin,k,k) f32, b (Cout) -> (B,OH,OW,Cout up 4) f32."""
+    from .weights import split_f16_planes
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, H, W, ld = x.shape
+    cin = ld if cin is None else cin
+    cout = w.shape[0]
+    assert tuple(w.shape) == (cout, cin, k, k)
+    hi, lo = split_f16_planes(w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, k * k * cin))
+    hi, lo = hi.contiguous().to(x.device), lo.contiguous().to(x.device)
+    bk = b.detach().float().contiguous().to(x.device)
+    p = k // 2
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ldy = (cout + 3) // 4 * 4
+    out = torch.zeros((B, OH, OW, ldy), dtype=torch.float32, device=x.device)
+    L.check(L.lib.bsy_conv2d_f32x(_p(x), ld, B, H, W, cin, _p(hi), _p(lo), hi.shape[1], _p(bk), _p(out), ldy, cout, k, s, int(act),
+                                  _p(res), res.shape[-1] if res is not None else 0, _stream(x)))
+    return out
+
+
 def conv_first(img: torch.Tensor, w: torch.Tensor, b: torch.Tensor, k: int = 3, s: int = 2, act: bool = True):
     """img BCHW fp16/fp32; w (Cout,3,3,3) fp32; -> NHWC fp16."""
     assert img.is_contiguous() and img.shape[1] == 3

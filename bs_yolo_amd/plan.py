@@ -107,10 +107,12 @@ class Plan:
                  fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None,
                  fuse_tail: Optional[bool] = None, precision: str = "fp16", lanes: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
-        if precision not in ("fp16", "fp32"):
-            raise ValueError(f"precision must be 'fp16' or 'fp32', not {precision!r}")
-        # fp32: the correctness mode (csrc/ref32.hip) -- every buffer f32, no fused kernels, same op list otherwise
-        self.f32_mode = precision == "fp32"
+        if precision not in ("fp16", "fp32", "fp32x"):
+            raise ValueError(f"precision must be 'fp16', 'fp32' or 'fp32x', not {precision!r}")
+        # fp32: the correctness mode (csrc/ref32.hip) -- every buffer f32, no fused kernels, same op list otherwise.
+        # fp32x: the same plan; its dense convs multiply on the fp16 matrix pipe with split-f16 operands (csrc/conv32x_mfma.hip)
+        self.f32_mode = precision in ("fp32", "fp32x")
+        self.split_f16 = precision == "fp32x"
         if self.f32_mode:
             fuse_stem = fuse_bneck = fuse_head = fuse_dwpw = merge_c3k = fuse_msca = fuse_tail = False
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
@@ -877,5 +879,5 @@ class Plan:
                 o.lvl_stride[j] = d["lvl_stride"][j] if j < len(d.get("lvl_stride", [])) else 0.0
             o.in_dtype, o.out_dtype, o.level = d.get("in_dtype", 0), d.get("out_dtype", 0), d.get("level", 0)
             o.lane, o.join, o.tuned_cfg = d.get("lane", 0), d.get("join", 0), 0
-            o.prec = 1 if self.f32_mode else 0
+            o.prec = (2 if self.split_f16 else 1) if self.f32_mode else 0
         return arr

@@ -44,10 +44,26 @@ def _align(n: int, a: int = 256) -> int:
     return (n + a - 1) // a * a
 
 
-def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f32: bool = False):
+def split_f16_planes(w2d: torch.Tensor):
+    """(Cout, K) f32 -> (hi, lo) f16 planes [Cout][K rounded up to 32] with w ~= hi + lo (csrc/conv32x_mfma.hip): hi = f16(w),
+    lo = f16(w - hi); the subtraction is exact in f32, so the pair carries w to ~22 bits (less where lo falls into f16's
+    subnormal range: |w| < 2^-3 keeps an absolute 2^-25).  Values beyond the f16 range saturate at +-65504 like the kernel's
+    pixel split (never an infinity)."""
+    cout, K = w2d.shape
+    kp = (K + 31) // 32 * 32
+    w = torch.zeros(cout, kp, dtype=torch.float32)
+    w[:, :K] = w2d
+    hi = w.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (w - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    return hi, lo
+
+
+def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f32: bool = False, split: bool = False):
     """-> (weight bytes, bias bytes) for one op.  f32: the fp32 correctness mode's layout for dense convs -- f32
     [k*k*cin][cout] (K order (kh, kw, cin) as in the fp16 layout, cout fastest), bias f32 [cout], no padding
-    (csrc/ref32.hip); depthwise / ELA records are f32 in both modes."""
+    (csrc/ref32.hip); depthwise / ELA records are f32 in both modes.  split (fp32x mode, with f32): the f32 matrix is followed
+    by the two f16 planes of split_f16_planes, each part padded to 256 bytes (csrc/engine.hip run_op_f32 computes the same
+    offsets; the image conv keeps the f32 matrix only)."""
     if r.kind == "ela":
         # ELA (nn/Addmodules/ELA.py:36-72): [spatial_conv (C,k)][ch_att.2 (C,k)][gn.weight][gn.bias]; the three scalar mixing
         # weights enter the op record as their sigmoids
@@ -113,8 +129,12 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f3
             idx = torch.as_tensor(r.perm, dtype=torch.long)
             w, b = w[idx], b[idx]
         if f32:
-            return (w.permute(2, 3, 1, 0).reshape(k * k * cin, cout).contiguous().numpy().tobytes(),
-                    b.contiguous().numpy().tobytes())
+            wb = w.permute(2, 3, 1, 0).reshape(k * k * cin, cout).contiguous().numpy().tobytes()
+            if split and r.kind not in ("first", "first_s2d"):
+                hi, lo = split_f16_planes(w.permute(0, 2, 3, 1).reshape(cout, k * k * cin))
+                hb = hi.numpy().tobytes()
+                wb = wb + b"\0" * (_align(len(wb)) - len(wb)) + hb + b"\0" * (_align(len(hb)) - len(hb)) + lo.numpy().tobytes()
+            return wb, b.contiguous().numpy().tobytes()
         if r.kind == "first":  # image conv: zero 4th input channel, k = (kh, kw, c4)  (csrc/image_conv.h)
             w = torch.cat([w, torch.zeros(cout, 4 - cin, k, k)], 1)
             cin = 4
@@ -153,7 +173,7 @@ def pack_plan_weights(plan: Plan, sd: Mapping[str, torch.Tensor], eps: float = B
     """Packs every record of `plan` (sets w_off / b_off on the records) -> host blob (fp32 layouts for an fp32-mode plan)."""
     chunks, off = [], 0
     for r in plan.wrecs.values():
-        wb, bb = pack_record(sd, r, eps, f32=getattr(plan, "f32_mode", False))
+        wb, bb = pack_record(sd, r, eps, f32=getattr(plan, "f32_mode", False), split=getattr(plan, "split_f16", False))
         r.w_off = off
         chunks.append(wb)
         pad = _align(len(wb)) - len(wb)

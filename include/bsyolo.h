@@ -129,7 +129,11 @@ typedef struct bsy_op {
     int64_t aux_off[18];    /* MSCA_SPATIAL: (weights, bias) byte offsets of its nine depthwise convs */
     int32_t prec;           /* 0: the fp16-storage product path.  1: fp32 correctness mode -- every workspace view is NHWC f32,
                              * dense conv weights are f32 [k*k*Cin][Cout], arithmetic is fp32 (csrc/ref32.hip); kinds CONV_FIRST,
-                             * CONV, DWCONV, DWCONV_G, SPPF_POOL, ATTN, DECODE, RAW_NCHW, NHWC2NCHW, COPY, GAP, MSCA_MIX, MUL, ELA */
+                             * CONV, DWCONV, DWCONV_G, SPPF_POOL, ATTN, DECODE, RAW_NCHW, NHWC2NCHW, COPY, GAP, MSCA_MIX, MUL, ELA.
+                             * 2: fp32x mode -- storage and every non-conv kernel as in mode 1; dense convs (CONV) multiply on the
+                             * fp16 matrix pipe with both operands split into f16 pairs (csrc/conv32x_mfma.hip: ~2^-21 relative
+                             * operand error instead of the exact fp32 chain); their weight record is the mode-1 f32 matrix followed
+                             * by two f16 planes [Cout][K rounded up to 32] (hi, lo), each part padded to 256 bytes */
     int32_t reserved0;
 } bsy_op;
 
@@ -209,8 +213,15 @@ int bsy_conv2d(const void* x, int ldx, int B, int H, int W, int C1, const void* 
  * (BSY_ERR_ARG where it does not apply).  Both kernels evaluate the same k-ordered fmaf chain: bit-identical results. */
 int bsy_conv2d_f32(const float* x, int ldx, int B, int H, int W, int C1, const float* w, const float* b, float* y, int ldy,
                    int C2, int ksize, int stride, int act, const float* res, int ldr, int impl, bsy_stream stream);
+/* The same module in the fp32x mode (fp32 storage, split-f16 arithmetic; what plugin.accelerate gives fp32 callers by default since
+ * round 4): w_hi / w_lo f16 [C2][k_pad] with w = hi + lo, K order (kh, kw, cin), k_pad = k*k*C1 rounded up to 32 with zeros.
+ * Needs C1 % 8 == 0, C2 % 4 == 0, row strides % 4 == 0, 16-byte aligned views (BSY_ERR_ARG otherwise: the engine then runs the
+ * exact kernel).  |y - exact| <~ 2^-20 * sum |w x|: three v_mfma_f32_32x32x16_f16 per product, f32 accumulation. */
+int bsy_conv2d_f32x(const float* x, int ldx, int B, int H, int W, int C1, const void* w_hi, const void* w_lo, int k_pad,
+                    const float* b, float* y, int ldy, int C2, int ksize, int stride, int act, const float* res, int ldr,
+                    bsy_stream stream);
 /* The image conv of the fp32 mode: img BCHW (f16 / f32) -> NHWC f32; w f32 [k*k*3][C2], K order (kh, kw, c).  impl as above (the
- * MFMA kernel widens every tap to 8 k values, 5 of them zeros: the same chain, the same bits). */
+ * MFMA kernel widens every tap to 4 k values, one of them zero, two taps per 8-k piece, K = 8 ceil(k^2 / 2): the same chain, the same bits). */
 int bsy_conv_first_f32(const void* img, int img_dtype, int B, int H, int W, const float* w, const float* b, float* y, int ldy,
                        int C2, int ksize, int stride, int act, int impl, bsy_stream stream);
 /* Attention (block.py:4279-4286) of the fp32 mode: qkv (B, N, ld) f32 rows [q (heads x key_dim) | k | v (heads x head_dim)] ->

@@ -77,7 +77,7 @@ def timing(scale="s", B=64, S=640, dt=torch.float16, family="yolo11", precision=
     cfg = stock_cfg(family, scale, 12 if family == "bsyolo11" else 80)
     sd = synth_state_dict(Plan(cfg, 1, 64, 64), 0)
     eng = YoloEngine(cfg, sd, precision=precision)
-    if precision == "fp32":
+    if precision in ("fp32", "fp32x"):
         dt = torch.float32
     x = torch.rand(B, 3, S, S, device=DEV).to(dt)
     for _ in range(3):
