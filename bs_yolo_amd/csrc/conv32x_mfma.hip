@@ -20,6 +20,8 @@
 // Workgroup = 4 waves, tile 128 pixels x (64 NT | 32 THIN) couts, K-step 32; LDS rows of 32 halfs + 8 of padding (80 bytes: the
 // 16 lanes of a ds_read_b128 group land on 16 distinct 16-byte bank slots).  Double-buffered stages, one barrier per K-step.
 // The image conv (3 channels) and shapes this kernel does not take stay on the exact kernels (launch_conv32).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -176,10 +178,14 @@ __global__ __launch_bounds__(256, 2) void conv32x_mfma_kernel(const Conv32Args a
 
     load_step(0);
     store_step(0);
+    if (nk > 1) load_step(1);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int st = kt & 1;
-        if (kt + 1 < nk) load_step(kt + 1);
+        // step kt + 1 goes to LDS before this step's MFMAs (its loads are a step old; stage st ^ 1 was last read in step kt - 1), the
+        // loads of step kt + 2 fly during them: split, ds_writes and MFMAs share one block for the scheduler to interleave
+        if (kt + 1 < nk) store_step(st ^ 1);
+        if (kt + 2 < nk) load_step(kt + 2);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             half8 bh[PB], bl[PB], ah[NT], al[NT];
@@ -204,7 +210,6 @@ __global__ __launch_bounds__(256, 2) void conv32x_mfma_kernel(const Conv32Args a
                     acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[an], bh[b], acc[an][b], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_step(st ^ 1);  // stage st ^ 1 was last read in step kt - 1, behind that step's barrier
         __syncthreads();
     }
 
@@ -239,6 +244,402 @@ __global__ __launch_bounds__(256, 2) void conv32x_mfma_kernel(const Conv32Args a
             }
     }
 }
+
+// ---- big tiles (round 4): 256 pixels x (256 | 128) couts, 8 waves, one workgroup per CU -------------------------------------
+// The 128 x 128 tile above stages (128 + 128) x 4 bytes per k for 2 x 128 x 128 FLOP = 31 KB per MFLOP, and the layers that carry
+// the FLOPs run at the rate a CU takes bytes in from L2 / Infinity Cache (~12.5 B/clk: 207-217 TFLOP/s on model.3 / model.5).
+// 256 x 256 stages 15.6 KB per MFLOP, 256 x 128 23 KB.  Same arithmetic, same staging path (f32 pixels split in registers, f16
+// weight planes through registers), K-step BK (16: 48-byte LDS rows; 32: 80-byte rows), two LDS stages + the staging registers.
+template <int TN, int BK>
+__global__ __launch_bounds__(512, 2) void conv32x_big_kernel(const Conv32Args a, const int M, const int ntn) {
+    static_assert((TN == 256 || TN == 128) && (BK == 16 || BK == 32), "tile");
+    constexpr int TM = 256, LDH = BK + 8, CPR = BK / 8, NST = 2;
+    constexpr int PPT = TM * CPR / 512;        // pixel pieces (8 consecutive k of one pixel) per thread per K-step
+    constexpr int WPT = TN * CPR / 512;        // weight pieces per thread per plane (TN 128, BK 16: threads 0..255 only)
+    constexpr int WPIECES = TN * CPR;
+    constexpr int WPTR = WPT > 0 ? WPT : 1;
+    constexpr int WN = TN / 64, WM = 8 / WN;   // wave grid: WM pixel rows x WN cout columns; wave tile (TM / WM) px x 64 couts
+    constexpr int PB = TM / WM / 32, NT = 2;
+    constexpr int STAGE = (TM + TN) * LDH;     // halves per plane per stage
+    __shared__ __attribute__((aligned(16))) half_t sm[NST * 2 * STAGE];  // [stage][hi | lo][pixel rows, then weight rows]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int prow0 = wm * (TM / WM);
+    const int lj = lane & 31, lh = lane >> 5;
+    // XCD-aware remap (conv_mfma.hip xcd_remap): blocks that share an XCD take consecutive tiles, so the cout tiles of one pixel tile
+    // read the pixels from that XCD's L2
+    const int nb = gridDim.x, bq = nb >> 3, br = nb & 7, bx = blockIdx.x & 7;
+    const int wg = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
+    const int tn_idx = wg % ntn, tm_idx = wg / ntn;
+    const int m0 = tm_idx * TM, n0 = tn_idx * TN;
+    const int Cin = a.C0 + a.C1, Cin8 = Cin >> 3;
+    const int K = a.ks * a.ks * Cin, nk = (K + BK - 1) / BK;
+    const int ohw = a.OH * a.OW;
+
+    const int gq = tid % CPR;
+    int pn[PPT], piy[PPT], pix_[PPT];
+    bool pok[PPT];
+#pragma unroll
+    for (int it = 0; it < PPT; ++it) {
+        const int m = m0 + tid / CPR + (512 / CPR) * it;
+        pok[it] = m < M;
+        const int mm = pok[it] ? m : 0;
+        pn[it] = mm / ohw;
+        const int rem = mm - pn[it] * ohw;
+        const int oh = rem / a.OW;
+        piy[it] = oh * a.stride - a.pad;
+        pix_[it] = (rem - oh * a.OW) * a.stride - a.pad;
+    }
+    int tap = 0, c8 = gq, tkh = 0, tkw = 0;
+    while (c8 >= Cin8) { c8 -= Cin8; ++tap; if (++tkw == a.ks) { tkw = 0; ++tkh; } }
+    const int H0 = a.H >> a.up0, W0 = a.W >> a.up0, H1 = a.H >> a.up1, W1 = a.W >> a.up1;
+    const cx_rsrc_t rs0 = cx_rsrc(a.src0, (unsigned)((((long long)a.B * H0 * W0 - 1) * a.ld0 + a.C0) * 4));
+    const cx_rsrc_t rs1 = cx_rsrc(a.C1 ? a.src1 : a.src0, a.C1 ? (unsigned)((((long long)a.B * H1 * W1 - 1) * a.ld1 + a.C1) * 4) : 0u);
+    const unsigned plane_bytes = (unsigned)a.Cout * (unsigned)a.wx_kpad * 2u;
+    const cx_rsrc_t rwh = cx_rsrc(a.wx_hi, plane_bytes), rwl = cx_rsrc(a.wx_lo, plane_bytes);
+
+    f32x4 pv[PPT][2], wvh[WPTR], wvl[WPTR];
+    auto load_step = [&](int kt) {
+        const int c = c8 * 8;
+        const bool s1 = c >= a.C0, kvalid = tap < a.ks * a.ks;
+#pragma unroll
+        for (int it = 0; it < PPT; ++it) {
+            const int iy = piy[it] + tkh, ix = pix_[it] + tkw;
+            const bool ok = kvalid && pok[it] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            // two concat operands: the piece's source differs from lane to lane -> one load from each descriptor, the other out of range
+            const unsigned o0 = (ok && !s1) ? 4u * ((unsigned)((pn[it] * H0 + (iy >> a.up0)) * W0 + (ix >> a.up0)) * (unsigned)a.ld0 + (unsigned)c) : CX_OOB;
+            pv[it][0] = cx_load(rs0, o0);
+            pv[it][1] = cx_load(rs0, o0 + 16u);
+            if (a.C1) {  // uniform
+                const unsigned o1 = (ok && s1) ? 4u * ((unsigned)((pn[it] * H1 + (iy >> a.up1)) * W1 + (ix >> a.up1)) * (unsigned)a.ld1 + (unsigned)(c - a.C0)) : CX_OOB;
+                const f32x4 q0 = cx_load(rs1, o1), q1 = cx_load(rs1, o1 + 16u);
+                if (s1) { pv[it][0] = q0; pv[it][1] = q1; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int id = tid + 512 * j;
+            const int row = id / CPR, q = id % CPR;
+            const bool ok = n0 + row < a.Cout;
+            const unsigned off = ok ? 2u * ((unsigned)(n0 + row) * (unsigned)a.wx_kpad + (unsigned)(kt * BK + 8 * q)) : CX_OOB;
+            wvh[j] = cx_load(rwh, off);
+            wvl[j] = cx_load(rwl, off);
+        }
+        if (WPT == 0) {  // TN 128, BK 16: 256 pieces per plane
+            const int row = tid / CPR, q = tid % CPR;
+            const bool ok = tid < WPIECES && n0 + row < a.Cout;
+            const unsigned off = ok ? 2u * ((unsigned)(n0 + row) * (unsigned)a.wx_kpad + (unsigned)(kt * BK + 8 * q)) : CX_OOB;
+            wvh[0] = cx_load(rwh, off);
+            wvl[0] = cx_load(rwl, off);
+        }
+        c8 += CPR;
+        while (c8 >= Cin8) { c8 -= Cin8; ++tap; if (++tkw == a.ks) { tkw = 0; ++tkh; } }
+    };
+    auto store_step = [&](int st) {
+        half_t* hi_p = sm + (size_t)st * 2 * STAGE;
+        half_t* lo_p = hi_p + STAGE;
+#pragma unroll
+        for (int it = 0; it < PPT; ++it) {
+            H8 hi, lo;
+            split8(pv[it][0], pv[it][1], hi, lo);
+            const int o = (tid / CPR + (512 / CPR) * it) * LDH + 8 * gq;
+            *reinterpret_cast<half8*>(hi_p + o) = hi.h;
+            *reinterpret_cast<half8*>(lo_p + o) = lo.h;
+        }
+#pragma unroll
+        for (int j = 0; j < WPTR; ++j) {
+            const int id = tid + 512 * j;
+            if (WPT > 0 || id < WPIECES) {
+                const int o = (TM + id / CPR) * LDH + 8 * (id % CPR);
+                H8 t;
+                t.f = wvh[j];
+                *reinterpret_cast<half8*>(hi_p + o) = t.h;
+                t.f = wvl[j];
+                *reinterpret_cast<half8*>(lo_p + o) = t.h;
+            }
+        }
+    };
+
+    f32x16 acc[NT][PB];
+#pragma unroll
+    for (int an = 0; an < NT; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = n0 + (wn * NT + an) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float bv = c < a.Cout ? a.bias[c] : 0.f;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) acc[an][b][r] = bv;
+        }
+
+    load_step(0);
+    store_step(0);
+    if (nk > 1) load_step(1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        // Step kt + 1 goes to LDS BEFORE this step's MFMAs: its loads were issued a whole step ago, the stage it overwrites was last
+        // read in step kt - 1 (behind that step's barrier), and the split's VALU work and ds_writes sit in one block with the MFMAs, so
+        // the scheduler interleaves them instead of leaving the matrix pipe idle behind a store phase; the loads of step kt + 2 fly
+        // during the MFMAs (the registers are the third stage).
+        if (kt + 1 < nk) store_step(st ^ 1);
+        if (kt + 2 < nk) load_step(kt + 2);
+        const half_t* hi_p = sm + (size_t)st * 2 * STAGE;
+        const half_t* lo_p = hi_p + STAGE;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            half8 ah[NT], al[NT];
+#pragma unroll
+            for (int an = 0; an < NT; ++an) {
+                const int o = (TM + (wn * NT + an) * 32 + lj) * LDH + 16 * s + 8 * lh;
+                ah[an] = *reinterpret_cast<const half8*>(hi_p + o);
+                al[an] = *reinterpret_cast<const half8*>(lo_p + o);
+            }
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                const int o = (prow0 + b * 32 + lj) * LDH + 16 * s + 8 * lh;
+                const half8 bh = *reinterpret_cast<const half8*>(hi_p + o);
+                const half8 bl = *reinterpret_cast<const half8*>(lo_p + o);
+#pragma unroll
+                for (int an = 0; an < NT; ++an) {
+                    acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[an], bh, acc[an][b], 0, 0, 0);
+                    acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[an], bl, acc[an][b], 0, 0, 0);
+                    acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[an], bh, acc[an][b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+        const int m = m0 + prow0 + b * 32 + lj;
+        if (m >= M) continue;
+        const int n = m / ohw, rem = m - n * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
+        const size_t pix = (size_t)(n * a.OH + oh) * a.OW + ow;
+        size_t dp = pix;
+        if (a.dst_scale != 1)
+            dp = ((size_t)n * (a.OH * a.dst_scale) + (oh * a.dst_scale + a.dst_dy)) * (size_t)(a.OW * a.dst_scale) + (ow * a.dst_scale + a.dst_dx);
+#pragma unroll
+        for (int an = 0; an < NT; ++an)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = n0 + (wn * NT + an) * 32 + 8 * q + 4 * lh;
+                if (c >= a.Cout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[an][b][4 * q + e];
+                    v[e] = a.act ? silu_x(t) : t;
+                }
+                if (a.res) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.ldr + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                *reinterpret_cast<f32x4*>(a.dst + dp * a.ldd + c) = v;
+            }
+    }
+}
+
+// ---- patch kernel (round 4): 3 x 3, stride 1, one source -----------------------------------------------------------------------
+// The implicit-GEMM kernels above fetch AND split every input pixel once per tap (nine times); thin layers (Cout <= 64 at 80 x 80 /
+// 160 x 160: the Bottlenecks inside C3k2, Detect's box branch) were bound by exactly that -- 47 KB staged per MFLOP.  Here the 10 x 18
+// input patch of an 8 x 16 output tile is fetched and split ONCE per CK-channel chunk into an f16 hi / lo patch in LDS and serves all
+// nine taps (a tap = a shifted window of the patch: the B fragment of pixel (y, x) for tap (kh, kw) is patch row (y + kh) * 18 + x + kw);
+// only the weights -- TPS taps x TN couts x CK per step, both planes -- stream through a double-buffered stage.  K walks chunk-major:
+// (chunk, kh, kw, channel in chunk).  CK = 32 (Cin % 32 == 0) or 16; TN = 128 / 64 (wave grid 2 x 2) or 32 (4 x 1).
+template <int NT, bool THIN, int CK, int TPS>
+__global__ __launch_bounds__(256, 2) void conv32x_patch_kernel(const Conv32Args a, const int tiles_y, const int tiles_x, const int ntn) {
+    static_assert((CK == 16 || CK == 32) && (TPS == 1 || TPS == 3) && (!THIN || NT == 1), "configuration");
+    constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPP = PH * PW;  // 180 patch pixels
+    constexpr int TN = THIN ? 32 : 64 * NT, LDH = CK + 8, CPR = CK / 8, PB = THIN ? 1 : 2, KS = CK / 16;
+    constexpr int PPT = (NPP * CPR + 255) / 256;          // patch pieces per thread
+    constexpr int WPIECES = TPS * TN * CPR;               // weight pieces per plane per step
+    constexpr int WPT = (WPIECES + 255) / 256;
+    constexpr int NSTEP = 9 / TPS;                        // steps per chunk
+    __shared__ __attribute__((aligned(16))) half_t sPat[2][NPP * LDH];           // [hi | lo]
+    __shared__ __attribute__((aligned(16))) half_t sWt[2][2][TPS * TN * LDH];    // [stage][hi | lo][tap][cout][k]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = THIN ? wave : wave >> 1, wn = THIN ? 0 : wave & 1;
+    const int prow0 = THIN ? wm * 32 : wm * 64;
+    const int lj = lane & 31, lh = lane >> 5;
+    const int nb = gridDim.x, bq = nb >> 3, br = nb & 7, bx = blockIdx.x & 7;
+    const int wg = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
+    const int tn_idx = wg % ntn;
+    int t = wg / ntn;
+    const int txi = t % tiles_x; t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int img = t / tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW, n0 = tn_idx * TN;
+    const int Cin = a.C0, nchunk = Cin / CK;
+    const cx_rsrc_t rs0 = cx_rsrc(a.src0, (unsigned)((((long long)a.B * a.H * a.W - 1) * a.ld0 + a.C0) * 4));
+    const unsigned plane_bytes = (unsigned)a.Cout * (unsigned)a.wx_kpad * 2u;
+    const cx_rsrc_t rwh = cx_rsrc(a.wx_hi, plane_bytes), rwl = cx_rsrc(a.wx_lo, plane_bytes);
+
+    // patch pieces of this thread: piece id -> (patch pixel, 8-channel group); offset of the pixel in the source (or out of range)
+    unsigned poff[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int id = tid + 256 * j, pp = id / CPR, q = id % CPR;
+        const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
+        const bool ok = pp < NPP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        poff[j] = ok ? 4u * ((unsigned)((img * a.H + iy) * a.W + ix) * (unsigned)a.ld0 + 8u * q) : CX_OOB;
+    }
+    f32x4 pv[PPT][2], wvh[WPT], wvl[WPT];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const unsigned o = poff[j] == CX_OOB ? CX_OOB : poff[j] + 4u * (unsigned)(c * CK);
+            pv[j][0] = cx_load(rs0, o);
+            pv[j][1] = cx_load(rs0, o + 16u);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int id = tid + 256 * j;
+            if (id < NPP * CPR) {
+                H8 hi, lo;
+                split8(pv[j][0], pv[j][1], hi, lo);
+                const int o = (id / CPR) * LDH + 8 * (id % CPR);
+                *reinterpret_cast<half8*>(&sPat[0][o]) = hi.h;
+                *reinterpret_cast<half8*>(&sPat[1][o]) = lo.h;
+            }
+        }
+    };
+    // weights of step g = chunk * NSTEP + j: taps TPS j .. TPS j + TPS - 1 of the chunk, k = tap * Cin + chunk * CK + ..
+    auto load_w = [&](int g) {
+        const int c = g / NSTEP, tap0 = (g % NSTEP) * TPS;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int id = tid + 256 * j;
+            const int q = id % CPR, row = (id / CPR) % TN, tp = id / (CPR * TN);
+            const bool ok = id < WPIECES && n0 + row < a.Cout;
+            const unsigned off = ok ? 2u * ((unsigned)(n0 + row) * (unsigned)a.wx_kpad + (unsigned)((tap0 + tp) * Cin + c * CK + 8 * q)) : CX_OOB;
+            wvh[j] = cx_load(rwh, off);
+            wvl[j] = cx_load(rwl, off);
+        }
+    };
+    auto store_w = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int id = tid + 256 * j;
+            if (id < WPIECES) {
+                const int o = (id / CPR) * LDH + 8 * (id % CPR);  // row = tap * TN + cout
+                H8 t2;
+                t2.f = wvh[j];
+                *reinterpret_cast<half8*>(&sWt[st][0][o]) = t2.h;
+                t2.f = wvl[j];
+                *reinterpret_cast<half8*>(&sWt[st][1][o]) = t2.h;
+            }
+        }
+    };
+
+    f32x16 acc[NT][PB];
+#pragma unroll
+    for (int an = 0; an < NT; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = n0 + (wn * NT + an) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float bv = c < a.Cout ? a.bias[c] : 0.f;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) acc[an][b][r] = bv;
+        }
+    // patch row (pixel index) of this lane's pixel of block b for tap (0, 0): (y + kh) * PW + x + kw is added per tap
+    int prow[PB];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+        const int p = prow0 + b * 32 + lj;
+        prow[b] = (p / TW) * PW + p % TW;
+    }
+
+    const int nsteps = nchunk * NSTEP;
+    load_patch(0);
+    load_w(0);
+    store_w(0);
+    if (nsteps > 1) load_w(1);
+    int g = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        store_patch();            // (every wave is done with the previous chunk's patch: the barrier that ended its last step)
+        if (c + 1 < nchunk) load_patch(c + 1);  // in flight during this chunk's nine taps
+        __syncthreads();
+        for (int j = 0; j < NSTEP; ++j, ++g) {
+            const int st = g & 1;
+            if (g + 1 < nsteps) store_w(st ^ 1);
+            if (g + 2 < nsteps) load_w(g + 2);
+#pragma unroll
+            for (int tp = 0; tp < TPS; ++tp) {
+                const int tap = j * TPS + tp, kh = tap / 3, kw = tap - 3 * kh;
+                const int shift = kh * PW + kw;
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2) {
+                    half8 ah[NT], al[NT];
+#pragma unroll
+                    for (int an = 0; an < NT; ++an) {
+                        const int o = (tp * TN + (wn * NT + an) * 32 + lj) * LDH + 16 * s2 + 8 * lh;
+                        ah[an] = *reinterpret_cast<const half8*>(&sWt[st][0][o]);
+                        al[an] = *reinterpret_cast<const half8*>(&sWt[st][1][o]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        const int o = (prow[b] + shift) * LDH + 16 * s2 + 8 * lh;
+                        const half8 bh = *reinterpret_cast<const half8*>(&sPat[0][o]);
+                        const half8 bl = *reinterpret_cast<const half8*>(&sPat[1][o]);
+#pragma unroll
+                        for (int an = 0; an < NT; ++an) {
+                            acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[an], bh, acc[an][b], 0, 0, 0);
+                            acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[an], bl, acc[an][b], 0, 0, 0);
+                            acc[an][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[an], bh, acc[an][b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+        const int p = prow0 + b * 32 + lj;
+        const int oy = y0 + p / TW, ox = x0 + p % TW;
+        if (oy >= a.H || ox >= a.W) continue;
+        const size_t pix = (size_t)(img * a.H + oy) * a.W + ox;
+#pragma unroll
+        for (int an = 0; an < NT; ++an)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = n0 + (wn * NT + an) * 32 + 8 * q + 4 * lh;
+                if (c >= a.Cout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tt = acc[an][b][4 * q + e];
+                    v[e] = a.act ? silu_x(tt) : tt;
+                }
+                if (a.res) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.ldr + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                *reinterpret_cast<f32x4*>(a.dst + pix * a.ldd + c) = v;
+            }
+    }
+}
+
+template <int NT, bool THIN, int TPS>
+int launch_patch(const Conv32Args& a, hipStream_t s) {
+    const int ty = ceil_div(a.H, 8), tx = ceil_div(a.W, 16), ntn = ceil_div(a.Cout, THIN ? 32 : 64 * NT);
+    const long long nb = (long long)a.B * ty * tx * ntn;
+    if (nb > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv32x_patch: grid out of range");
+    if (a.C0 % 32 == 0) hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 32, TPS>), dim3((unsigned)nb), dim3(256), 0, s, a, ty, tx, ntn);
+    else hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 16, TPS>), dim3((unsigned)nb), dim3(256), 0, s, a, ty, tx, ntn);
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
 }  // namespace
 
 bool conv32x_mfma_supported(const Conv32Args& a) {
@@ -254,6 +655,38 @@ int launch_conv32x_mfma(const Conv32Args& a, hipStream_t s) {
     if (!conv32x_mfma_supported(a)) BSY_FAIL(BSY_ERR_ARG, "conv32x_mfma: unsupported shape / alignment");
     const long long M = (long long)a.B * a.OH * a.OW;
     if (M <= 0 || M > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv32x_mfma: M out of range");
+    // tile choice (BSY_CONV32X_TILE=0 / 1 / 2 forces the 128-pixel tiles / 256 x 128 / 256 x 256 where they apply; _BK=16 / 32):
+    // 256 x 256 from 256 couts and 256 x 128 from 128, when the grid still gives every CU a workgroup or the layer is deep enough
+    // that staged bytes, not tile quantisation, set its time
+    const char* ef = getenv("BSY_CONV32X_TILE");   // (read per call: the tests switch it between launches)
+    const char* eb = getenv("BSY_CONV32X_BK");
+    const char* ep = getenv("BSY_CONV32X_PATCH");
+    const int force = ef ? atoi(ef) : -1, bk = eb ? atoi(eb) : 32;
+    // 3 x 3 stride-1 layers with one source: the patch kernel, where the map is big enough for its 8 x 16 tiles to waste little (a
+    // 20 x 20 map fills 52 % of them: those layers stay on the implicit-GEMM tiles).  BSY_CONV32X_PATCH=0 / 1 forces it off / on.
+    const bool patch_ok = a.ks == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && a.dst_scale == 1 && a.C0 % 16 == 0 && a.OH == a.H && a.OW == a.W;
+    const bool patch_fit = (long long)ceil_div(a.H, 8) * 8 * ceil_div(a.W, 16) * 16 * 10 <= (long long)a.H * a.W * 13;  // <= 30 % of the tile area outside the map
+    if (patch_ok && force < 0 && (ep ? atoi(ep) != 0 : patch_fit)) {
+        if (a.Cout > 64) return launch_patch<2, false, 1>(a, s);
+        if (a.Cout > 32) return launch_patch<1, false, 1>(a, s);
+        return launch_patch<1, true, 3>(a, s);
+    }
+    int big = 0;
+    const long long ptiles = (M + 255) / 256;
+    if (a.Cout >= 256 && ptiles * ceil_div(a.Cout, 256) >= 128) big = 2;
+    else if (a.Cout >= 128 && ptiles * ceil_div(a.Cout, 128) >= 128) big = 1;
+    if (force >= 0) big = force == 2 ? (a.Cout >= 256 ? 2 : (a.Cout >= 128 ? 1 : 0)) : (force == 1 ? (a.Cout >= 128 ? 1 : 0) : 0);
+    if (big) {
+        const int tn = big == 2 ? 256 : 128, ntn_b = ceil_div(a.Cout, tn);
+        const long long nb = (long long)ceil_div((int)M, 256) * ntn_b;
+        if (nb > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv32x_mfma: grid out of range");
+        if (big == 2 && bk == 16) hipLaunchKernelGGL((conv32x_big_kernel<256, 16>), dim3((unsigned)nb), dim3(512), 0, s, a, (int)M, ntn_b);
+        else if (big == 2) hipLaunchKernelGGL((conv32x_big_kernel<256, 32>), dim3((unsigned)nb), dim3(512), 0, s, a, (int)M, ntn_b);
+        else if (bk == 16) hipLaunchKernelGGL((conv32x_big_kernel<128, 16>), dim3((unsigned)nb), dim3(512), 0, s, a, (int)M, ntn_b);
+        else hipLaunchKernelGGL((conv32x_big_kernel<128, 32>), dim3((unsigned)nb), dim3(512), 0, s, a, (int)M, ntn_b);
+        HIP_TRY(hipGetLastError());
+        return BSY_OK;
+    }
     const bool wide = a.Cout > 64, thin = a.Cout <= 32;
     const int ntn = ceil_div(a.Cout, wide ? 128 : (thin ? 32 : 64));
     const long long nblk = (long long)ceil_div((int)M, 128) * ntn;

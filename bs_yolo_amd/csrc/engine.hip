@@ -21,6 +21,7 @@ struct bsy_engine {
     char* arena = nullptr;
     size_t arena_bytes = 0;
     unsigned arena_gen = 0;  // bumped whenever the arena moves: captured graphs hold its addresses
+    unsigned weights_gen = 0;  // bumped by every bsy_engine_load_weights: captured graphs hold addresses inside the weight blob too
 };
 
 struct bsy_plan {
@@ -43,7 +44,7 @@ struct bsy_plan {
     // captured forwards (bsy_plan_graph_launch): one executable graph per set of external pointers, oldest first
     struct Captured {
         std::vector<void*> ext;
-        unsigned arena_gen;
+        unsigned arena_gen, weights_gen;
         hipGraphExec_t exec;
     };
     std::vector<Captured> graphs;
@@ -76,9 +77,13 @@ extern "C" int bsy_engine_load_weights(bsy_engine* e, const void* host_blob, siz
     if (!e || !host_blob || !bytes) BSY_FAIL(BSY_ERR_ARG, "load_weights: bad argument");
     HIP_TRY(hipSetDevice(e->device));
     if (e->weights) {
+        // a reload on an engine that has run: nothing may still be reading the old blob (plans resolve `weights + w_off` when they
+        // are enqueued), and graphs captured so far hold its addresses -- weights_gen below makes bsy_plan_graph_launch drop them
+        HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipFree(e->weights));
         e->weights = nullptr;
     }
+    ++e->weights_gen;
     // BSY_WEIGHT_GUARD=<bytes> (test aid): that many bytes of 0x7C behind the blob -- as f16 every pair is a NaN (0x7C7C), as
     // f32 a huge finite number -- so a kernel that reads past the packed weights AND uses what it read changes the outputs
     // (tests compare a poisoned engine with a plain one; round 1 found such a read in the flat-DMA path by accident, 8ab4d40).
@@ -663,8 +668,8 @@ extern "C" int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream
 // eager replay is bound by the host's launch rate and by the fork / join events of the head lanes; a captured graph hands the
 // whole dependency structure -- lanes included, they become edges -- to the GPU's command processor in one submission.
 // The graph bakes in every address: it is cached per set of external pointers (callers that cycle through a few input / output
-// buffers hit the cache; at most BSY_GRAPH_MAX = 8 graphs per plan, oldest dropped), and dropped when the arena moves or the
-// tuning changes.  Captures on `stream` in thread-local mode (bsy_plan_run issues nothing but kernel launches and event
+// buffers hit the cache; at most BSY_GRAPH_MAX = 8 graphs per plan, least recently used dropped), and dropped when the arena
+// moves, the weight blob is replaced (bsy_engine_load_weights) or the tuning changes.  Captures on `stream` in thread-local mode (bsy_plan_run issues nothing but kernel launches and event
 // record / wait pairs); if a capture fails the plan runs eagerly, now and later.  *captured (may be null): 1 when this call
 // had to capture, 0 when it replayed a cached graph, -1 when it ran eagerly.
 #define BSY_GRAPH_MAX 8
@@ -673,16 +678,17 @@ extern "C" int bsy_plan_graph_launch(bsy_plan* p, void* const* ext, int n_ext, b
     hipStream_t s = (hipStream_t)stream;
     if (captured) *captured = -1;
     if (p->graph_unavailable || !s) return bsy_plan_run(p, ext, n_ext, stream);  // (the null stream cannot be captured)
-    const unsigned gen = p->use_arena ? p->eng->arena_gen : 0u;
+    const unsigned gen = p->use_arena ? p->eng->arena_gen : 0u, wgen = p->eng->weights_gen;
     std::vector<void*> key(ext, ext + n_ext);
     for (size_t i = 0; i < p->graphs.size(); ++i)
-        if (p->graphs[i].arena_gen == gen && p->graphs[i].ext == key) {
+        if (p->graphs[i].arena_gen == gen && p->graphs[i].weights_gen == wgen && p->graphs[i].ext == key) {
             if (captured) *captured = 0;
-            HIP_TRY(hipGraphLaunch(p->graphs[i].exec, s));
+            if (i + 1 != p->graphs.size()) std::rotate(p->graphs.begin() + i, p->graphs.begin() + i + 1, p->graphs.end());  // most recently used last
+            HIP_TRY(hipGraphLaunch(p->graphs.back().exec, s));
             return BSY_OK;
         }
-    for (size_t i = 0; i < p->graphs.size();)  // graphs of an arena that has moved since
-        if (p->graphs[i].arena_gen != gen) { (void)hipGraphExecDestroy(p->graphs[i].exec); p->graphs.erase(p->graphs.begin() + i); } else ++i;
+    for (size_t i = 0; i < p->graphs.size();)  // graphs of an arena that has moved, or of a weight blob that has been replaced since
+        if (p->graphs[i].arena_gen != gen || p->graphs[i].weights_gen != wgen) { (void)hipGraphExecDestroy(p->graphs[i].exec); p->graphs.erase(p->graphs.begin() + i); } else ++i;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -701,7 +707,7 @@ extern "C" int bsy_plan_graph_launch(bsy_plan* p, void* const* ext, int n_ext, b
     }
     (void)hipGraphDestroy(graph);
     if (p->graphs.size() >= BSY_GRAPH_MAX) { (void)hipGraphExecDestroy(p->graphs.front().exec); p->graphs.erase(p->graphs.begin()); }
-    p->graphs.push_back(bsy_plan::Captured{key, gen, exec});
+    p->graphs.push_back(bsy_plan::Captured{key, gen, wgen, exec});
     if (captured) *captured = 1;
     HIP_TRY(hipGraphLaunch(exec, s));
     return BSY_OK;

@@ -106,6 +106,19 @@ class YoloEngine:
         self.stride = torch.tensor(self.meta["strides"])
         self.names = {i: f"{i}" for i in range(self.nc)}
 
+    def load_weights(self, state_dict: Mapping[str, torch.Tensor], bn_eps: float = BN_EPS) -> None:
+        """Replace the engine's weights in place (same graph, new values: an EMA update, a fine-tuned checkpoint).  Plans, tuning and
+        the arena are kept; the library synchronises the device before it frees the old blob and drops every captured graph (they
+        hold addresses inside it: include/bsyolo.h, bsy_engine_load_weights)."""
+        with self._lock:
+            blob = pack_plan_weights(self._packed, state_dict, bn_eps)
+            if len(blob) != self.weight_bytes:
+                raise ValueError(f"state_dict packs to {len(blob)} bytes, the engine was built for {self.weight_bytes}")
+            for plan, _ in self._plans.values():
+                adopt_offsets(plan, self._packed)
+            buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+            L.check(L.lib.bsy_engine_load_weights(self._h, buf, len(blob)))
+
     def _fuse_kw(self):
         return dict(fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head, fuse_dwpw=self.fuse_dwpw,
                     merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail, precision=self.precision,

@@ -82,6 +82,22 @@ def _weights_version(model) -> tuple:
     return (n, ver, ptr)
 
 
+def graph_support(cfg: dict) -> dict:
+    """Which engine precisions can run this yaml graph: {"fp16": bool, "fp32": bool} (the fp32 / fp32x modes also take concat piece
+    widths that are not multiples of 8 channels, e.g. a width multiple of 0.1875).  Decided once, on the host, from the plan alone."""
+    out = {}
+    for prec in ("fp16", "fp32"):
+        try:
+            Plan(cfg, 1, 64, 64, precision=prec)
+            out[prec] = True
+        except (NotImplementedError, AssertionError):
+            out[prec] = False
+    return out
+
+
+FP32_MODES = {"engine_fp32x": "fp32x", "engine_fp32": "fp32", "engine": "fp16", "reference": None}
+
+
 def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_inputs: Optional[str] = None):
     """Install the engine behind ``model.forward``.  Returns the same model object.
 
@@ -89,21 +105,29 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
     engine/predictor.py:131).  The product path stores activations in fp16, which is NOT the fp32 model's arithmetic
     (max |dscore| up to 6e-3 against the fp32 reference, vs the north-star's 1e-3), so it is never
     applied to fp32 callers silently:
-      ``"engine_fp32"`` (default)  the engine's fp32 mode: fp32 storage, convs on the fp32 matrix pipe (csrc/conv32_mfma.hip,
-                                   exact f32 products and sums; |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz against the fp32
-                                   reference; ~83 TFLOP/s, 3.6 k images/s for YOLO11s 640 x 640 -- 1/6 of the fp16 path; a
-                                   one-time log line says so);
+      ``"engine_fp32x"`` (default) the engine's fp32x mode: fp32 storage, dense convs on the fp16 matrix pipe with both operands
+                                   split into f16 pairs (csrc/conv32x_mfma.hip; |dscore| ~1e-5, |dbox| ~1e-5 * imgsz against the
+                                   fp32 reference -- the north-star's 1e-3 with two orders of margin -- at 2-3x the exact mode's
+                                   throughput; a one-time log line says which mode runs);
+      ``"engine_fp32"``            the exact fp32 mode: convs on the fp32 matrix pipe (csrc/conv32_mfma.hip: exact f32 products,
+                                   k-ordered f32 sums, bit-reproducible against the scalar kernels);
       ``"engine"``                 opt in to the fast fp16-storage path for fp32 inputs (outputs come back as fp32);
       ``"reference"``              leave fp32 inputs to the original forward.
     ``BSY_FP32_INPUTS`` overrides the default.  fp16 inputs (``half=True`` / ``model.half()``) always run on the fp16
-    engine: there the reference itself computes in fp16."""
+    engine: there the reference itself computes in fp16.
+
+    Graphs only some precisions can run (``graph_support``): calls in a precision the engine does not take go straight to the
+    reference forward -- decided here, once, not by a failing engine build on every call."""
     import os
     cfg = cfg_of(model)
+    support = graph_support(cfg)
     orig_forward = model.forward
-    state = {"engine": None, "engine32": None, "key": None, "fallbacks": 0, "engine_calls": 0, "fp32_calls": 0, "rebuilds": 0}
-    fp32_mode = fp32_inputs or os.environ.get("BSY_FP32_INPUTS", "engine_fp32")
-    if fp32_mode not in ("reference", "engine", "engine_fp32"):
-        raise ValueError(f"fp32_inputs must be 'engine_fp32', 'engine' or 'reference', not {fp32_mode!r}")
+    state = {"engine": None, "engine32": None, "key": None, "fallbacks": 0, "engine_calls": 0, "fp32_calls": 0, "rebuilds": 0,
+             "support": support, "failed": set()}
+    fp32_mode = fp32_inputs or os.environ.get("BSY_FP32_INPUTS", "engine_fp32x")
+    if fp32_mode not in FP32_MODES:
+        raise ValueError(f"fp32_inputs must be one of {sorted(FP32_MODES)}, not {fp32_mode!r}")
+    prec32 = FP32_MODES[fp32_mode]  # engine precision fp32 images run in (None: the reference forward)
 
     def _engine_for(dev: torch.device, precision: str = "fp16") -> YoloEngine:
         key = (dev.index or 0, _weights_version(model))
@@ -113,13 +137,14 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
                     state[k].close()
                     state[k] = None
             state["key"] = key
-        slot = "engine32" if precision == "fp32" else "engine"
+            state["failed"].clear()
+        slot = "engine" if precision == "fp16" else "engine32"
         if state[slot] is None:
             # weights are read at this moment: after AutoBackend has called fuse()/half() (autobackend.py:139-145); the key
             # makes a later in-place update (EMA, load_state_dict, a training step) or a .half()/.to() rebuild the engine
             sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-            state[slot] = YoloEngine(cfg, sd, device=dev.index or 0, bn_eps=model_bn_eps(model), precision=precision)
             state["rebuilds"] += 1
+            state[slot] = YoloEngine(cfg, sd, device=dev.index or 0, bn_eps=model_bn_eps(model), precision=precision)
         return state[slot]
 
     def forward(self, x, *args, **kwargs):
@@ -129,24 +154,31 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
         profile = kwargs.get("profile", False)
         if (self.training or augment or visualize or embed or profile or args or not isinstance(x, torch.Tensor)
                 or not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float16, torch.float32)
-                or (x.dtype == torch.float32 and fp32_mode == "reference")
                 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32 or x.shape[0] == 0):
             state["fallbacks"] += 1
             return orig_forward(x, *args, **kwargs)
-        want32 = x.dtype == torch.float32 and fp32_mode == "engine_fp32"
-        if want32 and not state.get("fp32_notice"):
+        precision = "fp16" if x.dtype == torch.float16 else prec32
+        # a precision this graph cannot run in (or whose engine build has already failed for these weights): the reference runs it,
+        # without another device-to-host weight copy + engine create / destroy per call
+        if precision is None or not support["fp16" if precision == "fp16" else "fp32"] or precision in state["failed"]:
+            state["fallbacks"] += 1
+            return orig_forward(x, *args, **kwargs)
+        want32 = precision != "fp16"
+        if x.dtype == torch.float32 and not state.get("fp32_notice"):
             state["fp32_notice"] = True  # once per model: which engine default callers (predict(half=False)) are on, and the way out
             import logging
             logging.getLogger("bs_yolo_amd").warning(
-                "fp32 images run in the engine's fp32 mode (fp32 storage, fp32 matrix pipe: the fp32 model's numbers, about 1/6 of the "
-                "fp16 path's throughput -- YOLO11s 640x640: ~3.6 k vs ~21 k images/s per MI355X).  For the fp16 product path call "
-                "predict(half=True) or accelerate(model, fp32_inputs='engine'); fp32_inputs='reference' keeps fp32 inputs on the "
-                "original forward.")
+                "fp32 images run in the engine's %s mode (%s).  fp32_inputs / BSY_FP32_INPUTS selects: engine_fp32x (default: fp32 storage, "
+                "split-f16 matrix products, |dscore| ~1e-5 vs the fp32 model), engine_fp32 (exact fp32 arithmetic, 2-3x slower), engine "
+                "(the fp16 product path, ~3x faster again, |dscore| up to 6e-3), reference (the original forward); predict(half=True) "
+                "runs the fp16 path.", precision, fp32_mode)
         try:
-            y, raws = _engine_for(x.device, "fp32" if want32 else "fp16")(x)
+            y, raws = _engine_for(x.device, precision)(x)
         except (_L.BsyError, NotImplementedError, AssertionError) as e:  # a shape / graph the engine rejects: the reference runs it
             if verbose:
                 print(f"bs_yolo_amd: falling back to the reference forward ({e})")
+            if state["engine" if precision == "fp16" else "engine32"] is None:
+                state["failed"].add(precision)  # the BUILD failed: do not try again until the weights change
             state["fallbacks"] += 1
             return orig_forward(x, *args, **kwargs)
         state["fp32_calls" if want32 else "engine_calls"] += 1

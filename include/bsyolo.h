@@ -140,7 +140,10 @@ typedef struct bsy_op {
 int bsy_engine_create(int device, bsy_engine** out);
 void bsy_engine_destroy(bsy_engine* e);
 /* HOST blob: packed weights produced by bs_yolo_amd/weights.py (BN already folded: replaces
- * utils/torch_utils.py:242-269 fuse_conv_and_bn as called from nn/tasks.py:209-215).  Copied to the device. */
+ * utils/torch_utils.py:242-269 fuse_conv_and_bn as called from nn/tasks.py:209-215).  Copied to the device.
+ * May be called again on an engine that already has plans (same layout, new values: EMA / fine-tuned weights): the call synchronises
+ * the device before it frees the old blob, plans resolve weight addresses when they are enqueued, and every graph captured by
+ * bsy_plan_graph_launch so far is dropped on its plan's next launch (they hold addresses inside the old blob). */
 int bsy_engine_load_weights(bsy_engine* e, const void* host_blob, size_t bytes);
 
 /* ops: HOST array; buf_bytes: HOST array of workspace buffer sizes.  The plan owns its workspace. */
@@ -159,7 +162,8 @@ int bsy_plan_run(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream);
 /* The same forward as ONE graph launch: the first call with a given set of external pointers captures bsy_plan_run on `stream`
  * (thread-local capture; side lanes become graph edges) and instantiates it, later calls with the same pointers replay it -- one
  * submission instead of 70-odd launches, which is what bounds a forward at the 8- or 16-image share of a strong-scaled batch.
- * Up to 8 graphs per plan (oldest dropped); all are dropped when the arena moves or the plan's tuning changes.  `stream` must not
+ * Up to 8 graphs per plan (least recently used dropped); all are dropped when the arena moves, when bsy_engine_load_weights replaces
+ * the weight blob, or when the plan's tuning changes.  `stream` must not
  * be the null stream (falls back to bsy_plan_run, as it does for good if a capture ever fails).  *captured (optional): 1 captured
  * now, 0 replayed, -1 ran eagerly.  Results are those of bsy_plan_run bit for bit (the same launches). */
 int bsy_plan_graph_launch(bsy_plan* p, void* const* ext, int n_ext, bsy_stream stream, int* captured);

@@ -515,8 +515,48 @@ def ap_fixtures():
     print("wrote ap_per_class", len(cases), "cases")
 
 
+def config1_fixture():
+    """BASELINE config 1 on the reference's own test image (ultralytics/assets/bus.jpg, the ASSETS image of the reference's tests,
+    tests/__init__.py:11): pixels -> the reference's LetterBox (predictor.pre_transform's settings: auto=True for a pt model,
+    engine/predictor.py:155-160) -> BGR->RGB, /255 (predictor.py:125-133) -> the reference's YOLO11n DetectionModel (fused, fp32,
+    CPU) -> the reference's non_max_suppression (predict defaults conf 0.25, iou 0.7, cfg/default.yaml) -> scale_boxes to the
+    original image (models/yolo/detect/predict.py:23-41).  The JPEG is decoded ONCE here with PIL (cv2 is not in this image;
+    decoders may differ by +-1 on isolated pixels, which is upstream of the path) and the u8 BGR array is the fixture's input.
+    The class head's bias is shifted so that 2 % of the anchors pass conf 0.25 on this image (random weights)."""
+    from PIL import Image
+    bgr = np.ascontiguousarray(np.asarray(Image.open("/root/reference/ultralytics/assets/bus.jpg").convert("RGB"))[:, :, ::-1])
+    assert bgr.shape == (1080, 810, 3)
+    m, names, _ = build_ref("yolo11", "n", "detect", 80, 0)
+    lb = LetterBox((640, 640), auto=True, stride=32)(image=bgr)
+    assert lb.shape == (640, 480, 3)
+    x = torch.from_numpy(np.ascontiguousarray(lb[None][..., ::-1].transpose(0, 3, 1, 2))).float() / 255.0
+    det = m.model[-1]
+    with torch.inference_mode():
+        _, raw = m(x)
+        top = torch.cat([r[:, 64:].flatten(2) for r in raw], 2).amax(1).flatten()
+        shift = float(np.log(0.25 / 0.75) - torch.quantile(top, 0.98))
+        for seq in det.cv3:
+            seq[-1].bias.add_(shift)
+        y, raw = m(x)
+        pred = rops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300)[0]
+        boxes = rops.scale_boxes(x.shape[2:], pred[:, :4].clone(), bgr.shape)
+    # y is (1, 84, 6300): the fixture keeps the 1000 highest-scoring anchors (every NMS candidate and a wide margin below conf) and,
+    # for the letterboxed pixels, shape + crc32 (the HIP letterbox is compared bit for bit with the oracle's, whose crc is this one)
+    import zlib
+    idx = torch.argsort(y[0, 4:].amax(0), descending=True)[:1000].sort().values
+    out = {"meta": json.dumps({"family": "yolo11", "scale": "n", "nc": 80, "seed": 0, "cls_shift": shift, "conf": 0.25, "iou": 0.7,
+                               "n_det": int(pred.shape[0]), "lb_shape": list(lb.shape), "lb_crc32": zlib.crc32(np.ascontiguousarray(lb).tobytes()),
+                               "y_shape": list(y.shape)}),
+           "bgr": bgr, "y_idx": idx.numpy(), "y_top": y[0][:, idx].numpy(), "pred": pred.numpy(), "boxes": boxes.numpy()}
+    np.savez_compressed(HERE / "config1_bus.npz", **out)
+    print("wrote config1_bus:", pred.shape[0], "detections, letterbox", lb.shape, "shift", shift)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":  # BASELINE config 1 on bus.jpg (round 4)
+        config1_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "val":  # only the validator-matching vectors
         val_match_fixtures()
         sys.exit(0)
@@ -548,3 +588,4 @@ if __name__ == "__main__":
     nms_fixtures()
     letterbox_fixtures()
     val_match_fixtures()
+    config1_fixture()

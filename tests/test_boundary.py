@@ -102,22 +102,25 @@ def test_accelerate_falls_back_where_the_engine_does_not_apply():
 
 
 def test_accelerate_never_downcasts_fp32_callers_silently():
-    """predict()'s default is half=False (engine/predictor.py:131).  fp32 images get the fp32 correctness mode by default
-    (the fp32 model's numbers: |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz against the reference forward), the fp16-storage
-    engine only on request, and the reference forward under fp32_inputs="reference"."""
+    """predict()'s default is half=False (engine/predictor.py:131).  fp32 images get an fp32-storage engine mode by default
+    (fp32x since round 4: split-f16 matrix products; "engine_fp32" = the exact fp32 mode) -- the fp32 model's numbers, |dscore|
+    <= 1e-3, |dbox| <= 1e-3 * imgsz against the reference forward as the north-star states it (measured ~1e-5) --, the
+    fp16-storage engine only on request, and the reference forward under fp32_inputs="reference"."""
     x = _x(seed=7).to(DEV)
     ref = StandIn().to(DEV)
     y_ref, raws_ref = ref(x)
-    m = plugin.accelerate(StandIn().to(DEV))
-    y, raws = m(x)
-    assert m.calls == 0 and m._bsy_state["fp32_calls"] == 1 and m._bsy_state["engine_calls"] == 0 and y.dtype == torch.float32
-    assert float((y[:, 4:] - y_ref[:, 4:]).abs().max()) <= 1e-3
-    assert float((y[:, :4] - y_ref[:, :4]).abs().max()) <= 1e-3 * 96
-    for a, b in zip(raws, raws_ref):
-        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
-    m(x.half())                                 # an fp16 caller of the same model: the fp16 engine
-    assert m._bsy_state["engine_calls"] == 1
-    plugin.restore(m)
+    for mode, prec in ((None, "fp32x"), ("engine_fp32x", "fp32x"), ("engine_fp32", "fp32")):
+        m = plugin.accelerate(StandIn().to(DEV), **({"fp32_inputs": mode} if mode else {}))
+        y, raws = m(x)
+        assert m.calls == 0 and m._bsy_state["fp32_calls"] == 1 and m._bsy_state["engine_calls"] == 0 and y.dtype == torch.float32
+        assert m._bsy_state["engine32"].precision == prec
+        assert float((y[:, 4:] - y_ref[:, 4:]).abs().max()) <= 1e-4          # north-star: 1e-3
+        assert float((y[:, :4] - y_ref[:, :4]).abs().max()) <= 1e-4 * 96     # north-star: 1e-3 * imgsz
+        for a, b in zip(raws, raws_ref):
+            assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+        m(x.half())                                 # an fp16 caller of the same model: the fp16 engine
+        assert m._bsy_state["engine_calls"] == 1
+        plugin.restore(m)
     m = plugin.accelerate(StandIn().to(DEV), fp32_inputs="engine")
     y16, _ = m(x)
     assert m._bsy_state["engine_calls"] == 1 and m._bsy_state["fp32_calls"] == 0 and y16.dtype == torch.float32
@@ -127,6 +130,33 @@ def test_accelerate_never_downcasts_fp32_callers_silently():
     m(x)
     assert m.calls == 1 and m._bsy_state["fallbacks"] == 1
     plugin.restore(m)
+
+
+def test_accelerate_on_a_graph_only_the_fp32_modes_take():
+    """a width multiple of 0.1875 gives C3k2 chunk widths of 12 channels, which only the fp32-storage modes run (the fp16
+    kernels read 8-channel pieces).  `accelerate` accepts the model; fp32 images take the engine; fp16 images go STRAIGHT to the
+    reference forward -- no engine build (device-to-host weight copy, engine create / destroy) per call: `rebuilds` does not grow."""
+    fam = "yolo11"
+    R.SCALES[fam] = dict(R.SCALES[fam], t=(0.5, 0.1875, 1024))
+    try:
+        m = StandIn(fam, "t", 80, "detect", seed=2)
+        m.yaml = dict(stock_cfg(fam, "n", 80), scale="t", scales={"t": [0.5, 0.1875, 1024]})
+        m = m.to(DEV)
+        assert plugin.graph_support(m.yaml) == {"fp16": False, "fp32": True}
+        plugin.accelerate(m)
+        x = _x(seed=9).to(DEV)
+        y_ref, _ = StandIn.forward(m, x)
+        calls0 = m.calls
+        y, _ = m(x)
+        st = m._bsy_state
+        assert m.calls == calls0 and st["fp32_calls"] == 1 and st["rebuilds"] == 1
+        assert float((y[:, 4:] - y_ref[:, 4:]).abs().max()) <= 1e-4 and float((y[:, :4] - y_ref[:, :4]).abs().max()) <= 1e-4 * 96
+        for i in range(3):
+            m(x.half())
+        assert m.calls == calls0 + 3 and st["fallbacks"] == 3 and st["rebuilds"] == 1 and st["engine"] is None
+        plugin.restore(m)
+    finally:
+        R.SCALES[fam].pop("t", None)
 
 
 def test_accelerate_follows_weight_updates_half_and_to():

@@ -147,6 +147,65 @@ def test_conv32_routing_falls_back_to_scalar():
             O.conv2d_nhwc_f32(nhwc(x).to(DEV), w, b, 3, 1, True, impl=2)
 
 
+CONV32X_CASES = CONV32_CASES + [
+    (4, 40, 40, 256, 256, 3, 2, True, False, 0),     # 256 x 256 tile (two pixel tiles, K = 2304), stride 2
+    (2, 80, 80, 192, 256, 1, 1, True, True, 0),      # 256 x 256 tile, 1x1, shortcut, 50 pixel tiles
+    (3, 47, 33, 128, 136, 3, 1, True, True, 8),      # 256 x 128 tile: ragged last pixel tile, couts past the second tile's range
+    (2, 64, 64, 64, 128, 1, 1, False, False, 0),     # 256 x 128 tile, thin K = 64 (two K-steps)
+    (2, 80, 80, 128, 64, 3, 1, True, False, 0),      # patch kernel: Detect cv2.0.0's shape (four 32-channel chunks, 64 couts)
+    (3, 40, 40, 64, 160, 3, 1, True, True, 0),       # patch kernel: 128-cout tiles, the second one ragged; 40 x 40 = 5 x 3 tiles, last column half outside
+    (2, 37, 21, 48, 16, 3, 1, True, False, 8),       # patch kernel: 16-channel chunks (Cin = 48), thin tile, ragged map, padded row stride
+    (2, 160, 160, 16, 32, 3, 1, True, True, 0),      # patch kernel: ONE 16-channel chunk (model.2.m.0.cv2 of YOLO11s)
+]
+
+
+@pytest.mark.parametrize("case", CONV32X_CASES)
+def test_conv32x_matches_fp64_reference(case, monkeypatch):
+    """fp32x mode's conv (conv32x_mfma.hip: fp32 storage, operands split into f16 pairs, three fp16 MFMAs per product) against an
+    fp64 torch conv: 2e-6 of the output range -- the exact fp32 kernel's own distance to fp64 on these cases is 1-2e-6 (one rounding
+    per product), the split-f16 form measured 0.4-1.6e-6 -- on every tile the launcher can pick (128-pixel tiles, 256 x 128, 256 x 256;
+    K-steps of 16 and 32).  Activations include tiny values (lo parts in f16's subnormal range) and channels outside the view hold
+    NaNs."""
+    B, H, W, cin, cout, k, s, act, use_res, ldx = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, cin, H, W, generator=g)
+    x[:, ::3] *= 1e-3
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.5
+    y = F.conv2d(x.double(), w.double(), b.double(), s, k // 2)
+    if act:
+        y = F.silu(y)
+    res = torch.randn(y.shape, generator=g) if use_res else None
+    if use_res:
+        y = y + res.double()
+    xd = torch.zeros(B, H, W, cin + ldx)
+    xd[..., :cin] = nhwc(x)
+    xd[..., cin:] = float("nan")
+    xd = xd.to(DEV)
+    rd = nhwc(res).to(DEV) if use_res else None
+    rng = max(float(y.abs().max()), 1.0)
+    for env in ({}, {"BSY_CONV32X_PATCH": "1"}, {"BSY_CONV32X_PATCH": "0"}, {"BSY_CONV32X_TILE": "0"}, {"BSY_CONV32X_TILE": "1", "BSY_CONV32X_BK": "16"},
+                {"BSY_CONV32X_TILE": "1"}, {"BSY_CONV32X_TILE": "2", "BSY_CONV32X_BK": "16"}, {"BSY_CONV32X_TILE": "2"}):
+        for kname in ("BSY_CONV32X_PATCH", "BSY_CONV32X_TILE", "BSY_CONV32X_BK"):
+            monkeypatch.delenv(kname, raising=False)
+        for kname, v in env.items():
+            monkeypatch.setenv(kname, v)
+        got = O.conv2d_nhwc_f32x(xd, w, b, k, s, act, res=rd, cin=cin)[..., :cout].cpu()
+        err = float((nchw(got).double() - y).abs().max())
+        assert err <= 2e-6 * rng, (env, err, rng)
+
+
+def test_conv32x_rejects_what_it_does_not_take():
+    """Shapes outside the kernel's rules (Cout % 4, Cin % 8) are BSY_ERR_ARG on the stand-alone entry point; the engine routes them
+    to the exact kernels (test_engine_on_custom_width_multiples runs such graphs in this mode)."""
+    g = torch.Generator().manual_seed(5)
+    for cin, cout in ((16, 6), (12, 16)):
+        x = torch.randn(2, 9, 9, cin, generator=g).to(DEV)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+        with pytest.raises(L.BsyError):
+            O.conv2d_nhwc_f32x(x, w, torch.zeros(cout), 3, 1, True)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
 def test_conv32_first_mfma_equals_scalar(dt):
     """fp32 mode's image conv on the fp32 MFMA kernel (taps widened to 8 k values, 5 of them zero) = the scalar kernel, bit for bit."""
@@ -919,6 +978,33 @@ def test_engine_graph_mode_equals_eager(fam, scale, nc, task, shape, own_stream)
     graph.close()
 
 
+def test_engine_graph_mode_follows_a_weight_reload():
+    """captured graphs hold addresses inside the weight blob.  Reloading weights on an engine that has captured graphs
+    (bsy_engine_load_weights frees and reallocates the blob) must drop them: the next graph launch re-captures and returns the bits
+    of an eager engine built from the new weights -- never a replay that reads the freed blob."""
+    m = R.Model("yolo11", "n", 80, "detect")
+    P0, P1 = R.synth_params(m, 3), R.synth_params(m, 4)
+    cfg = stock_cfg("yolo11", "n")
+    x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(5)).half().to(DEV)
+    stream = torch.cuda.Stream(device=DEV)
+    g = YoloEngine(cfg, P0, autotune=False, graph=True, graph_ring=1)
+    e0, e1 = YoloEngine(cfg, P0, autotune=False), YoloEngine(cfg, P1, autotune=False)
+    with torch.cuda.stream(stream):
+        a0 = g(x)[0].clone()
+        a0b = g(x)[0].clone()
+        assert g.graph_stats == {"captures": 1, "replays": 1, "eager": 0}, g.graph_stats
+        g.load_weights(P1)
+        a1 = g(x)[0].clone()
+        a1b = g(x)[0].clone()
+        r0, r1 = e0(x)[0], e1(x)[0]
+    torch.cuda.synchronize()
+    assert g.graph_stats == {"captures": 2, "replays": 2, "eager": 0}, g.graph_stats  # the old graph was not replayed
+    assert torch.equal(a0, r0) and torch.equal(a0b, r0)
+    assert torch.equal(a1, r1) and torch.equal(a1b, r1) and not torch.equal(r0, r1)
+    for e in (g, e0, e1):
+        e.close()
+
+
 def test_engine_serialises_forwards_across_streams_and_threads():
     """All plans of an engine share one liveness-packed arena (round 2), so two forwards must never overlap: forwards
     enqueued on different torch streams, of different shapes (different plans aliasing the same memory), and from two host threads
@@ -1670,14 +1756,17 @@ def test_engine_splits_batches_by_the_largest_view():
 # fp32 correctness mode (csrc/ref32.hip): the north-star's tolerance, asserted as stated -- |dscore| <= 1e-3 and
 # |dbox| <= 1e-3 * imgsz against the REFERENCE's own fp32 outputs, on all seven golden graphs and every golden input.
 # ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["fp32", "fp32x"])
 @pytest.mark.parametrize("tag", ["yolo11n_detect", "yolo11s_detect", "yolo11m_detect", "yolo11n_segment",
                                  "yolov8n_segment", "bsyolo11n_detect", "bsyolo11s_detect", "yolov5n_detect", "yolov5s_detect"])
-def test_engine_fp32_mode_meets_the_north_star_tolerance(tag):
+def test_engine_fp32_mode_meets_the_north_star_tolerance(tag, precision):
+    """Both fp32-storage modes -- "fp32" (exact fp32 arithmetic) and "fp32x" (round 4: dense convs on the fp16 matrix pipe with
+    split-f16 operands) -- against the REFERENCE's own fp32 outputs at the north-star's tolerance, as stated."""
     z = np.load(GOLDEN / f"graph_{tag}.npz")
     meta = json.loads(str(z["meta"]))
     m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
     P = R.synth_params(m, meta["seed"])
-    eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), P, precision="fp32")
+    eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), P, precision=precision)
     nc, si = meta["nc"], 0
     while f"x{si}" in z:
         x = torch.from_numpy(z[f"x{si}"])
@@ -1737,6 +1826,75 @@ def test_engine_fp32_mode_layers_match_reference(monkeypatch):
             n += 1
         assert n >= 22
         eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x"])
+@pytest.mark.parametrize("scale", ["s", "m"])
+def test_engine_fp32_modes_match_the_oracle_at_640(scale, precision):
+    """the fp32 modes were pinned to the reference only on <= 96 x 160 inputs, while the tiles, occupancy and partial
+    rounds of the real workload occur at 640 x 640.  Here: YOLO11s / YOLO11m, two 640 x 640 images, both fp32-storage modes against
+    the CPU oracle (itself pinned by the reference's golden vectors, tests/test_oracle_golden.py) at the north-star's tolerance:
+    |dscore| <= 1e-3, |dbox| <= 1e-3 * imgsz, raw maps <= 1e-3 of their range (measured: ~1e-5)."""
+    m = R.Model("yolo11", scale, 80, "detect")
+    P = R.synth_params(m, 5)
+    x = torch.rand(2, 3, 640, 640, generator=torch.Generator().manual_seed(640))
+    with torch.inference_mode():
+        yref, rawref = m.forward(P, x)
+    eng = YoloEngine(stock_cfg("yolo11", scale), P, precision=precision)
+    y, raws = eng(x.to(DEV))
+    torch.cuda.synchronize()
+    y = y.cpu()
+    es, eb = float((y[:, 4:] - yref[:, 4:]).abs().max()), float((y[:, :4] - yref[:, :4]).abs().max())
+    assert tuple(y.shape) == (2, 84, 8400) and es <= 1e-3 and eb <= 1e-3 * 640, (scale, precision, es, eb)
+    assert es <= 2e-4 and eb <= 2e-4 * 640, (scale, precision, es, eb)  # what the modes actually hold, with margin
+    for r, rr in zip(raws, rawref):
+        assert float((r.cpu() - rr).abs().max()) <= 1e-3 * max(1.0, float(rr.abs().max()))
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x", "fp16"])
+def test_config1_on_the_reference_image(precision):
+    """BASELINE config 1 on the reference's own test image (ultralytics/assets/bus.jpg; pixels decoded once in the build container,
+    tests/golden/config1_bus.npz, every expected value produced by RUNNING THE REFERENCE: LetterBox -> YOLO11n -> non_max_suppression
+    -> scale_boxes, make_fixtures.py config1_fixture).  HIP letterbox: the reference's letterboxed pixels bit for bit (crc32);
+    forward: y at the reference's 1000 highest-scoring anchors; HIP NMS + scale_boxes: the reference's detections one for one in the
+    fp32 modes (same count, same classes, boxes to 1e-3 * imgsz, scores to 1e-3); the fp16 path: its documented statistics."""
+    import zlib
+    z = np.load(GOLDEN / "config1_bus.npz")
+    meta = json.loads(str(z["meta"]))
+    bgr = z["bgr"]
+    m = R.Model("yolo11", "n", 80, "detect")
+    P = R.synth_params(m, meta["seed"])
+    for k in P:
+        if ".cv3." in k and k.endswith(".2.bias"):
+            P[k] = P[k] + meta["cls_shift"]
+    half = precision == "fp16"
+    xd = HLB.preprocess([bgr], (640, 640), half=half, pt=True, stride=32, device=DEV)
+    assert tuple(xd.shape) == (1, 3, 640, 480)
+    lb = (xd[0].float() * 255.0).round().to(torch.uint8).permute(1, 2, 0).flip(-1).contiguous().cpu().numpy()  # back to HWC BGR u8
+    assert list(lb.shape) == meta["lb_shape"] and zlib.crc32(lb.tobytes()) == meta["lb_crc32"]
+    eng = YoloEngine(stock_cfg("yolo11", "n"), P, **({} if half else {"precision": precision}))
+    y, _ = eng(xd)
+    assert list(y.shape) == meta["y_shape"]
+    ytop = y[0].float().cpu()[:, torch.from_numpy(z["y_idx"])].numpy()  # before NMS: it converts the box rows to xyxy in place (ops.py:243-244)
+    det, counts = HN.nms_batched(y, meta["conf"], meta["iou"], max_det=300)
+    HN.scale_boxes_batched(det, counts, xd.shape[2:], [bgr.shape])
+    torch.cuda.synchronize()
+    es, eb = np.abs(ytop[4:] - z["y_top"][4:]).max(), np.abs(ytop[:4] - z["y_top"][:4]).max()
+    n = int(counts[0])
+    got, ref_pred, ref_boxes = det[0, :n].cpu().numpy(), z["pred"], z["boxes"]
+    if half:
+        # fp16 storage on a real photograph (wider activation range than the seeded-noise inputs of the golden graphs): measured score
+        # max 8.1e-3, box max 1.8 px over the 1000 anchors -- the fp16 path's stated class of error (DESIGN.md section 4), not 1e-3
+        assert es < 2e-2 and eb < 4.0, (es, eb)
+        assert abs(n - len(ref_pred)) <= max(3, len(ref_pred) // 10), (n, len(ref_pred))
+        return eng.close()
+    assert es <= 1e-3 and eb <= 1e-3 * 640, (precision, es, eb)
+    assert n == meta["n_det"] == len(ref_pred), (n, meta["n_det"])
+    assert np.array_equal(got[:, 5], ref_pred[:, 5])                       # same classes in the same (score) order
+    assert np.abs(got[:, 4] - ref_pred[:, 4]).max() <= 1e-3
+    assert np.abs(got[:, :4] - ref_boxes).max() <= 1e-3 * 1080             # boxes in the ORIGINAL image's pixels (1080 x 810)
+    eng.close()
 
 
 def test_engine_fp16_path_vs_fp32_mode_at_the_benchmark_size():

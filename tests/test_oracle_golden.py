@@ -280,3 +280,34 @@ def test_masks_native_oracle_matches_reference_golden():
             assert np.array_equal(got.numpy().astype(np.uint8), z[f"c{ci}.native"])
         np.testing.assert_allclose(PP.scale_masks(protos[None, :2], shape).numpy(), z[f"c{ci}.scaled"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(PP.scale_masks(protos[None, :2], shape, padding=False).numpy(), z[f"c{ci}.scaled_nopad"], rtol=0, atol=1e-6)
+
+
+def test_config1_on_the_reference_image():
+    """BASELINE config 1 on ultralytics/assets/bus.jpg (tests/golden/config1_bus.npz: every expected value was produced by the
+    reference -- LetterBox, YOLO11n forward, non_max_suppression, scale_boxes; make_fixtures.py config1_fixture): the oracle's
+    letterbox gives the reference's pixels (crc32), its forward the reference's y at the 1000 highest-scoring anchors, its NMS and
+    scale_boxes the reference's detections."""
+    import zlib
+    z = _load("config1_bus.npz")
+    meta = json.loads(str(z["meta"]))
+    bgr = z["bgr"]
+    assert bgr.shape == (1080, 810, 3) and bgr.dtype == np.uint8
+    lb = LB.pre_transform([bgr], (640, 640), True, 32)[0]
+    assert list(lb.shape) == meta["lb_shape"] and zlib.crc32(np.ascontiguousarray(lb).tobytes()) == meta["lb_crc32"]
+    x = LB.preprocess([bgr], (640, 640), half=False, pt=True, stride=32)
+    m = R.Model("yolo11", "n", 80, "detect")
+    P = R.synth_params(m, meta["seed"])
+    for k in P:
+        if ".cv3." in k and k.endswith(".2.bias"):
+            P[k] = P[k] + meta["cls_shift"]
+    with torch.inference_mode():
+        y, _ = m.forward(P, x)
+    assert list(y.shape) == meta["y_shape"]
+    ytop = y[0][:, torch.from_numpy(z["y_idx"])].numpy()
+    np.testing.assert_allclose(ytop[:4], z["y_top"][:4], rtol=1e-5, atol=3e-3)
+    np.testing.assert_allclose(ytop[4:], z["y_top"][4:], **TOL)
+    pred = PP.non_max_suppression(y.clone(), meta["conf"], meta["iou"], max_det=300)[0]
+    assert pred.shape[0] == meta["n_det"]
+    np.testing.assert_allclose(pred.numpy(), z["pred"], rtol=1e-5, atol=3e-3)
+    boxes = PP.scale_boxes(x.shape[2:], pred[:, :4].clone(), bgr.shape)
+    np.testing.assert_allclose(boxes.numpy(), z["boxes"], rtol=1e-5, atol=5e-3)
