@@ -640,10 +640,121 @@ int launch_patch(const Conv32Args& a, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
+
+// ---- image conv (round 4): BCHW image (f16 / f32, 3 channels), 3 x 3, stride 1 or 2 -> NHWC f32 --------------------------------
+// K = (kh, kw, c) = 27, padded to 32 with zeros: ONE K-step of two 16-deep sub-steps, so no loop and no ring -- a workgroup gathers
+// the 27 taps of its 128 output pixels straight from the three image planes (thread = (pixel, half of the K range)), splits them, and
+// every wave multiplies its 32 pixels with all NT 32-cout tiles of the layer (weights: the layer's two planes [Cout][32] parked in
+// LDS).  HBM-bound by design: B x 3 x H x W in, B x OH x OW x Cout x 4 bytes out (0.84 GB for YOLO11s at 64 x 640 x 640; the exact
+// kernel took 0.63 ms over it on the fp32 matrix pipe).
+template <int NT, typename TI>
+__global__ __launch_bounds__(256) void conv32x_first_kernel(const Conv32Args a, const int M) {
+    constexpr int TM = 128, LDH = 40;
+    __shared__ __attribute__((aligned(16))) half_t sP[2][TM * LDH];
+    __shared__ __attribute__((aligned(16))) half_t sW[2][NT * 32 * LDH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * TM;
+    const int ohw = a.OH * a.OW;
+    // weights: NT * 32 rows x 4 pieces per plane
+    for (int id = tid; id < NT * 32 * 4; id += 256) {
+        const int row = id >> 2, q = id & 3;
+        H8 h, l;
+        h.f = f32x4{0.f, 0.f, 0.f, 0.f};
+        l.f = h.f;
+        if (row < a.Cout) {
+            h.f = *reinterpret_cast<const f32x4*>(a.wx_hi + (size_t)row * a.wx_kpad + 8 * q);
+            l.f = *reinterpret_cast<const f32x4*>(a.wx_lo + (size_t)row * a.wx_kpad + 8 * q);
+        }
+        *reinterpret_cast<half8*>(&sW[0][row * LDH + 8 * q]) = h.h;
+        *reinterpret_cast<half8*>(&sW[1][row * LDH + 8 * q]) = l.h;
+    }
+    {   // pixels: thread = (pixel tid >> 1, k half tid & 1): k = 16 half .. 16 half + 15, k = (kh * 3 + kw) * 3 + c
+        const int pl = tid >> 1, k0 = 16 * (tid & 1);
+        const int m = m0 + pl;
+        const bool pok = m < M;
+        const int mm = pok ? m : 0;
+        const int n = mm / ohw, rem = mm - n * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
+        const int iy0 = oh * a.stride - a.pad, ix0 = ow * a.stride - a.pad;
+        const size_t hw = (size_t)a.H * a.W;
+        const TI* img = reinterpret_cast<const TI*>(a.src0) + (size_t)n * 3 * hw;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + j, tap = k / 3, c = k - 3 * tap, kh = tap / 3, kw = tap - 3 * kh;
+            const int iy = iy0 + kh, ix = ix0 + kw;
+            v[j] = (pok && k < 27 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? (float)img[(size_t)c * hw + (size_t)iy * a.W + ix] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            H8 hi, lo;
+            split8(f32x4{v[8 * g], v[8 * g + 1], v[8 * g + 2], v[8 * g + 3]}, f32x4{v[8 * g + 4], v[8 * g + 5], v[8 * g + 6], v[8 * g + 7]}, hi, lo);
+            *reinterpret_cast<half8*>(&sP[0][pl * LDH + k0 + 8 * g]) = hi.h;
+            *reinterpret_cast<half8*>(&sP[1][pl * LDH + k0 + 8 * g]) = lo.h;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int an = 0; an < NT; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = an * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            acc[an][r] = c < a.Cout ? a.bias[c] : 0.f;
+        }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int o = (wave * 32 + lj) * LDH + 16 * s2 + 8 * lh;
+        const half8 bh = *reinterpret_cast<const half8*>(&sP[0][o]);
+        const half8 bl = *reinterpret_cast<const half8*>(&sP[1][o]);
+#pragma unroll
+        for (int an = 0; an < NT; ++an) {
+            const int ow_ = (an * 32 + lj) * LDH + 16 * s2 + 8 * lh;
+            const half8 ah = *reinterpret_cast<const half8*>(&sW[0][ow_]);
+            const half8 al = *reinterpret_cast<const half8*>(&sW[1][ow_]);
+            acc[an] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[an], 0, 0, 0);
+            acc[an] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[an], 0, 0, 0);
+            acc[an] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[an], 0, 0, 0);
+        }
+    }
+    const int m = m0 + wave * 32 + lj;
+    if (m >= M) return;
+#pragma unroll
+    for (int an = 0; an < NT; ++an)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = an * 32 + 8 * q + 4 * lh;
+            if (c >= a.Cout) continue;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = acc[an][4 * q + e];
+                v[e] = a.act ? silu_x(t) : t;
+            }
+            *reinterpret_cast<f32x4*>(a.dst + (size_t)m * a.ldd + c) = v;
+        }
+}
+
+template <typename TI>
+int launch_first(const Conv32Args& a, int M, hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(M, 128));
+    switch (ceil_div(a.Cout, 32)) {
+        case 1: hipLaunchKernelGGL((conv32x_first_kernel<1, TI>), grid, dim3(256), 0, s, a, M); break;
+        case 2: hipLaunchKernelGGL((conv32x_first_kernel<2, TI>), grid, dim3(256), 0, s, a, M); break;
+        case 3: hipLaunchKernelGGL((conv32x_first_kernel<3, TI>), grid, dim3(256), 0, s, a, M); break;
+        default: hipLaunchKernelGGL((conv32x_first_kernel<4, TI>), grid, dim3(256), 0, s, a, M); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return BSY_OK;
+}
 }  // namespace
 
 bool conv32x_mfma_supported(const Conv32Args& a) {
-    if (a.first || !a.wx_hi || !a.wx_lo || a.wx_kpad <= 0 || (a.wx_kpad & 31)) return false;
+    if (!a.wx_hi || !a.wx_lo || a.wx_kpad <= 0 || (a.wx_kpad & 31)) return false;
+    if (a.first)  // the image conv: 3 x 3 over 3 channels (K = 27 -> one 32-deep step), up to 128 couts, NHWC f32 output in 16-byte pieces
+        return a.ks == 3 && a.C0 == 3 && !a.C1 && !a.up0 && a.wx_kpad == 32 && a.Cout > 0 && a.Cout <= 128 && !(a.Cout & 3) && !(a.ldd & 3) && !a.res &&
+               a.dst_scale == 1 && (a.src_dtype == BSY_F16 || a.src_dtype == BSY_F32) && !(((uintptr_t)a.wx_hi | (uintptr_t)a.wx_lo | (uintptr_t)a.dst) & 15);
     if (!conv32_mfma_supported(a)) return false;  // the same view / alignment rules as the exact MFMA kernel
     if (((uintptr_t)a.wx_hi | (uintptr_t)a.wx_lo) & 15) return false;
     if (a.wx_kpad < a.ks * a.ks * (a.C0 + a.C1)) return false;
@@ -655,6 +766,7 @@ int launch_conv32x_mfma(const Conv32Args& a, hipStream_t s) {
     if (!conv32x_mfma_supported(a)) BSY_FAIL(BSY_ERR_ARG, "conv32x_mfma: unsupported shape / alignment");
     const long long M = (long long)a.B * a.OH * a.OW;
     if (M <= 0 || M > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv32x_mfma: M out of range");
+    if (a.first) return a.src_dtype == BSY_F16 ? launch_first<half_t>(a, (int)M, s) : launch_first<float>(a, (int)M, s);
     // tile choice (BSY_CONV32X_TILE=0 / 1 / 2 forces the 128-pixel tiles / 256 x 128 / 256 x 256 where they apply; _BK=16 / 32):
     // 256 x 256 from 256 couts and 256 x 128 from 128, when the grid still gives every CU a workgroup or the layer is deep enough
     // that staged bytes, not tile quantisation, set its time

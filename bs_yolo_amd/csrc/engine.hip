@@ -283,7 +283,7 @@ int run_op_f32(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, 
             a.act = op.act; a.dst_scale = op.dst_scale > 0 ? op.dst_scale : 1; a.dst_dy = op.dst_dy; a.dst_dx = op.dst_dx;
             if (op.out_f32 >= 2) BSY_FAIL(BSY_ERR_ARG, "fp32 mode: fused Detect decoder ops are not part of fp32 plans");
             if (!R.ok) return BSY_ERR_ARG;
-            if (op.prec == 2 && !a.first) {  // fp32x: split-f16 planes behind the f32 matrix; shapes the kernel does not take stay exact
+            if (op.prec == 2) {  // fp32x: split-f16 planes behind the f32 matrix; shapes the kernel does not take stay exact
                 const size_t K = (size_t)a.ks * a.ks * (a.C0 + a.C1), kpad = (K + 31) & ~(size_t)31;
                 const size_t hi_off = fp32x_align(K * a.Cout * 4), lo_off = hi_off + fp32x_align((size_t)a.Cout * kpad * 2);
                 a.wx_hi = (const half_t*)(wb + op.w_off + hi_off);

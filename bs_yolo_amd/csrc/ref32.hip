@@ -201,6 +201,103 @@ __global__ __launch_bounds__(256) void sppf32x4_kernel(float* buf, int ld, int B
     *reinterpret_cast<f32x4*>(o + 3 * C) = m2;
 }
 
+// 3 x 3, stride 1: four outputs along x per thread from a register window of 3 x 6 pieces (18 16-byte loads for four outputs instead
+// of 36; the depthwise layers of Detect's class branch at 80 x 80 x 128 were bound by load issue, 0.19 ms each for 0.42 GB of traffic).
+// Every output still sums its taps in (kh, kw) order starting at the bias, and a tap outside the map contributes fmaf(0, w, acc) = acc:
+// the same bits as dw32x4_kernel / dw32_kernel.
+__global__ __launch_bounds__(256) void dw32_3x3x4_kernel(const Dw32Args a) {
+    const int C4 = a.C >> 2, XB = (a.OW + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.B * a.OH * XB * C4) return;
+    const int c = (int)(idx % C4) * 4;
+    long long t = idx / C4;
+    const int ow0 = (int)(t % XB) * 4;
+    t /= XB;
+    const int oh = (int)(t % a.OH);
+    const int n = (int)(t / a.OH);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b + c);
+    f32x4 acc[4] = {bias, bias, bias, bias};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int iy = oh - 1 + i;
+        const bool rowok = (unsigned)iy < (unsigned)a.H;
+        const float* row = a.src + ((size_t)(n * a.H + (rowok ? iy : 0)) * a.W) * a.lds + c;
+        f32x4 x[6];
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+            const int ix = ow0 - 1 + col;
+            x[col] = (rowok && (unsigned)ix < (unsigned)a.W) ? *reinterpret_cast<const f32x4*>(row + (size_t)ix * a.lds) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(a.w + (size_t)(i * 3 + j) * a.wld + c);
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(x[o + j][e], w[e], acc[o][e]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (ow0 + o >= a.OW) break;
+        const size_t pix = (size_t)(n * a.OH + oh) * a.OW + ow0 + o;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c + e < a.act_c ? silu32(acc[o][e]) : acc[o][e];
+        if (a.res) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(a.res + pix * a.ldr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+        }
+        *reinterpret_cast<f32x4*>(a.dst + pix * a.ldd + c) = v;
+    }
+}
+
+// SPPF's three chained 5 x 5 max pools out of LDS: one workgroup per (image, 4 V channels) holds the map in two LDS buffers and
+// runs every pool as a row pass and a column pass (separable; -inf padding = windows clipped to the map), writing the three results
+// behind the input channels.  Maxima are exact, so this returns sppf32_kernel's bits; that kernel read 169 taps per output (0.22 ms
+// per forward for 26 MB in and 79 MB out), this one reads 30.
+template <int V>
+__global__ __launch_bounds__(256) void sppf32_lds_kernel(float* buf, int ld, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sppf_smem[];
+    const int HW = H * W, NV = HW * V;
+    f32x4* A = reinterpret_cast<f32x4*>(sppf_smem);
+    f32x4* Bf = A + NV;
+    const int tid = threadIdx.x, n = blockIdx.y, c0 = blockIdx.x * 4 * V;
+    float* base = buf + (size_t)n * HW * ld + c0;
+    for (int id = tid; id < NV; id += 256) A[id] = *reinterpret_cast<const f32x4*>(base + (size_t)(id / V) * ld + 4 * (id % V));
+    __syncthreads();
+    for (int pool = 1; pool <= 3; ++pool) {
+        for (int id = tid; id < NV; id += 256) {  // row pass
+            const int p = id / V, x = p % W;
+            f32x4 m = A[id];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d && (unsigned)(x + d) < (unsigned)W) {
+                    const f32x4 v = A[id + d * V];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                }
+            Bf[id] = m;
+        }
+        __syncthreads();
+        for (int id = tid; id < NV; id += 256) {  // column pass; the result is the next pool's input and this pool's output
+            const int p = id / V, y = p / W;
+            f32x4 m = Bf[id];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d && (unsigned)(y + d) < (unsigned)H) {
+                    const f32x4 v = Bf[id + d * W * V];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                }
+            A[id] = m;
+            *reinterpret_cast<f32x4*>(base + (size_t)p * ld + pool * C + 4 * (id % V)) = m;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- attention: out[i] = sum_j softmax_j(scale * q_i . k_j) v_j per (image, head); qkv = [q | k | v] by heads ----------------
 #define ATT32_MAXD 128
 __global__ __launch_bounds__(64) void attn32_kernel(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale,
@@ -407,7 +504,11 @@ int launch_dw32(const Dw32Args& a, hipStream_t s) {
     if (!a.src || !a.w || !a.b || !a.dst || a.kh < 1 || a.kw < 1 || (a.stride != 1 && a.stride != 2)) BSY_FAIL(BSY_ERR_ARG, "dw32: bad argument");
     const bool vec4 = !(a.C & 3) && !(a.lds & 3) && !(a.ldd & 3) && !(a.wld & 3) && (!a.res || !(a.ldr & 3)) &&
                       !(((uintptr_t)a.src | (uintptr_t)a.dst | (uintptr_t)a.w | (uintptr_t)a.b | (uintptr_t)a.res) & 15);
-    if (vec4) hipLaunchKernelGGL(dw32x4_kernel, dim3(nblk((long long)a.B * a.OH * a.OW * (a.C / 4))), dim3(256), 0, s, a);
+    const char* slow_e = getenv("BSY_REF32_SLOW");  // test / A-B aid: the round-3 kernels (read per call: tests flip it)
+    const bool slow = slow_e && atoi(slow_e) != 0;
+    if (vec4 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.OH == a.H && a.OW == a.W && !slow)
+        hipLaunchKernelGGL(dw32_3x3x4_kernel, dim3(nblk((long long)a.B * a.OH * ((a.OW + 3) / 4) * (a.C / 4))), dim3(256), 0, s, a);
+    else if (vec4) hipLaunchKernelGGL(dw32x4_kernel, dim3(nblk((long long)a.B * a.OH * a.OW * (a.C / 4))), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(dw32_kernel, dim3(nblk((long long)a.B * a.OH * a.OW * a.C)), dim3(256), 0, s, a);
     HIP_TRY(hipGetLastError());
     return BSY_OK;
@@ -415,7 +516,21 @@ int launch_dw32(const Dw32Args& a, hipStream_t s) {
 
 int launch_sppf32(float* buf, int ld, int B, int H, int W, int C, hipStream_t s) {
     if (!buf || ld < 4 * C) BSY_FAIL(BSY_ERR_ARG, "sppf32: bad argument");
-    if (!(C & 3) && !(ld & 3) && !((uintptr_t)buf & 15))
+    const char* slow_e = getenv("BSY_REF32_SLOW");
+    const bool slow = slow_e && atoi(slow_e) != 0;
+    const bool vec4 = !(C & 3) && !(ld & 3) && !((uintptr_t)buf & 15);
+    const long long hw = (long long)H * W;
+    // the LDS form: the map of 4 V channels of one image twice in LDS (<= 64 KiB), V as large as fits and divides C / 4
+    int V = 0;
+    for (int v = 4; v >= 1 && !V; v >>= 1)
+        if (hw * v * 32 <= 65536 && (C / 4) % v == 0) V = v;
+    if (vec4 && V && !slow && B <= 65535) {
+        const size_t smem = (size_t)hw * V * 32;
+        const dim3 grid(C / (4 * V), B);
+        if (V == 4) hipLaunchKernelGGL((sppf32_lds_kernel<4>), grid, dim3(256), smem, s, buf, ld, H, W, C);
+        else if (V == 2) hipLaunchKernelGGL((sppf32_lds_kernel<2>), grid, dim3(256), smem, s, buf, ld, H, W, C);
+        else hipLaunchKernelGGL((sppf32_lds_kernel<1>), grid, dim3(256), smem, s, buf, ld, H, W, C);
+    } else if (vec4)
         hipLaunchKernelGGL(sppf32x4_kernel, dim3(nblk((long long)B * H * W * (C / 4))), dim3(256), 0, s, buf, ld, B, H, W, C);
     else
         hipLaunchKernelGGL(sppf32_kernel, dim3(nblk((long long)B * H * W * C)), dim3(256), 0, s, buf, ld, B, H, W, C);

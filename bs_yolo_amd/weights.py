@@ -63,7 +63,7 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f3
     [k*k*cin][cout] (K order (kh, kw, cin) as in the fp16 layout, cout fastest), bias f32 [cout], no padding
     (csrc/ref32.hip); depthwise / ELA records are f32 in both modes.  split (fp32x mode, with f32): the f32 matrix is followed
     by the two f16 planes of split_f16_planes, each part padded to 256 bytes (csrc/engine.hip run_op_f32 computes the same
-    offsets; the image conv keeps the f32 matrix only)."""
+    offsets)."""
     if r.kind == "ela":
         # ELA (nn/Addmodules/ELA.py:36-72): [spatial_conv (C,k)][ch_att.2 (C,k)][gn.weight][gn.bias]; the three scalar mixing
         # weights enter the op record as their sigmoids
@@ -130,7 +130,7 @@ def pack_record(sd: Mapping[str, torch.Tensor], r: WRec, eps: float = BN_EPS, f3
             w, b = w[idx], b[idx]
         if f32:
             wb = w.permute(2, 3, 1, 0).reshape(k * k * cin, cout).contiguous().numpy().tobytes()
-            if split and r.kind not in ("first", "first_s2d"):
+            if split:
                 hi, lo = split_f16_planes(w.permute(0, 2, 3, 1).reshape(cout, k * k * cin))
                 hb = hi.numpy().tobytes()
                 wb = wb + b"\0" * (_align(len(wb)) - len(wb)) + hb + b"\0" * (_align(len(hb)) - len(hb)) + lo.numpy().tobytes()

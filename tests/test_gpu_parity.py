@@ -1803,15 +1803,17 @@ def test_engine_fp32_mode_meets_the_north_star_tolerance(tag, precision):
     eng.close()
 
 
-def test_engine_fp32_mode_layers_match_reference(monkeypatch):
-    """The same per layer (buffers kept alive: BSY_ARENA_REUSE=0): every top-level layer of the fp32 mode against the
-    reference's own layer outputs, 1e-4 of the layer's range."""
+@pytest.mark.parametrize("precision", ["fp32", "fp32x"])
+def test_engine_fp32_mode_layers_match_reference(monkeypatch, precision):
+    """The same per layer (buffers kept alive: BSY_ARENA_REUSE=0): every top-level layer of the fp32-storage modes against the
+    reference's own layer outputs, 1e-4 of the layer's range (fp32x: the image conv, the patch / implicit-GEMM split-f16 kernels and
+    every non-conv kernel in place)."""
     monkeypatch.setenv("BSY_ARENA_REUSE", "0")
     for tag in ("yolo11n_detect", "bsyolo11n_detect", "yolov5n_detect"):
         z = np.load(GOLDEN / f"graph_{tag}.npz")
         meta = json.loads(str(z["meta"]))
         m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
-        eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), R.synth_params(m, meta["seed"]), precision="fp32")
+        eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), R.synth_params(m, meta["seed"]), precision=precision)
         x = torch.from_numpy(z["x0"])
         eng(x.to(DEV))
         torch.cuda.synchronize()
@@ -1895,6 +1897,27 @@ def test_config1_on_the_reference_image(precision):
     assert np.abs(got[:, 4] - ref_pred[:, 4]).max() <= 1e-3
     assert np.abs(got[:, :4] - ref_boxes).max() <= 1e-3 * 1080             # boxes in the ORIGINAL image's pixels (1080 x 810)
     eng.close()
+
+
+def test_fp32_mode_fast_pool_and_depthwise_kernels_return_the_same_bits(monkeypatch):
+    """Round 4 gave the fp32-storage modes an LDS form of SPPF's pools and a register-window form of the 3 x 3 depthwise conv
+    (csrc/ref32.hip).  Maxima are exact and every depthwise output still sums its taps in (kh, kw) order from the bias, so the exact
+    fp32 mode returns the bits of the round-3 kernels (BSY_REF32_SLOW=1) -- on a graph with SPPF, Attention.pe and Detect's DWConv
+    units, at a size with ragged window blocks (W = 72: 18 blocks of four; 9 x 7 maps at stride 32)."""
+    m = R.Model("yolo11", "s", 80, "detect")
+    P = R.synth_params(m, 6)
+    x = torch.rand(2, 3, 288, 224, generator=torch.Generator().manual_seed(6)).to(DEV)
+    outs = []
+    for slow in ("1", "0"):
+        monkeypatch.setenv("BSY_REF32_SLOW", slow)
+        eng = YoloEngine(stock_cfg("yolo11", "s"), P, precision="fp32")
+        y, raws = eng(x)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), [r.clone() for r in raws]))
+        eng.close()
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
 
 
 def test_engine_fp16_path_vs_fp32_mode_at_the_benchmark_size():
