@@ -40,6 +40,7 @@ SOURCES = {
     "ref32.hip": ["-ffp-contract=off", "-fno-vectorize"],  # loop vectoriser: packed f32 math in attn32_kernel otherwise
     "conv32_mfma.hip": ["-ffp-contract=off", "-fno-vectorize"],  # the same flags: its SiLU must be ref32.hip's bit for bit
     "conv32x_mfma.hip": ["-fno-vectorize"],  # fp32x mode: split-f16 operands on the fp16 matrix pipe
+    "attention32x.hip": ["-fno-vectorize"],
     "engine.hip": [],
 }
 

@@ -230,6 +230,8 @@ int launch_mix32(const Mix32Args& a, hipStream_t s);
 int launch_sppf32(float* buf, int ld, int B, int H, int W, int C, hipStream_t s);
 int launch_attn32(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s,
                   int impl = 0);  // impl 0: tiled kernel where it applies (key_dim 32, head_dim 64), 1: generic kernel, 2: tiled or error
+bool attn32x_supported(int ld, int ldo, int kd, int hd, const void* qkv, const void* out);  // attention32x.hip (fp32x mode)
+int launch_attn32x(const float* qkv, int ld, int B, int N, int heads, int kd, int hd, float scale, float* out, int ldo, hipStream_t s);
 int launch_nhwc2nchw32(const float* src, int ld, int B, int C, int hw, void* out, int out_dtype, hipStream_t s);
 int launch_copy32(const float* src, int lds_, int up, int B, int H, int W, int C, float* dst, int ldd, hipStream_t s);
 int launch_gap32(const float* src, int lds_, int B, int H, int W, int C, float* out, int ldo, hipStream_t s);

@@ -316,6 +316,8 @@ int run_op_f32(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, 
             const float* q = R.f(op.src0);
             float* o = R.f(op.dst);
             if (!R.ok) return BSY_ERR_ARG;
+            if (op.prec == 2 && attn32x_supported(op.src0.ld, op.dst.ld, op.key_dim, op.head_dim, q, o))  // fp32x: split-f16 products on the matrix pipe
+                return launch_attn32x(q, op.src0.ld, op.B, op.H * op.W, op.heads, op.key_dim, op.head_dim, op.scale, o, op.dst.ld, s);
             return launch_attn32(q, op.src0.ld, op.B, op.H * op.W, op.heads, op.key_dim, op.head_dim, op.scale, o, op.dst.ld, s);
         }
         case BSY_OP_NHWC2NCHW: {
@@ -998,7 +1000,8 @@ extern "C" int bsy_conv_first_f32(const void* img, int img_dtype, int B, int H, 
 
 extern "C" int bsy_attention_f32(const float* qkv, int ld, int B, int N, int heads, int key_dim, int head_dim, float scale, float* out,
                                  int ldo, int impl, bsy_stream stream) {
-    if (!qkv || !out || B <= 0 || N <= 0 || impl < 0 || impl > 2) BSY_FAIL(BSY_ERR_ARG, "attention_f32: bad argument");
+    if (!qkv || !out || B <= 0 || N <= 0 || impl < 0 || impl > 3) BSY_FAIL(BSY_ERR_ARG, "attention_f32: bad argument");
+    if (impl == 3) return launch_attn32x(qkv, ld, B, N, heads, key_dim, head_dim, scale, out, ldo, (hipStream_t)stream);
     return launch_attn32(qkv, ld, B, N, heads, key_dim, head_dim, scale, out, ldo, (hipStream_t)stream, impl);
 }
 

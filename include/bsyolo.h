@@ -231,7 +231,9 @@ int bsy_conv_first_f32(const void* img, int img_dtype, int B, int H, int W, cons
 /* Attention (block.py:4279-4286) of the fp32 mode: qkv (B, N, ld) f32 rows [q (heads x key_dim) | k | v (heads x head_dim)] ->
  * out (B, N, ldo) f32, one thread per query, keys in order, online softmax.  impl 0: the LDS-tiled kernel for key_dim 32 /
  * head_dim 64 (every YOLO11 C2PSA), the generic one otherwise; 1: generic; 2: tiled (BSY_ERR_ARG where it does not apply).
- * Same operations in the same order: bit-identical. */
+ * Same operations in the same order: bit-identical.  impl 3: the fp32x mode's kernel (csrc/attention32x.hip: flash-style on the fp16
+ * matrix pipe, q / k / v / p split into f16 pairs, three MFMAs per product; key_dim 32 / head_dim 64 only) -- fp32-class accuracy
+ * (~1e-6 of the output range), not the bits of impl 0-2. */
 int bsy_attention_f32(const float* qkv, int ld, int B, int N, int heads, int key_dim, int head_dim, float scale, float* out,
                       int ldo, int impl, bsy_stream stream);
 /* Packed sizes for a (C2, C1, k, k) conv: rows padded to 128 output channels, K = k*k*C1 padded to 32.

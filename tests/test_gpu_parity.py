@@ -252,6 +252,27 @@ def test_attention32_tiled_equals_generic(N):
     assert float((got[2] - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("N", [100, 400, 1600, 37])
+def test_attention32x_matches_fp64_softmax_attention(N):
+    """fp32x mode's attention (attention32x.hip: flash-style on the fp16 matrix pipe, q / k / v / p as f16 pairs) against softmax
+    attention in torch fp64: 3e-6 of the output range (the exact kernels above hold 1e-5 against torch fp32), on ragged key counts
+    (100 = 3 tiles + 4 keys, 37) and with large logits (q scaled so that the softmax is peaky: the online rescale path runs)."""
+    g = torch.Generator().manual_seed(N)
+    B, heads, kd, hd = 2, 2, 32, 64
+    ld = heads * (2 * kd + hd)
+    qkv = torch.randn(B, N, ld, generator=g)
+    qkv[..., :heads * kd] *= 3.0
+    q = qkv[..., :heads * kd].view(B, N, heads, kd).permute(0, 2, 1, 3).double()
+    k = qkv[..., heads * kd:2 * heads * kd].view(B, N, heads, kd).permute(0, 2, 1, 3).double()
+    v = qkv[..., 2 * heads * kd:].view(B, N, heads, hd).permute(0, 2, 1, 3).double()
+    ref = (torch.softmax((q @ k.transpose(-1, -2)) * kd ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, heads * hd)
+    qd = qkv.to(DEV)
+    out = torch.zeros(B, N, heads * hd, device=DEV)
+    L.check(L.lib.bsy_attention_f32(O._p(qd), ld, B, N, heads, kd, hd, kd ** -0.5, O._p(out), heads * hd, 3, O._stream(qd)))
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err <= 3e-6 * max(float(ref.abs().max()), 1.0), err
+
+
 PATCH_CASES = [
     # B, H, W, cin, cout, cfg, res      cfg = tile << 4 | variant: 161 = patch kernel TN 128, 177 = TN 64
     (2, 24, 40, 64, 64, 177, False),      # 40-wide map: 2.5 tiles per row
