@@ -43,6 +43,18 @@ from .weights import BN_EPS
 SUPPORTED_HEADS = ("Detect", "Segment")
 
 
+def _on_device(t) -> bool:
+    """The hooks' dispatch test: the library runs tensors that live on a ROCm device; everything else goes to the reference's own
+    code.  One function so that the contract test (tests/test_host_logic.py, build container, no GPU) can let CPU tensors reach
+    RECORDING stand-ins for the engine / NMS / letterbox calls while the reference's predictor drives the hooks -- the product never
+    rebinds it, and the library itself has no CPU path (bs_yolo_amd.lib raises without the .so, YoloEngine without a GPU)."""
+    return bool(t.is_cuda)
+
+
+def _device_is_gpu(device) -> bool:
+    return str(device).startswith("cuda")
+
+
 def model_bn_eps(model) -> float:
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -153,7 +165,7 @@ def accelerate(model, device: Optional[int] = None, verbose: bool = False, fp32_
         embed = kwargs.get("embed", None)
         profile = kwargs.get("profile", False)
         if (self.training or augment or visualize or embed or profile or args or not isinstance(x, torch.Tensor)
-                or not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float16, torch.float32)
+                or not _on_device(x) or x.dim() != 4 or x.dtype not in (torch.float16, torch.float32)
                 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32 or x.shape[0] == 0):
             state["fallbacks"] += 1
             return orig_forward(x, *args, **kwargs)
@@ -548,7 +560,7 @@ def install_nms(ops_module):
         # labels (5), max_det, nc, max_time_img, max_nms, max_wh, in_place, rotated (12)
         rotated = kwargs.get("rotated", False) or (len(args) > 12 and args[12])
         labels = kwargs.get("labels", ()) or (args[5] if len(args) > 5 else ())
-        if (not isinstance(p, torch.Tensor)) or (not p.is_cuda) or rotated or len(labels) or p.shape[-1] == 6 \
+        if (not isinstance(p, torch.Tensor)) or (not _on_device(p)) or rotated or len(labels) or p.shape[-1] == 6 \
                 or p.dtype not in (torch.float16, torch.float32):
             return orig(prediction, *args, **kwargs)
         return _nms.non_max_suppression(prediction, *args, **kwargs)
@@ -607,7 +619,7 @@ def install_val_metrics(validator):
     orig = validator._process_batch
 
     def _process_batch(self, detections, gt_bboxes, gt_cls):
-        if not (isinstance(detections, torch.Tensor) and detections.is_cuda) or detections.shape[0] > 1024:
+        if not (isinstance(detections, torch.Tensor) and _on_device(detections)) or detections.shape[0] > 1024:
             return orig(detections, gt_bboxes, gt_cls)
         return _val.process_batch(detections, gt_bboxes, gt_cls, self.iouv)
 
@@ -644,7 +656,7 @@ def install_preprocess(predictor):
     orig = predictor.preprocess
 
     def preprocess(self, im):
-        if isinstance(im, torch.Tensor) or not str(self.device).startswith("cuda"):
+        if isinstance(im, torch.Tensor) or not _device_is_gpu(self.device):
             return orig(im)
         return _lb.preprocess(list(im), tuple(self.imgsz), half=bool(self.model.fp16), pt=bool(self.model.pt),
                               stride=int(self.model.stride), device=str(self.device))
