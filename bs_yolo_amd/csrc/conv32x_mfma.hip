@@ -450,10 +450,12 @@ __global__ __launch_bounds__(512, 2) void conv32x_big_kernel(const Conv32Args a,
 // nine taps (a tap = a shifted window of the patch: the B fragment of pixel (y, x) for tap (kh, kw) is patch row (y + kh) * 18 + x + kw);
 // only the weights -- TPS taps x TN couts x CK per step, both planes -- stream through a double-buffered stage.  K walks chunk-major:
 // (chunk, kh, kw, channel in chunk).  CK = 32 (Cin % 32 == 0) or 16; TN = 128 / 64 (wave grid 2 x 2) or 32 (4 x 1).
-template <int NT, bool THIN, int CK, int TPS>
+// TW = 16: 8 x 16 output tile; TW = 20: 6 x 20 (120 of the 128 MFMA pixel slots) for maps whose width is a multiple of 20 and not of 16
+// -- a 20 x 20 map is 4 such tiles (83 % of their area inside the map) instead of 6 tiles of 8 x 16 (52 %).
+template <int NT, bool THIN, int CK, int TPS, int TW>
 __global__ __launch_bounds__(256, 2) void conv32x_patch_kernel(const Conv32Args a, const int tiles_y, const int tiles_x, const int ntn) {
-    static_assert((CK == 16 || CK == 32) && (TPS == 1 || TPS == 3) && (!THIN || NT == 1), "configuration");
-    constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPP = PH * PW;  // 180 patch pixels
+    static_assert((CK == 16 || CK == 32) && (TPS == 1 || TPS == 3) && (!THIN || NT == 1) && (TW == 16 || TW == 20), "configuration");
+    constexpr int TH = TW == 16 ? 8 : 6, PH = TH + 2, PW = TW + 2, NPP = PH * PW;  // 180 / 176 patch pixels
     constexpr int TN = THIN ? 32 : 64 * NT, LDH = CK + 8, CPR = CK / 8, PB = THIN ? 1 : 2, KS = CK / 16;
     constexpr int PPT = (NPP * CPR + 255) / 256;          // patch pieces per thread
     constexpr int WPIECES = TPS * TN * CPR;               // weight pieces per plane per step
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv32x_patch_kernel(const Conv32Args 
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
         const int p = prow0 + b * 32 + lj;
-        prow[b] = (p / TW) * PW + p % TW;
+        prow[b] = p < TH * TW ? (p / TW) * PW + p % TW : 0;  // (6 x 20: slots 120..127 compute on pixel 0 and are not stored)
     }
 
     const int nsteps = nchunk * NSTEP;
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void conv32x_patch_kernel(const Conv32Args 
     for (int b = 0; b < PB; ++b) {
         const int p = prow0 + b * 32 + lj;
         const int oy = y0 + p / TW, ox = x0 + p % TW;
-        if (oy >= a.H || ox >= a.W) continue;
+        if (p >= TH * TW || oy >= a.H || ox >= a.W) continue;
         const size_t pix = (size_t)(img * a.H + oy) * a.W + ox;
 #pragma unroll
         for (int an = 0; an < NT; ++an)
@@ -632,11 +634,18 @@ __global__ __launch_bounds__(256, 2) void conv32x_patch_kernel(const Conv32Args 
 
 template <int NT, bool THIN, int TPS>
 int launch_patch(const Conv32Args& a, hipStream_t s) {
-    const int ty = ceil_div(a.H, 8), tx = ceil_div(a.W, 16), ntn = ceil_div(a.Cout, THIN ? 32 : 64 * NT);
+    const bool w20 = a.W % 20 == 0 && a.W % 16 != 0;
+    const int ty = ceil_div(a.H, w20 ? 6 : 8), tx = ceil_div(a.W, w20 ? 20 : 16), ntn = ceil_div(a.Cout, THIN ? 32 : 64 * NT);
     const long long nb = (long long)a.B * ty * tx * ntn;
     if (nb > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv32x_patch: grid out of range");
-    if (a.C0 % 32 == 0) hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 32, TPS>), dim3((unsigned)nb), dim3(256), 0, s, a, ty, tx, ntn);
-    else hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 16, TPS>), dim3((unsigned)nb), dim3(256), 0, s, a, ty, tx, ntn);
+    const dim3 grid((unsigned)nb), blk(256);
+    if (a.C0 % 32 == 0) {
+        if (w20) hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 32, TPS, 20>), grid, blk, 0, s, a, ty, tx, ntn);
+        else hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 32, TPS, 16>), grid, blk, 0, s, a, ty, tx, ntn);
+    } else {
+        if (w20) hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 16, TPS, 20>), grid, blk, 0, s, a, ty, tx, ntn);
+        else hipLaunchKernelGGL((conv32x_patch_kernel<NT, THIN, 16, TPS, 16>), grid, blk, 0, s, a, ty, tx, ntn);
+    }
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }
@@ -774,11 +783,11 @@ int launch_conv32x_mfma(const Conv32Args& a, hipStream_t s) {
     const char* eb = getenv("BSY_CONV32X_BK");
     const char* ep = getenv("BSY_CONV32X_PATCH");
     const int force = ef ? atoi(ef) : -1, bk = eb ? atoi(eb) : 32;
-    // 3 x 3 stride-1 layers with one source: the patch kernel, where the map is big enough for its 8 x 16 tiles to waste little (a
-    // 20 x 20 map fills 52 % of them: those layers stay on the implicit-GEMM tiles).  BSY_CONV32X_PATCH=0 / 1 forces it off / on.
+    // 3 x 3 stride-1 layers with one source: the patch kernel (faster than the implicit-GEMM tiles on every such layer of the YOLO
+    // graphs, 20 x 20 maps included: cv2.2.0 166 -> 105 us with 8 x 16 tiles at 52 % fill; 6 x 20 tiles since).  BSY_CONV32X_PATCH=0
+    // switches it off (tests / A-B).
     const bool patch_ok = a.ks == 3 && a.stride == 1 && a.pad == 1 && !a.C1 && !a.up0 && a.dst_scale == 1 && a.C0 % 16 == 0 && a.OH == a.H && a.OW == a.W;
-    const bool patch_fit = (long long)ceil_div(a.H, 8) * 8 * ceil_div(a.W, 16) * 16 * 10 <= (long long)a.H * a.W * 13;  // <= 30 % of the tile area outside the map
-    if (patch_ok && force < 0 && (ep ? atoi(ep) != 0 : patch_fit)) {
+    if (patch_ok && force < 0 && (ep ? atoi(ep) != 0 : true)) {
         if (a.Cout > 64) return launch_patch<2, false, 1>(a, s);
         if (a.Cout > 32) return launch_patch<1, false, 1>(a, s);
         return launch_patch<1, true, 3>(a, s);

@@ -156,6 +156,8 @@ CONV32X_CASES = CONV32_CASES + [
     (3, 40, 40, 64, 160, 3, 1, True, True, 0),       # patch kernel: 128-cout tiles, the second one ragged; 40 x 40 = 5 x 3 tiles, last column half outside
     (2, 37, 21, 48, 16, 3, 1, True, False, 8),       # patch kernel: 16-channel chunks (Cin = 48), thin tile, ragged map, padded row stride
     (2, 160, 160, 16, 32, 3, 1, True, True, 0),      # patch kernel: ONE 16-channel chunk (model.2.m.0.cv2 of YOLO11s)
+    (3, 20, 20, 128, 128, 3, 1, True, True, 0),      # patch kernel, 6 x 20 tiles (W % 20 == 0): 4 tile rows, the last with 2 of 6 rows inside
+    (2, 17, 40, 64, 48, 3, 1, True, False, 0),       # 6 x 20 tiles on a 40-wide map, ragged height, ragged couts
 ]
 
 
