@@ -66,6 +66,11 @@ struct ConvArgs {
     // the decoder fields above describe what the tail writes.  nullptr: no tail.
     const half_t* tail_wgt;
     const float* tail_bias;
+    // Split-K (latency mode): nsl_c channel slices x nsl_t tap slices of the layer's K walk, computed by separate workgroups of one launch
+    // into f32 slabs of split_ws (nsl_c * nsl_t * B * OH * OW * round_up(Cout, 32) floats) and summed in slice order by a second
+    // launch.  0 / 1 x 0 / 1: off.  Implicit-GEMM kernel only (conv_cfg_valid).
+    int nsl_c = 0, nsl_t = 0;
+    float* split_ws = nullptr;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 #define BSY_CONV_MAX_CFG 64

@@ -55,6 +55,13 @@ struct ConvK {
     const half_t* tail_wgt;  // box-branch tail (ConvArgs::tail_wgt): packed [128][64] 1x1 weights, f32 bias
     const float* tail_bias;
     unsigned span0, span1, wspan;  // bytes addressable from src0 / src1 / wgt (buffer-descriptor num_records)
+    // Split-K (latency mode, round 4; implicit-GEMM kernel, ALIGNED variants): the K walk is cut into nsl_c x nsl_t slices -- slice
+    // (sc, st) sums channels [sc * cb_per, (sc + 1) * cb_per) of taps [st * taps_per, (st + 1) * taps_per) in the layer's own order --
+    // each computed by its own workgroups of ONE launch into an f32 slab of split_ws ([slice][pixel][ldw] raw sums; the bias enters in
+    // slice 0); splitk_reduce_kernel adds the slabs in slice order and applies activation / shortcut.  nsl_c * nsl_t <= 1: off.
+    int nsl_c, nsl_t, cb_per, taps_per, ldw;
+    float* split_ws;
+    long long slab;   // floats per slice
     int dbg;  // ablation switches for profiling (BSY_CONV_DBG; results are WRONG under them): 1 = no DMA, 4 = no epilogue
     int korder;  // the layer's K walk (conv_korder below: a function of the layer's SHAPE, never of the configuration): 0 = the packed
                  // order (taps outer, channels inner), 1 = chunk-major with 32-channel chunks (32 channels of all ntaps taps, then
@@ -443,7 +450,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    // split-K: workgroups [slice * tiles, (slice + 1) * tiles) compute slice `slice` of every tile
+    const bool split = ALIGNED && p.nsl_c * p.nsl_t > 1;
+    int slice = 0;
+    if (split) {
+        const int per = p.ntn * ((p.M + TM - 1) / TM);
+        slice = wg / per;
+        wg -= slice * per;
+    }
+    const int tap0 = split ? (slice % p.nsl_t) * p.taps_per : 0, tap1 = split ? tap0 + p.taps_per : p.ntaps;
+    const int cb0 = split ? (slice / p.nsl_t) * p.cb_per : 0, cb1 = split ? cb0 + p.cb_per : p.Cin8 * 8;
     const int tn_idx = wg % p.ntn;
     const int tm_idx = wg / p.ntn;
     const int m0 = tm_idx * TM;
@@ -515,7 +532,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
                      rsw = make_rsrc(p.wgt, p.wspan);
 
     // K-step state.  ALIGNED: uniform (scalar) tap / channel base.  Generic: per-lane tap / 8-channel chunk index.
-    int s_tap = 0, s_cb = 0;
+    int s_tap = tap0, s_cb = cb0;
     int tap = ALIGNED ? 0 : kc0 / p.Cin8;
     int c8 = ALIGNED ? 0 : kc0 - tap * p.Cin8;
     const int Cin = p.Cin8 * 8;
@@ -570,13 +587,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     do {                                                                                                 \
         if (ALIGNED) {                                                                                   \
             if (p.korder == 1 || (p.korder == 2 && BK == 64)) { /* chunk-major, chunk = this kernel's BK */ \
-                if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += BK; }                                       \
+                if (++s_tap >= tap1) { s_tap = tap0; s_cb += BK; }                                       \
             } else if (p.korder == 2) { /* 64-channel chunks walked by a BK-32 kernel: (tap, half) */       \
-                if (s_cb & 32) { s_cb -= 32; if (++s_tap >= p.ntaps) { s_tap = 0; s_cb += 64; } }        \
+                if (s_cb & 32) { s_cb -= 32; if (++s_tap >= tap1) { s_tap = tap0; s_cb += 64; } }        \
                 else s_cb += 32;                                                                         \
             } else {                                                                                     \
                 s_cb += BK;                                                                              \
-                if (s_cb >= Cin) { s_cb = 0; ++s_tap; }                                                  \
+                if (s_cb >= cb1) { s_cb = cb0; ++s_tap; }                                                \
             }                                                                                            \
         } else {                                                                                         \
             c8 += 4;                                                                                     \
@@ -586,12 +603,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
 
     const int lrow = lane & 31;
     const int lh = lane >> 5;
-    const int nk = p.Kpad / BK;
-    f32x16 acc[NT][MT];  // start at the bias of their couts (common.h acc_bias)
+    const int nk = split ? (tap1 - tap0) * (cb1 - cb0) / BK : p.Kpad / BK;
+    f32x16 acc[NT][MT];  // start at the bias of their couts (common.h acc_bias); split-K: in slice 0 only
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < MT; ++b) acc_bias(acc[a][b], p.bias + n0 + (wn * NT + a) * 32, lh);
+        for (int b = 0; b < MT; ++b) {
+            acc_bias(acc[a][b], p.bias + n0 + (wn * NT + a) * 32, lh);
+            if (slice) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            }
+        }
 
     // prologue: STAGES-1 K-steps in flight
 #pragma unroll
@@ -647,6 +670,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(const
     }
     if (p.dbg & 4) {
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.dst)[0] = 1.f;  // keep the accumulators live
+        return;
+    }
+    if (split) {  // raw f32 sums of this slice -> its slab [pixel][ldw]; lane = pixel, registers 4 g .. 4 g + 3 = couts 8 g + 4 lh + {0..3}
+        float* ws = p.split_ws + (size_t)slice * (size_t)p.slab;
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int m = m0 + (wm * MT + b) * 32 + lrow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const int cbase = n0 + (wn * NT + a) * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = cbase + 8 * g + 4 * lh;
+                    if (c < p.ldw) *reinterpret_cast<f32x4*>(ws + (size_t)m * p.ldw + c) = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                }
+            }
+        }
         return;
     }
     if (p.epi) {  // fused Detect decoder
@@ -1604,15 +1645,57 @@ int launch_dwpw_fused(const DwPwArgs& a, hipStream_t s) {
     return BSY_OK;
 }
 
+// Split-K second step: out[pixel][c] = act(sum over slices, IN SLICE ORDER, of the raw f32 sums) (+ shortcut) -> f16 NHWC.  One thread
+// per (pixel, 8 couts); the order of the adds is fixed by the slice index, so the result does not depend on which workgroup finished
+// first, on the tile configuration or on the batch.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const int nsl, const long long slab, const int ldw,
+                                                           const int M, const int Cout, const int act, const half_t* __restrict__ res, const int ldr,
+                                                           half_t* __restrict__ dst, const int ldd) {
+    const int c8n = Cout >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * c8n) return;
+    const int c = (int)(idx % c8n) * 8;
+    const size_t m = (size_t)(idx / c8n);
+    const float* wp = ws + m * ldw + c;
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(wp), a1 = *reinterpret_cast<const f32x4*>(wp + 4);
+    for (int sl = 1; sl < nsl; ++sl) {
+        const float* q = wp + (size_t)sl * (size_t)slab;
+        a0 = add4_f(a0, *reinterpret_cast<const f32x4*>(q));
+        a1 = add4_f(a1, *reinterpret_cast<const f32x4*>(q + 4));
+    }
+    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    }
+    if (res) {
+        const half8 rv = *reinterpret_cast<const half8*>(res + m * ldr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+    *reinterpret_cast<half8*>(dst + m * ldd + c) = o;
+}
+
 template <int KS, int WM, int WN, int MT, int NT, int STAGES, bool ALIGNED, int BK>
 static int launch_cfg(const ConvK& k, hipStream_t s) {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
     ConvK p = k;
     p.ntn = ceil_div(k.Cout, TN);
-    const long long nblk = (long long)ceil_div(k.M, TM) * p.ntn;
+    const int nsl = k.nsl_c * k.nsl_t;
+    if (nsl > 1 && (!ALIGNED || (k.cb_per % BK))) BSY_FAIL(BSY_ERR_ARG, "conv: split-K needs an aligned configuration whose K-step divides the channel slices");
+    const long long nblk = (long long)ceil_div(k.M, TM) * p.ntn * (nsl > 1 ? nsl : 1);
     if (nblk <= 0 || nblk > 0x7fffffffLL) BSY_FAIL(BSY_ERR_ARG, "conv: grid %lld out of range", nblk);
     hipLaunchKernelGGL((conv_mfma_kernel<KS, WM, WN, MT, NT, STAGES, ALIGNED, BK>), dim3((unsigned)nblk), dim3(64 * WM * WN), 0, s, p);
     HIP_TRY(hipGetLastError());
+    if (nsl > 1) {
+        const long long items = (long long)k.M * (k.Cout >> 3);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, k.split_ws, nsl, k.slab, k.ldw, k.M, k.Cout, k.act,
+                           k.res, k.ldr, reinterpret_cast<half_t*>(k.dst), k.ldd);
+        HIP_TRY(hipGetLastError());
+    }
     return BSY_OK;
 }
 
@@ -1665,6 +1748,10 @@ bool conv_cfg_valid(const ConvArgs& a, int cfg) {
         return a.epi == 3 && a.Cout == 64 && !a.res && conv_cfg_valid(b, cfg);
     }
     if (a.epi && tile >= 8) return false;           // fused decoder: implicit-GEMM kernel only
+    if (a.nsl_c * a.nsl_t > 1) {                    // split-K: implicit-GEMM tiles, aligned variants, K-step dividing the channel slices
+        const int cbp = Cin / (a.nsl_c > 0 ? a.nsl_c : 1);
+        if (tile >= 8 || var < 1 || (var == 3 && (cbp & 63)) || (cbp & 31)) return false;
+    }
     if (tile >= 14) {  // weights-resident streaming 1x1 kernel (14: 128-cout tiles, 15: 64-cout tiles; variant 1: 4-stage pixel ring, 2: 3 stages)
         const int K = Cin, nt = tile == 14 ? 2 : 1, stages = var == 1 ? 4 : 3;
         return a.ksize == 1 && a.stride == 1 && (var == 1 || var == 2) && !(Cin & 31) && !(a.C0 & 31) && !a.out_f32 && !a.res && !(a.Cout & 7) &&
@@ -1782,6 +1869,17 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     k.tail_wgt = a.tail_wgt; k.tail_bias = a.tail_bias;
     if (a.tail_wgt && !a.epi) BSY_FAIL(BSY_ERR_ARG, "conv: a box-branch tail needs the decoder arguments (epi 3)");
     k.dst_scale = a.dst_scale > 0 ? a.dst_scale : 1; k.dst_dy = a.dst_dy; k.dst_dx = a.dst_dx; k.ntn = 1;
+    k.nsl_c = k.nsl_t = 1; k.cb_per = Cin; k.taps_per = a.ksize * a.ksize; k.split_ws = nullptr; k.slab = 0; k.ldw = 0;
+    if (a.nsl_c * a.nsl_t > 1) {
+        const int nt = a.ksize * a.ksize;
+        if (a.nsl_c < 1 || a.nsl_t < 1 || !a.split_ws || a.epi || a.out_f32 || a.tail_wgt || (a.dst_scale > 1) || (Cin % a.nsl_c) || ((Cin / a.nsl_c) & 31) || (a.C0 & 31) ||
+            (nt % a.nsl_t) || (a.Cout & 7) || (a.ldd & 7) || ((uintptr_t)a.dst & 15) || (a.res && ((a.ldr & 7) || ((uintptr_t)a.res & 15))) || ((uintptr_t)a.split_ws & 15))
+            BSY_FAIL(BSY_ERR_ARG, "conv: bad split-K arguments (%d x %d slices)", a.nsl_c, a.nsl_t);
+        if (conv_korder(a) == 2 && ((Cin / a.nsl_c) & 63)) BSY_FAIL(BSY_ERR_ARG, "conv: split-K slices of a 64-channel-chunk layer must be multiples of 64 channels");
+        k.nsl_c = a.nsl_c; k.nsl_t = a.nsl_t; k.cb_per = Cin / a.nsl_c; k.taps_per = nt / a.nsl_t; k.split_ws = a.split_ws;
+        k.ldw = round_up(a.Cout, 32);               // whole 32-cout MFMA tiles: the slab rows take every accumulator group unconditionally
+        k.slab = (long long)M * k.ldw;
+    }
     // ---- configuration: explicit (autotuned, ConvArgs::cfg) or heuristic -----------------------------------------
     if (a.ksize == 3 && (a.up0 || a.up1)) BSY_FAIL(BSY_ERR_ARG, "conv: upsampled source only with ksize 1");
     // element offsets are kept in 32 bits inside the kernel

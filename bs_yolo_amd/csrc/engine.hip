@@ -55,6 +55,8 @@ struct bsy_plan {
     }
 };
 
+extern "C" int bsy_sizeof_op(void) { return (int)sizeof(bsy_op); }  // the host mirrors the record with ctypes: checked at load
+
 extern "C" int bsy_engine_create(int device, bsy_engine** out) {
     if (!out) BSY_FAIL(BSY_ERR_ARG, "engine_create: null out");
     int ndev = 0;
@@ -543,6 +545,10 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
                     a.Cout = op.mid_c;
                     a.tail_wgt = (const half_t*)(wb + op.w2_off); a.tail_bias = (const float*)(wb + op.b2_off);
                 }
+            }
+            if (op.ksplit > 0 && op.out_f32 == 0) {  // split-K (latency-mode plans): ksplit = channel slices | tap slices << 8, box[0] = the f32 slab buffer
+                a.nsl_c = op.ksplit & 255; a.nsl_t = (op.ksplit >> 8) & 255;
+                a.split_ws = R.f(op.box[0]);
             }
             a.cfg = op.tuned_cfg - 1;  // 0 = not tuned -> heuristic
             if (!R.ok) return BSY_ERR_ARG;

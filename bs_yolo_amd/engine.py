@@ -26,7 +26,8 @@ class YoloEngine:
                  autotune: Optional[bool] = None, fuse_stem: Optional[bool] = None,
                  fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None, fuse_dwpw: Optional[bool] = None,
                  merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None, fuse_tail: Optional[bool] = None,
-                 max_plans: Optional[int] = None, precision: str = "fp16", graph: Optional[bool] = None, graph_ring: int = 3):
+                 max_plans: Optional[int] = None, precision: str = "fp16", graph: Optional[bool] = None, graph_ring: int = 3,
+                 latency: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
@@ -35,6 +36,10 @@ class YoloEngine:
         # and non-conv kernels, dense convs on the fp16 matrix pipe with split-f16 operands (csrc/conv32x_mfma.hip): the
         # north-star's 1e-3 at several times the fp32 mode's throughput.  "fp16" is the product path.
         self.precision = precision
+        # latency mode (BSY_LATENCY=1): split-K on the long-K, few-tile conv layers -- for small per-rank batches (a rank's 8- or
+        # 16-image share of a strong-scaled batch).  The split factors depend on the layer shape only, so any batch split returns the
+        # bits of the whole batch IN THIS MODE; they differ from the default mode's by f32 summation order (Plan.split_factors).
+        self.latency = (os.environ.get("BSY_LATENCY", "0") == "1") if latency is None else bool(latency)
         self.device = torch.device("cuda", device)
         self._h = C.c_void_p()
         L.check(L.lib.bsy_engine_create(device, C.byref(self._h)))
@@ -122,7 +127,7 @@ class YoloEngine:
     def _fuse_kw(self):
         return dict(fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head, fuse_dwpw=self.fuse_dwpw,
                     merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail, precision=self.precision,
-                    lanes=True if getattr(self, "graph", False) else None)
+                    lanes=True if getattr(self, "graph", False) else None, latency=getattr(self, "latency", False))
 
     # -- plans --------------------------------------------------------------------------------------------------
     def plan_for(self, B: int, H: int, W: int, in_dtype: torch.dtype, out_dtype: torch.dtype):

@@ -24,7 +24,7 @@ SYMBOLS = [
     "bsy_plan_run", "bsy_plan_graph_launch", "bsy_plan_profile", "bsy_plan_copy_buffer", "bsy_plan_check_guards", "bsy_plan_autotune", "bsy_plan_get_tuning", "bsy_plan_get_tuning_alt", "bsy_plan_check_tuning", "bsy_plan_autotune_in_place", "bsy_conv2d", "bsy_conv2d_f32", "bsy_conv2d_f32x", "bsy_conv_first_f32", "bsy_attention_f32", "bsy_conv_packed_dims", "bsy_conv_first", "bsy_stem_fused", "bsy_stem_fused_supported", "bsy_bottleneck_fused", "bsy_bottleneck_fused_supported", "bsy_c3k2_fused", "bsy_c3k2_fused_supported", "bsy_dwconv", "bsy_dwpw_fused", "bsy_dwpw_fused_supported", "bsy_ela", "bsy_ela_scratch_bytes", "bsy_dwconv3x3",
     "bsy_sppf_pool", "bsy_attention", "bsy_detect_decode", "bsy_nms_workspace_bytes", "bsy_nms", "bsy_scale_boxes",
     "bsy_letterbox", "bsy_process_mask", "bsy_process_mask_native", "bsy_scale_masks", "bsy_val_match", "bsy_slice_tiles", "bsy_sahi_merge_workspace_bytes",
-    "bsy_sahi_merge", "bsy_ap_workspace_bytes", "bsy_ap_per_class", "bsy_last_error", "bsy_version",
+    "bsy_sahi_merge", "bsy_ap_workspace_bytes", "bsy_ap_per_class", "bsy_last_error", "bsy_version", "bsy_sizeof_op",
 ]
 
 
@@ -59,7 +59,7 @@ class Op(C.Structure):
         ("mid_c", C.c_int32),
         ("w2_off", C.c_int64), ("b2_off", C.c_int64),
         ("aux_off", C.c_int64 * 18),
-        ("prec", C.c_int32), ("reserved0", C.c_int32),
+        ("prec", C.c_int32), ("reserved0", C.c_int32), ("ksplit", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -76,6 +76,8 @@ def _load() -> C.CDLL:
     missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:
         raise ImportError(f"{LIB_PATH} does not export {missing}; rebuild it")
+    if lib.bsy_sizeof_op() != C.sizeof(Op):
+        raise ImportError(f"{LIB_PATH}: bsy_op is {lib.bsy_sizeof_op()} bytes in the library, {C.sizeof(Op)} in bs_yolo_amd/lib.py; rebuild it")
     vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     lib.bsy_last_error.restype = C.c_char_p
     lib.bsy_engine_create.argtypes = [i32, C.POINTER(vp)]

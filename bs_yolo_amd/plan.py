@@ -105,8 +105,10 @@ class Plan:
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
                  fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None,
-                 fuse_tail: Optional[bool] = None, precision: str = "fp16", lanes: Optional[bool] = None):
+                 fuse_tail: Optional[bool] = None, precision: str = "fp16", lanes: Optional[bool] = None, latency: bool = False):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
+        # latency mode (round 4; fp16 path): long-K conv layers with few tiles per image run split-K (split_factors below)
+        self.latency = bool(latency) and precision == "fp16"
         if precision not in ("fp16", "fp32", "fp32x"):
             raise ValueError(f"precision must be 'fp16', 'fp32' or 'fp32x', not {precision!r}")
         # fp32: the correctness mode (csrc/ref32.hip) -- every buffer f32, no fused kernels, same op list otherwise.
@@ -132,6 +134,8 @@ class Plan:
         self.meta: Dict = {}
         self._lane = 0
         self._build()
+        if self.latency:
+            self._apply_split_k()
         # Side lanes (the Detect branches on their own streams) pay a fork / join event pair each: worth it when the branch kernels
         # are long enough to overlap -- from about 12 images of 640 x 640 (measured: 0.74 vs 0.79 ms at 1 image, 0.94 vs 0.96 at 8,
         # 1.25 vs 1.24 at 16, 1.92 vs 1.87 at 32, 3.3 vs 3.2 at 64).  BSY_LANES=0 / 1 forces one or the other (0: the tests' serial
@@ -143,6 +147,46 @@ class Plan:
                 if "lane" in o:
                     o["lane"] = 0
         assert all(o.get("lane", 0) == 0 or o["kind"] in (L.OP_CONV, L.OP_DWCONV, L.OP_BNECK, L.OP_DWCONV_G, L.OP_DWPW, L.OP_C3K2) for o in self.ops)
+
+    # ---- split-K (latency mode) ------------------------------------------------------------------------------------
+    @staticmethod
+    def split_factors(k: int, stride: int, cin: int, c0: int, cout: int, OH: int, OW: int) -> Tuple[int, int]:
+        """(channel slices, tap slices) of a dense conv's K walk in latency mode -- a function of the LAYER'S SHAPE ONLY, never of
+        the batch: a rank's share of a strong-scaled batch (8 images of 64) and the whole batch cut their K walks at the same places
+        and add the partial sums in the same order, so shards of a batch return the bits of the whole.
+        Rule (measured, 8 images of 640 x 640, r04: a split costs a second launch and an f32 round trip of the output, ~6 us, so it
+        only pays on layers that are long AND thin): at least 32 K-steps of 64, fewer than 11 tiles of 128 x 128 per image, at least
+        three slices; 3 x 3 layers are cut by kernel row first, then by 64-channel groups; at most 8 slices, each at least four
+        64-deep K-steps.  On YOLO11s that is Detect's cv2.2.0 (3 x 3, 512 -> 64 at 20 x 20: 26.7 -> 16.6 us) and model.20 (19.8 ->
+        15.3 us); splitting the 6-10-us 1 x 1 layers of the 20 x 20 stage made each of them 4-8 us SLOWER."""
+        if cin % 64 or c0 % 64 or cout % 8:
+            return 1, 1
+        steps = k * k * cin // 64
+        tiles = -(-OH * OW // 128) * -(-cout // 128)
+        want = min(32 // max(tiles, 1), 8, steps // 4)
+        if steps < 32 or want < 3:
+            return 1, 1
+        nt = 3 if k == 3 else 1
+        n64 = cin // 64
+        nc = max((d for d in range(1, n64 + 1) if n64 % d == 0 and d * nt <= want), default=1)
+        return (nc, nt) if nc * nt >= 3 else (1, 1)
+
+    def _apply_split_k(self) -> None:
+        for o in self.ops:
+            if o["kind"] != L.OP_CONV or o.get("out_f32", 0) or o.get("dst_scale", 1) != 1 or o["ksize"] not in (1, 3):
+                continue
+            s0, s1 = o["src0"], o.get("src1")
+            cin = s0.C + (s1.C if s1 else 0)
+            cout = o.get("cout", o["dst"].C)
+            if o["dst"].ld % 8 or (o.get("res") is not None and o["res"].ld % 8):
+                continue
+            nc, nt = self.split_factors(o["ksize"], o["stride"], cin, s0.C if s1 else cin, cout, o["OH"], o["OW"])
+            if nc * nt < 2:
+                continue
+            ldw = (cout + 31) // 32 * 32
+            self.buf_bytes.append(nc * nt * self.B * o["OH"] * o["OW"] * ldw * 4)
+            o["box"] = [T(len(self.buf_bytes) - 1, ldw, 0, ldw, o["OH"], o["OW"], False, True)]
+            o["ksplit"] = nc | (nt << 8)
 
     # ---- buffers -------------------------------------------------------------------------------------------
     def alloc(self, C: int, H: int, W: int, f32: bool = False) -> T:
@@ -834,7 +878,7 @@ class Plan:
         s0, s1, d, r = o["src0"], o.get("src1"), o["dst"], o.get("res")
         return (self.B, o["H"], o["W"], s0.C, s0.ld, int(s0.up), s1.C if s1 else 0, s1.ld if s1 else 0, int(s1.up) if s1 else 0,
                 o.get("cout", d.C), d.ld, o["ksize"], o["stride"], int(r is not None), r.ld if r is not None else 0,
-                o.get("out_f32", 0), o.get("dst_scale", 1), o.get("act", 0))
+                o.get("out_f32", 0), o.get("dst_scale", 1), o.get("act", 0), o.get("ksplit", 0))
 
     # ---- serialisation ------------------------------------------------------------------------------------------
     def c_ops(self):
@@ -880,4 +924,5 @@ class Plan:
             o.in_dtype, o.out_dtype, o.level = d.get("in_dtype", 0), d.get("out_dtype", 0), d.get("level", 0)
             o.lane, o.join, o.tuned_cfg = d.get("lane", 0), d.get("join", 0), 0
             o.prec = (2 if self.split_f16 else 1) if self.f32_mode else 0
+            o.ksplit = d.get("ksplit", 0)
         return arr

@@ -135,8 +135,15 @@ typedef struct bsy_op {
                              * operand error instead of the exact fp32 chain); their weight record is the mode-1 f32 matrix followed
                              * by two f16 planes [Cout][K rounded up to 32] (hi, lo), each part padded to 256 bytes */
     int32_t reserved0;
+    int32_t ksplit;         /* CONV, latency-mode plans (round 4): 0 = off; else (channel slices) | (tap slices) << 8 of the layer's K walk.  The
+                             * slices are computed by separate workgroups of one launch into f32 slabs in the workspace buffer box[0]
+                             * (slices x B x OH x OW x round_up(Cout, 32) floats) and summed IN SLICE ORDER by a second launch that applies
+                             * activation and shortcut: deterministic, independent of the batch and of the tile configuration.  The host
+                             * chooses the factors from the layer's SHAPE only (bs_yolo_amd/plan.py split_factors), never from the batch. */
+    int32_t reserved1;
 } bsy_op;
 
+int bsy_sizeof_op(void); /* sizeof(bsy_op) of the library: a host binding that mirrors the record (bs_yolo_amd/lib.py) checks it at load */
 int bsy_engine_create(int device, bsy_engine** out);
 void bsy_engine_destroy(bsy_engine* e);
 /* HOST blob: packed weights produced by bs_yolo_amd/weights.py (BN already folded: replaces

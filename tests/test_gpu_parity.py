@@ -1001,6 +1001,44 @@ def test_engine_graph_mode_equals_eager(fam, scale, nc, task, shape, own_stream)
     graph.close()
 
 
+@pytest.mark.parametrize("scale,shape", [("s", (8, 640, 640)), ("n", (6, 320, 224))])
+def test_engine_latency_mode_split_k(scale, shape):
+    """Latency mode (round 4): long-K conv layers with few tiles per image run split-K -- the slices of a layer's K
+    walk are computed by separate workgroups of one launch and added in slice order.  The split factors are a function of the layer
+    shape only (Plan.split_factors), so (a) a batch cut into shards returns the bits of the whole batch, (b) a tuned engine returns
+    the bits of the untuned one (every tile configuration walks the slices alike), (c) the result stays within f32 summation-order
+    distance of the default mode and inside the fp16 path's bounds against the oracle.  (Which layers are split: Plan.split_factors --
+    only long, thin ones; splitting everything that has few tiles was measured SLOWER.)"""
+    m = R.Model("yolo11", scale, 80, "detect")
+    P = R.synth_params(m, 9)
+    cfg = stock_cfg("yolo11", scale)
+    B, H, W = shape
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(B * H)).half().to(DEV)
+    lat = YoloEngine(cfg, P, autotune=False, latency=True)
+    plan, _ = lat.plan_for(B, H, W, torch.float16, torch.float16)
+    nsplit = sum(1 for o in plan.ops if o.get("ksplit"))
+    assert nsplit >= 1, nsplit
+    y, raws = lat(x)
+    ys = [lat(x[i:i + B // 2]) for i in (0, B // 2)]                # two shards: other plans of the same engine
+    tuned = YoloEngine(cfg, P, autotune=True, latency=True)
+    yt, rt = tuned(x)
+    base = YoloEngine(cfg, P, autotune=False)
+    yb, rb = base(x)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([ys[0][0], ys[1][0]]), y)
+    for l in range(3):
+        assert torch.equal(torch.cat([ys[0][1][l], ys[1][1][l]]), raws[l]) and torch.equal(rt[l], raws[l])
+    assert torch.equal(yt, y) and tuned.tune_stats["timed_ops"] > 0
+    d = (y.float() - yb.float()).abs()  # another f32 summation order + fp16 storage downstream: the fp16 path's own class of distance
+    assert float(d[:, 4:].max()) < 2e-2 and float(d[:, :4].max()) < 4.0 and float(d[:, 4:].mean()) < 1e-4, (float(d[:, 4:].max()), float(d[:, :4].max()))
+    with torch.inference_mode():
+        yref, _ = m.forward(P, x.float().cpu())
+    e = (y.float().cpu() - yref).abs()
+    assert float(e[:, 4:].max()) < 1e-2 and float(e[:, :4].max()) < 2.0, (float(e[:, 4:].max()), float(e[:, :4].max()))
+    for eng in (lat, tuned, base):
+        eng.close()
+
+
 def test_engine_graph_mode_follows_a_weight_reload():
     """captured graphs hold addresses inside the weight blob.  Reloading weights on an engine that has captured graphs
     (bsy_engine_load_weights frees and reallocates the blob) must drop them: the next graph launch re-captures and returns the bits
