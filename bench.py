@@ -214,7 +214,9 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     main = torch.cuda.current_stream(dev)
-    post = main if args.serial_nms else torch.cuda.Stream(device=dev)
+    # graph mode returns outputs from a ring of preallocated tensors that a later replay overwrites: a consumer on another stream
+    # could still be reading them -- NMS stays on the forward's stream there
+    post = main if (args.serial_nms or use_graph) else torch.cuda.Stream(device=dev)
 
     def step():
         nonlocal pending, gathered

@@ -349,6 +349,15 @@ class YoloEngine:
             else:
                 L.check(L.lib.bsy_plan_graph_launch(h, ext, n, C.c_void_p(stream), C.byref(how)))
             self.graph_stats[{1: "captures", 0: "replays"}.get(how.value, "eager")] += 1
+            if how.value == 1 and self.graph_stats["captures"] > 4 * self.graph_ring + 4 and not getattr(self, "_graph_warned", False):
+                # the graph key holds the INPUT pointer: callers that hand over a freshly allocated image tensor per call re-capture
+                # (and re-instantiate) on almost every forward -- slower than the eager replay; say so once
+                self._graph_warned = True
+                import logging
+                logging.getLogger("bs_yolo_amd").warning(
+                    "graph mode has captured %d graphs (%d replays): inputs arrive at new addresses on every call, so every forward is "
+                    "re-captured.  Reuse the input tensor (copy_ into one buffer per shape) or switch graph mode off.",
+                    self.graph_stats["captures"], self.graph_stats["replays"])
         else:
             L.check(L.lib.bsy_plan_run(h, ext, n, C.c_void_p(stream)))
         if self._last_done is None:

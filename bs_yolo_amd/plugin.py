@@ -475,7 +475,10 @@ def _block_forward(m, kind):
         def fwd(self, x):
             xs = list(x) if isinstance(x, (list, tuple)) else None
             nm = 0
-            if (xs is None or len(xs) != self.nl or self.training or getattr(self, "export", False)
+            # export / format / end2end variants compute something else (head.py:66-67, 109-127: dist2bbox(xywh=not end2end), format-
+            # specific rescaling), checked at CALL time: exporters flip these attributes on live modules
+            if (xs is None or len(xs) != self.nl or self.training or getattr(self, "export", False) or getattr(self, "end2end", False)
+                    or getattr(self, "format", None) is not None
                     or not all(torch.is_tensor(t) and t.is_cuda and t.dtype in (torch.float16, torch.float32) and t.dim() == 4
                                and t.shape[1] == self.no and t.shape[0] == xs[0].shape[0] for t in xs)):
                 st["fallbacks"] += 1
@@ -495,6 +498,10 @@ def _block_forward(m, kind):
             with torch.cuda.device(dev):
                 _L.check(_L.lib.bsy_detect_decode(box, ldv, cls, ldv, None, None, hh, ww, sv, nl, B, nc, nm, _p(y), _L.dtype_code(dt), _stream(y)))
             st["calls"] += 1
+            # the reference's _inference caches anchors / strides per input shape as a side effect (head.py:105-107) and code outside
+            # the path may read them (exporters, Detect.decode_bboxes callers): keep `shape` as the reference does and drop the cached
+            # grids, so that the reference's own _inference -- on a fallback call -- rebuilds them for ITS shape instead of reusing ours
+            self.shape = None
             return y
     return fwd, st
 
