@@ -63,6 +63,50 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, H8& hi, H
 
 __device__ __forceinline__ float silu_x(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 
+// Epilogue of one 32-pixel block of a wave's accumulator tiles (lane = pixel, registers = couts) through a WAVE-PRIVATE LDS tile
+// [32 pixels][NT * 32 + 4] floats: each lane parks its pixel's activated couts, then the wave reads the tile back row-wise, so that a
+// store instruction writes whole rows (NT * 128 contiguous bytes per pixel, 64 / (NT * 8) pixels per instruction) instead of 32 pieces
+// of 32 bytes, and the shortcut is read the same way.  The fp32 modes' 160 x 160 / 80 x 80 layers are HBM-bound (fp32 storage): the
+// direct form ran them at ~75 % of a streaming copy.  (Round 4, measured: it pays on the image conv only, 406 -> 313 us -- a pixel's 32 couts
+// are ONE 128-byte row there; on the other kernels the direct 32-byte pieces were already merged in L2 and the extra LDS round trip
+// cost 0-8 %: they keep the direct form.)  No workgroup barrier: the tile belongs to one wave, whose LDS operations
+// complete in issue order.  rowfn(r, pix, dp): source-geometry pixel index (shortcut) and destination pixel index of row r, false
+// if the row lies outside the output.  Same arithmetic per element as the direct form (activation, then + shortcut).
+template <int NT, int PB, typename RowFn>
+__device__ __forceinline__ void epilogue_block(f32x16 (&acc)[NT][PB], const int b, float* wl, const int lane, const int cw0, const Conv32Args& a, RowFn rowfn) {
+    constexpr int RS = NT * 32 + 4, PPR = NT * 8;
+    const int lj = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int an = 0; an < NT; ++an)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = acc[an][b][4 * q + e];
+                v[e] = a.act ? silu_x(t) : t;
+            }
+            *reinterpret_cast<f32x4*>(wl + lj * RS + an * 32 + 8 * q + 4 * lh) = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < NT * 4; ++j) {
+        const int id = lane + 64 * j, r = id / PPR, c4 = (id % PPR) * 4, c = cw0 + c4;
+        size_t pix = 0, dp = 0;
+        if (rowfn(r, pix, dp) && c < a.Cout) {  // Cout % 4 == 0: a piece is inside or outside as a whole
+            f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * RS + c4);
+            if (a.res) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + pix * a.ldr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            }
+            *reinterpret_cast<f32x4*>(a.dst + dp * a.ldd + c) = v;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are in registers before the next block overwrites the tile
+}
+#define CX_EPI_BYTES(NT_, WAVES_) ((WAVES_) * 32 * ((NT_) * 32 + 4) * 4)
+
 template <int NT, bool THIN = false>
 __global__ __launch_bounds__(256, 2) void conv32x_mfma_kernel(const Conv32Args a, const int M, const int ntn) {
     static_assert(!THIN || NT == 1, "thin tile: one 32-cout accumulator tile per wave");
@@ -659,8 +703,14 @@ int launch_patch(const Conv32Args& a, hipStream_t s) {
 template <int NT, typename TI>
 __global__ __launch_bounds__(256) void conv32x_first_kernel(const Conv32Args a, const int M) {
     constexpr int TM = 128, LDH = 40;
-    __shared__ __attribute__((aligned(16))) half_t sP[2][TM * LDH];
-    __shared__ __attribute__((aligned(16))) half_t sW[2][NT * 32 * LDH];
+    struct Stages {
+        half_t sP[2][TM * LDH];
+        half_t sW[2][NT * 32 * LDH];
+    };
+    constexpr int EPI = CX_EPI_BYTES(1, 4), SMEM = (int)sizeof(Stages) > EPI ? (int)sizeof(Stages) : EPI;  // epilogue: one 32-cout tile at a time
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM];
+    auto& sP = reinterpret_cast<Stages*>(smem_raw)->sP;
+    auto& sW = reinterpret_cast<Stages*>(smem_raw)->sW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 31, lh = lane >> 5;
@@ -727,22 +777,20 @@ __global__ __launch_bounds__(256) void conv32x_first_kernel(const Conv32Args a, 
             acc[an] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[an], 0, 0, 0);
         }
     }
-    const int m = m0 + wave * 32 + lj;
-    if (m >= M) return;
+    __syncthreads();  // every wave has read its fragments: the stages become the waves' output tiles
+    // one 32-cout tile at a time through the wave's LDS tile [32 pixels][36]: a pixel's Cout floats are contiguous in the output, so a
+    // store instruction then writes 8 pixels x 128 bytes instead of 32 pieces of 32 bytes
+    float* wl = reinterpret_cast<float*>(smem_raw) + wave * 32 * 36;
+    const int mb = m0 + wave * 32;
 #pragma unroll
-    for (int an = 0; an < NT; ++an)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = an * 32 + 8 * q + 4 * lh;
-            if (c >= a.Cout) continue;
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = acc[an][4 * q + e];
-                v[e] = a.act ? silu_x(t) : t;
-            }
-            *reinterpret_cast<f32x4*>(a.dst + (size_t)m * a.ldd + c) = v;
-        }
+    for (int an = 0; an < NT; ++an) {
+        f32x16 one[1][1] = {{acc[an]}};
+        epilogue_block<1, 1>(one, 0, wl, lane, an * 32, a, [&](int r, size_t& pix, size_t& dp) {
+            if (mb + r >= M) return false;
+            pix = dp = (size_t)(mb + r);
+            return true;
+        });
+    }
 }
 
 template <typename TI>
