@@ -2112,6 +2112,10 @@ def test_engine_extreme_shapes_match_fp32_mode(shape):
     e32 = YoloEngine(cfg, P, precision="fp32")
     y32 = e32(x.to(DEV))[0].cpu()
     e32.close()
+    ex = YoloEngine(cfg, P, precision="fp32x")   # round 4: the split-f16 mode on the same shapes -- its patch / big-tile / 6 x 20-tile kernels
+    yx = ex(x.to(DEV))[0].cpu()                  # on one-pixel-high maps, 200 x 200 levels and 130 images -- against the exact mode
+    ex.close()
+    assert float((yx[:, 4:] - y32[:, 4:]).abs().max()) <= 2e-4 and float((yx[:, :4] - y32[:, :4]).abs().max()) <= 2e-4 * max(H, W)
     e16 = YoloEngine(cfg, P)
     y16 = e16(x.half().to(DEV))[0].float().cpu()
     e16.close()
@@ -2177,10 +2181,11 @@ def test_engine_on_custom_width_multiples(fam, width):
         x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(11))
         with torch.inference_mode():
             yref, _ = m.forward(P, x)
-        e32 = YoloEngine(cfg, P, precision="fp32")
-        y32, _ = e32(x.to(DEV))
-        assert float((y32.cpu()[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3 and float((y32.cpu()[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 128
-        e32.close()
+        for prec in ("fp32", "fp32x"):  # fp32x: channel counts its kernels do not take (Cin % 8, Cout % 4) run on the exact ones
+            e32 = YoloEngine(cfg, P, precision=prec)
+            y32, _ = e32(x.to(DEV))
+            assert float((y32.cpu()[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3 and float((y32.cpu()[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 128, prec
+            e32.close()
         e16 = YoloEngine(cfg, P)
         y16, _ = e16(x.half().to(DEV))
         d = (y16.float().cpu() - yref).abs()
