@@ -1152,6 +1152,40 @@ def test_engine_no_out_of_bounds_stores(fam, scale, nc, task, shapes, monkeypatc
         eng.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32x", "fp32"])
+def test_fp32_storage_modes_store_inside_their_buffers_and_read_inside_the_weights(precision, monkeypatch):
+    """The two tests above for the fp32-storage modes (round 4: the fp32x kernels -- implicit GEMM, 256-pixel tiles, patch kernel
+    with 8 x 16 and 6 x 20 tiles, image conv, attention -- and the LDS pool / windowed depthwise kernels both modes share): guard bands
+    behind every workspace buffer stay intact on whole, ragged and tiny maps, latency-mode split-K slabs included for the fp16 path,
+    and a weight blob followed by poison returns the plain engine's bits."""
+    cfg = stock_cfg("yolo11", "s")
+    m = R.Model("yolo11", "s", 80, "detect")
+    P = R.synth_params(m, 2)
+    shapes = [(2, 160, 32), (3, 96, 224), (1, 640, 416), (5, 64, 64)]
+    monkeypatch.setenv("BSY_PLAN_GUARD", "4096")
+    eng = YoloEngine(cfg, P, precision=precision)
+    for B, H, W in shapes:
+        eng(torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).to(DEV))
+    assert eng.check_guards() == []
+    eng.close()
+    lat = YoloEngine(cfg, P, autotune=False, latency=True)
+    for B, H, W in shapes:
+        lat(torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV))
+    assert lat.check_guards() == []
+    lat.close()
+    monkeypatch.delenv("BSY_PLAN_GUARD")
+    plain = YoloEngine(cfg, P, precision=precision)
+    monkeypatch.setenv("BSY_WEIGHT_GUARD", str(1 << 20))
+    poisoned = YoloEngine(cfg, P, precision=precision)
+    for B, H, W in shapes:
+        x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H * W)).to(DEV)
+        y0, a0 = plain(x)
+        y1, a1 = poisoned(x)
+        assert torch.equal(y0, y1) and all(torch.equal(p, q) for p, q in zip(a0, a1))
+    plain.close()
+    poisoned.close()
+
+
 @pytest.mark.parametrize("fam,scale,nc,task,shapes", [
     ("yolo11", "n", 80, "detect", [(1, 32, 32), (3, 96, 224)]),
     ("yolo11", "s", 80, "detect", [(2, 160, 32), (8, 320, 320)]),
