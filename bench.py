@@ -242,12 +242,9 @@ def main():
                 gathered = pending.wait()
             pending = None
 
-    for _ in range(args.warmup):
-        det, counts = step()
-    drain()
-    torch.cuda.synchronize()
-    # Parity of the benchmarked path and the CPU leg run HERE, before the timed region: the timed steps and the three serial profile
-    # passes are then the last GPU work of the process (tools/prof_summary.py and the PMC scripts window the trace by launch count)
+    # Parity of the benchmarked path and the CPU leg run HERE, before the warm-up: the W warm-up steps lead straight into the K timed steps
+    # (no idle gap in front of the timed region: the CPU leg takes ~10 s), and the timed steps and the three serial profile passes are the
+    # last GPU work of the process (tools/prof_summary.py and the PMC scripts window the trace by launch count)
     cpu_base, parity = None, None
     if rank == 0:
         # Parity of the benchmarked path, so that the headline number travels with its tolerance (north-star: 1e-3 on scores, 1e-3 * imgsz on
@@ -270,6 +267,10 @@ def main():
                 yg = eng(xc.to(dev).to(x.dtype), want_raw=False)[0].float().cpu()
                 parity["vs_cpu_reference"] = dict(parity_stats(yg, yc), images=int(xc.shape[0]),
                                                   against="the cpu_baseline leg's oracle forward (torch fp32 restatement of the reference) on its own sample")
+    for _ in range(args.warmup):
+        det, counts = step()
+    drain()
+    torch.cuda.synchronize()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
