@@ -28,6 +28,7 @@ SOURCES = {
     "bneck_fused.hip": [],
     "c3k2_fused.hip": [],
     "bsyolo_ops.hip": [],
+    "pmsfa_fused.hip": [],
     "elementwise.hip": [],
     "attention.hip": [],
     "detect.hip": [],

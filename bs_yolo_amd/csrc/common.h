@@ -146,6 +146,26 @@ struct DwGenArgs {       // depthwise kh x kw, stride 1 / 2, "same" padding, + b
                          // weights.py "dwg_ext") -- the tiled kernels write x + 0 for them, which is what the full tap loop returns
 };
 int launch_dwconv_generic(const DwGenArgs& a, hipStream_t s);
+struct PmsfaArgs {       // PMSFA's tail in one launch (pmsfa_fused.hip): dst = conv4([conv3(conv2(p1)[:C/4]) | conv2(p1)[C/4:] | p2]) + x, P = [p1 | p2] = conv1(x)
+    const half_t* P;     // conv1's output, C channels
+    int ldp;
+    const half_t* x;     // the module's input (shortcut operand), C channels
+    int ldx;
+    half_t* dst;
+    int ldd;
+    int B, H, W, C;
+    const float* w2;     // conv2: depthwise 5x5 on C/2 channels, f32 [25][wld2]
+    const float* b2;
+    int wld2;
+    const float* w3;     // conv3: depthwise 7x7 on C/4 channels, f32 [49][wld3]
+    const float* b3;
+    int wld3;
+    const half_t* w4;    // conv4: packed 1x1 weights [cout][kpad4]
+    const float* b4;
+    int kpad4;
+};
+bool pmsfa_tail_supported(int C);
+int launch_pmsfa_tail(const PmsfaArgs& a, hipStream_t s);
 int launch_copy_view(const half_t* src, int lds_, int up, int B, int H, int W, int C, half_t* dst, int ldd, hipStream_t s);
 int launch_gap(const half_t* src, int lds_, int B, int H, int W, int C, half_t* out, int ldo, hipStream_t s);
 struct MscaSpArgs {

@@ -464,6 +464,18 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok) return BSY_ERR_ARG;
             return launch_dwconv_generic(a, s);
         }
+        case BSY_OP_PMSFA_TAIL: {
+            PmsfaArgs a;
+            a.P = R.h(op.src0); a.ldp = op.src0.ld; a.x = R.h(op.res); a.ldx = op.res.ld; a.dst = R.h(op.dst); a.ldd = op.dst.ld;
+            a.B = op.B; a.H = op.H; a.W = op.W; a.C = op.dst.C;
+            a.w2 = (const float*)(wb + op.aux_off[0]); a.b2 = (const float*)(wb + op.aux_off[1]); a.wld2 = op.heads;
+            a.w3 = (const float*)(wb + op.aux_off[2]); a.b3 = (const float*)(wb + op.aux_off[3]); a.wld3 = op.key_dim;
+            a.w4 = (const half_t*)(wb + op.aux_off[4]); a.b4 = (const float*)(wb + op.aux_off[5]);
+            int cp = 0;
+            bsy_conv_packed_dims(a.C, a.C, 1, &cp, &a.kpad4);
+            if (!R.ok || op.src0.C != a.C || op.res.C != a.C) return BSY_ERR_ARG;
+            return launch_pmsfa_tail(a, s);
+        }
         case BSY_OP_COPY: {
             const half_t* src = R.h(op.src0);
             half_t* dst = R.h(op.dst);

@@ -81,6 +81,11 @@ def msca_spatial_supported(H: int, W: int) -> bool:
     return H > 0 and W > 0 and H * W <= 1890
 
 
+def pmsfa_tail_supported(c: int) -> bool:
+    """Widths csrc/pmsfa_fused.hip is instantiated for (mirror of pmsfa_tail_supported there)."""
+    return c in (32, 64)
+
+
 def dwpw_supported(c: int, cout: int) -> bool:
     """Widths dwpw_fused_kernel accepts (mirror of bsy_dwpw_fused_supported)."""
     return c > 0 and c % 32 == 0 and c <= 256 and cout % 8 == 0
@@ -105,7 +110,8 @@ class Plan:
     def __init__(self, cfg: dict, B: int, H: int, W: int, in_dtype: int = L.BSY_F16, out_dtype: int = L.BSY_F16,
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
                  fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None,
-                 fuse_tail: Optional[bool] = None, precision: str = "fp16", lanes: Optional[bool] = None, latency: bool = False):
+                 fuse_tail: Optional[bool] = None, precision: str = "fp16", lanes: Optional[bool] = None, latency: bool = False,
+                 fuse_pmsfa: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         # latency mode (round 4; fp16 path): long-K conv layers with few tiles per image run split-K (split_factors below)
         self.latency = bool(latency) and precision == "fp16"
@@ -116,7 +122,7 @@ class Plan:
         self.f32_mode = precision in ("fp32", "fp32x")
         self.split_f16 = precision == "fp32x"
         if self.f32_mode:
-            fuse_stem = fuse_bneck = fuse_head = fuse_dwpw = merge_c3k = fuse_msca = fuse_tail = False
+            fuse_stem = fuse_bneck = fuse_head = fuse_dwpw = merge_c3k = fuse_msca = fuse_tail = fuse_pmsfa = False
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
@@ -127,6 +133,8 @@ class Plan:
         self.merge_c3k = (os.environ.get("BSY_MERGE_C3K", "1") != "0") if merge_c3k is None else bool(merge_c3k)
         self.fuse_msca = (os.environ.get("BSY_FUSE_MSCA", "1") != "0") if fuse_msca is None else bool(fuse_msca)
         self.fuse_tail = (os.environ.get("BSY_FUSE_TAIL", "1") != "0") if fuse_tail is None else bool(fuse_tail)
+        # PMSFA's depthwise 5x5 -> depthwise 7x7 -> 1x1 + shortcut as one launch (round 4, csrc/pmsfa_fused.hip)
+        self.fuse_pmsfa = (os.environ.get("BSY_FUSE_PMSFA", "1") != "0") if fuse_pmsfa is None else bool(fuse_pmsfa)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -399,6 +407,17 @@ class Plan:
         if c % 16:
             return self._pmsfa_padded(name, x, dst)
         P = self.conv(name + ".conv1", x, c, 3, 1)
+        if self.fuse_pmsfa and pmsfa_tail_supported(c) and not x.up:
+            # everything after conv1 in one launch: the map is read once and written once (csrc/pmsfa_fused.hip); the weight records are
+            # the unfused plan's, in its order (blob layout, synth_state_dict's random draws)
+            k2 = self._wrec(name + ".conv2", name=name + ".conv2", kind="dwg", cout=c // 2, cin=1, k=5, kw=5, post=None, rows=None, real_cout=0)
+            k3 = self._wrec(name + ".conv3", name=name + ".conv3", kind="dwg_ext", cout=c // 2, cin=1, k=7, kw=7, post=None, rows=None, real_cout=0)
+            k4 = self._wrec(name + ".conv4", name=name + ".conv4", kind="conv", cout=c, cin=c, k=1, perm=None)
+            self.ops.append(dict(kind=L.OP_PMSFA_TAIL, H=x.H, W=x.W, OH=x.H, OW=x.W, src0=P, res=x, dst=dst, ksize=1, stride=1, pad=0, act=1,
+                                 wkeys=[k2, k3, k4], heads=c // 2, key_dim=c // 2, name=name + ".tail", lane=self._lane,
+                                 mfma_flops=2 * self.B * x.H * x.W * c * c))
+            self.flops += 2 * self.B * x.H * x.W * (c // 2 * 25 + c // 2 * 49 + c * c)  # what the three launches count
+            return
         Q = self.dwconv_g(name + ".conv2", P.slice(0, c // 2), 5, 5, 1, c // 2)
         # S overwrites p1 (dead once conv2 has read it): conv4 then reads ONE contiguous source [S | p2] = P -- at c = 32 two 16-channel
         # sources put it on the unaligned configuration (0.10 ms at 160 x 160, B = 64); same K order, same bits

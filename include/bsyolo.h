@@ -86,6 +86,11 @@ enum bsy_op_kind {
                             * m.0.cv1, m.0.cv2, cv2.  Widths (Cin, c, C2) = (64, 32, 128): YOLO11s model.2, YOLO11n model.4        */
     BSY_OP_S2D = 19,       /* space-to-depth of the image for a 6x6 stride-2 pad-2 stem (YOLOv5u): src0 = image (BCHW, in_dtype) -> dst
                             * NHWC f16 (B, H/2, W/2, 16): channel (dy*2+dx)*3 + c, 12..15 zero; an ordinary 3x3 s1 conv follows   */
+    BSY_OP_PMSFA_TAIL = 20, /* PMSFA after its conv1, as one launch (block.py:3046-3054; round 4, csrc/pmsfa_fused.hip): src0 = P = conv1's output
+                            * [p1 | p2] (C channels), res = the module's input x, dst = conv4(cat(conv3(q1), q2, p2)) + x with
+                            * [q1 | q2] = conv2(p1).  aux_off = (weights, bias) byte offsets of conv2 (f32 [25][heads]), conv3 (f32 [49][key_dim])
+                            * and conv4 (packed 1x1); heads / key_dim = row lengths of the two depthwise weight tensors.  C in {32, 64, 128};
+                            * the same bits as the three launches it replaces                                              */
     BSY_OP_ELA = 15        /* ELA (nn/Addmodules/ELA.py:77-101): ksize = Conv1d taps; w_off -> f32 blob [spatial_conv C*k]
                             * [ch_att conv C*k][gn.weight C][gn.bias C]; scale, lvl_stride[0], lvl_stride[1] =
                             * sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight);

@@ -1354,7 +1354,7 @@ def test_engine_pmsfa_pass_through_half_is_bit_identical(scale, shape, monkeypat
     cfg = stock_cfg("bsyolo11", scale, 12)
     B, H, W = shape
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV)
-    eng = YoloEngine(cfg, P, autotune=False)
+    eng = YoloEngine(cfg, P, autotune=False, fuse_pmsfa=False)
     plan, _ = eng.plan_for(B, H, W, torch.float16, torch.float16)
     assert sum(1 for o in plan.ops if o["kind"] == L.OP_DWCONV_G and o.get("mid_c", 0) > 0) >= 6
     y1, r1 = eng(x)
@@ -1367,6 +1367,34 @@ def test_engine_pmsfa_pass_through_half_is_bit_identical(scale, shape, monkeypat
     for a, b in zip(r1, r2):
         assert torch.equal(a, b)
     eng.close()
+
+
+@pytest.mark.parametrize("scale,shape", [("s", (2, 96, 160)), ("s", (1, 640, 640)), ("n", (3, 64, 64)), ("s", (2, 416, 288)), ("n", (1, 1280, 1280)),
+                                         ("m", (1, 160, 96))])
+def test_engine_pmsfa_tail_fusion_is_bit_identical(scale, shape):
+    """BS-YOLO: PMSFA's depthwise 5 x 5 -> depthwise 7 x 7 -> concat -> 1 x 1 conv + shortcut as one launch (block.py:3046-3054,
+    csrc/pmsfa_fused.hip) returns exactly what the three launches it replaces return: widths 32 / 64 (scale s: model.2 / 4 / 6; n: model.4 / 6 / 8;
+    m: model.2 -- 16- and 128-wide modules stay unfused), maps that are not multiples of the 16 x 16 / 8 x 16 tiles (104 x 72 ...
+    13 x 9: partial tiles, halos that leave the image on every side), 2 x 2 maps (the whole halo is padding) and 320 x 320 maps."""
+    m = R.Model("bsyolo11", scale, 12, "detect")
+    P = R.synth_params(m, 11)
+    cfg = stock_cfg("bsyolo11", scale, 12)
+    fused = YoloEngine(cfg, P, fuse_pmsfa=True, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_pmsfa=False, autotune=False)
+    B, H, W = shape
+    pf, _ = fused.plan_for(B, H, W, torch.float16, torch.float16)
+    pp, _ = plain.plan_for(B, H, W, torch.float16, torch.float16)
+    nt = sum(o["kind"] == L.OP_PMSFA_TAIL for o in pf.ops)
+    assert nt >= (1 if scale == "m" else 4) and len(pp.ops) - len(pf.ops) == 2 * nt and not any(o["kind"] == L.OP_PMSFA_TAIL for o in pp.ops)
+    assert {o["dst"].C for o in pf.ops if o["kind"] == L.OP_PMSFA_TAIL} <= {32, 64}
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV)
+    yf, rf = fused(x)
+    yp, rp = plain(x)
+    assert torch.equal(yf, yp)
+    for a, b in zip(rf, rp):
+        assert torch.equal(a, b)
+    fused.close()
+    plain.close()
 
 
 @pytest.mark.parametrize("shape", [(2, 96, 160), (1, 640, 640), (3, 64, 64), (1, 1280, 1280)])
@@ -1729,7 +1757,7 @@ def test_engine_every_layer_matches_reference(tag, fused, monkeypatch):
     m = R.Model(meta["family"], meta["scale"], meta["nc"], meta["task"])
     P = R.synth_params(m, meta["seed"])
     kw = {} if fused else dict(fuse_stem=False, fuse_bneck=False, fuse_head=False, fuse_dwpw=False, merge_c3k=False, fuse_msca=False,
-                               fuse_tail=False)
+                               fuse_tail=False, fuse_pmsfa=False)
     eng = YoloEngine(stock_cfg(meta["family"], meta["scale"], meta["nc"], meta["task"]), P, **kw)
     x = torch.from_numpy(z["x0"])
     eng(x.half().to(DEV))

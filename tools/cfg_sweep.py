@@ -17,7 +17,7 @@ for (B, H, W, cin, cout, k, s) in SHAPES:
     w = torch.randn(cout, cin, k, k) * (2.0 / (cin * k * k)) ** 0.5
     wp, bp = O.pack_conv_weight(w, torch.zeros(cout), dev)
     res = []
-    for cfg in [-1] + [(t << 4) | v for t in range(12) for v in range(4)]:
+    for cfg in [-1] + [(t << 4) | v for t in range(16) for v in range(8)]:
         if cfg < 0:
             os.environ.pop("BSY_CONV_CFG", None)
         else:
