@@ -17,53 +17,71 @@
 
 #define VT_LD 36  // halves per V^T row in LDS (72 B: conflict-free 8-byte reads across 32 rows)
 
+// KD = key_dim (channels of q and k per head), HD = head_dim (channels of v per head).  The stock scales give 32 / 64 (block.py:4253-4258:
+// num_heads = dim // 64, key_dim = head_dim / 2); other width multiples give other pairs (0.1875: one head of 48 / 96) -- instantiated for
+// KD in {16, 32, 48, 64} and HD in {32, 64, 96, 128}.  K rows in LDS are KD + 8 halves long (16 x odd bytes: conflict-free 16-byte reads).
+template <int KD, int HD>
 __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv, int ld, int N, int heads,
                                                         float scale, half_t* __restrict__ out, int ldo) {
-    __shared__ __attribute__((aligned(16))) half_t sK[32 * 32];
-    __shared__ __attribute__((aligned(16))) half_t sVT[64 * VT_LD];
+    constexpr int KS = KD / 16, DT = HD / 32, NCK = KD / 8, NCV = HD / 8, KLD = KD + 8;
+    constexpr int NV = (32 * NCV + 255) / 256;  // V pieces per thread per key tile
+    static_assert(KD % 16 == 0 && KD <= 64 && HD % 32 == 0 && HD <= 128, "head shape");
+    __shared__ __attribute__((aligned(16))) half_t sK[32 * KLD];
+    __shared__ __attribute__((aligned(16))) half_t sVT[HD * VT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int qoff = head * 32, koff = heads * 32 + head * 32, voff = heads * 64 + head * 64;
+    const int qoff = head * KD, koff = heads * KD + head * KD, voff = heads * 2 * KD + head * HD;
     const half_t* base = qkv + (size_t)b * N * ld;
 
     const int q = blockIdx.x * 128 + wave * 32 + lrow;
     const bool qvalid = q < N;
-    half8 qf[2];
+    half8 qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         qf[ks] = qvalid ? *reinterpret_cast<const half8*>(base + (size_t)q * ld + qoff + 16 * ks + 8 * lh) : z;
     }
 
-    f32x16 o[2];
+    f32x16 o[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int kkey = tid >> 2, kchunk = tid & 3;  // K staging (threads 0..127)
-    const int vkey = tid >> 3, vchunk = tid & 7;  // V staging (all threads)
+    const int kkey = tid / NCK, kchunk = tid % NCK;  // K staging (threads 0 .. 32 * NCK - 1)
     const int ntiles = (N + 31) / 32;
     // K / V rows of key tile t are fetched into registers while tile t - 1 is being multiplied (round 3: fetched at the top of their
     // own iteration, every one of the 13 tiles of a 20 x 20 map exposed a full global-load latency: 38 us for 8 GFLOP)
     const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    half8 kreg = z, vreg = z;
+    half8 kreg = z, vreg[NV];
     auto fetch = [&](const int k0) {
         kreg = z;
-        vreg = z;
-        if (tid < 128 && k0 + kkey < N)
+        if (tid < 32 * NCK && k0 + kkey < N)
             kreg = *reinterpret_cast<const half8*>(base + (size_t)(k0 + kkey) * ld + koff + kchunk * 8);
-        if (k0 + vkey < N) vreg = *reinterpret_cast<const half8*>(base + (size_t)(k0 + vkey) * ld + voff + vchunk * 8);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int id = tid + 256 * i;
+            const int vkey = id / NCV, vchunk = id % NCV;
+            vreg[i] = z;
+            if (id < 32 * NCV && k0 + vkey < N) vreg[i] = *reinterpret_cast<const half8*>(base + (size_t)(k0 + vkey) * ld + voff + vchunk * 8);
+        }
     };
     fetch(0);
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = t * 32;
         __syncthreads();  // previous tile fully consumed
-        if (tid < 128) *reinterpret_cast<half8*>(sK + kkey * 32 + ((kchunk ^ ((kkey >> 2) & 3)) << 3)) = kreg;
+        if (tid < 32 * NCK) *reinterpret_cast<half8*>(sK + kkey * KLD + kchunk * 8) = kreg;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sVT[(vchunk * 8 + i) * VT_LD + vkey] = vreg[i];
+        for (int i = 0; i < NV; ++i) {
+            const int id = tid + 256 * i;
+            const int vkey = id / NCV, vchunk = id % NCV;
+            if (id < 32 * NCV) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sVT[(vchunk * 8 + j) * VT_LD + vkey] = vreg[i][j];
+            }
+        }
         __syncthreads();
         if (t + 1 < ntiles) fetch(k0 + 32);
 
@@ -72,9 +90,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 2 * ks + lh;
-            const half8 a = *reinterpret_cast<const half8*>(sK + lrow * 32 + ((chunk ^ ((lrow >> 2) & 3)) << 3));
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 a = *reinterpret_cast<const half8*>(sK + lrow * KLD + 16 * ks + 8 * lh);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s, 0, 0, 0);
         }
         float mt = -INFINITY;
@@ -99,7 +116,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
         l_run = l_run * alpha + rs;
         m_run = m_new;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         // O^T += V^T P^T
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) pb[j] = (half_t)s[8 * ks + j];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 const half_t* vp = sVT + (dt * 32 + lrow) * VT_LD + 16 * ks + 4 * lh;
                 const half4 v0 = *reinterpret_cast<const half4*>(vp);
                 const half4 v1 = *reinterpret_cast<const half4*>(vp + 8);
@@ -120,9 +137,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
     }
     if (!qvalid) return;
     const float inv = 1.0f / l_run;
-    half_t* op = out + ((size_t)b * N + q) * ldo + head * 64;
+    half_t* op = out + ((size_t)b * N + q) * ldo + head * HD;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             half4 v = {(half_t)(o[dt][4 * g] * inv), (half_t)(o[dt][4 * g + 1] * inv), (half_t)(o[dt][4 * g + 2] * inv),
@@ -131,13 +148,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
         }
 }
 
+bool attention_supported(int key_dim, int head_dim) {
+    return key_dim > 0 && key_dim <= 64 && !(key_dim & 15) && head_dim > 0 && head_dim <= 128 && !(head_dim & 31);
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t s) {
-    if (a.key_dim != 32 || a.head_dim != 64) BSY_FAIL(BSY_ERR_ARG, "attention: key_dim/head_dim must be 32/64 (got %d/%d)", a.key_dim, a.head_dim);
+    if (!attention_supported(a.key_dim, a.head_dim))
+        BSY_FAIL(BSY_ERR_ARG, "attention: key_dim must be 16 / 32 / 48 / 64 and head_dim 32 / 64 / 96 / 128 (got %d / %d)", a.key_dim, a.head_dim);
     if ((a.ld & 7) || (a.ldo & 3) || ((uintptr_t)a.qkv & 15) || ((uintptr_t)a.out & 7) || a.N <= 0 || a.heads <= 0)
         BSY_FAIL(BSY_ERR_ARG, "attention: bad layout");
-    if (a.ld < a.heads * 128 || a.ldo < a.heads * 64) BSY_FAIL(BSY_ERR_ARG, "attention: row stride too small");
+    if (a.ld < a.heads * (2 * a.key_dim + a.head_dim) || a.ldo < a.heads * a.head_dim) BSY_FAIL(BSY_ERR_ARG, "attention: row stride too small");
     dim3 grid((a.N + 127) / 128, a.heads, a.B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, a.qkv, a.ld, a.N, a.heads, a.scale, a.out, a.ldo);
+#define ATT_GO(KD_, HD_) \
+    if (a.key_dim == KD_ && a.head_dim == HD_) hipLaunchKernelGGL((attention_kernel<KD_, HD_>), grid, dim3(256), 0, s, a.qkv, a.ld, a.N, a.heads, a.scale, a.out, a.ldo)
+#define ATT_ROW(KD_) ATT_GO(KD_, 32); ATT_GO(KD_, 64); ATT_GO(KD_, 96); ATT_GO(KD_, 128)
+    ATT_ROW(16); ATT_ROW(32); ATT_ROW(48); ATT_ROW(64);
+#undef ATT_ROW
+#undef ATT_GO
     HIP_TRY(hipGetLastError());
     return BSY_OK;
 }

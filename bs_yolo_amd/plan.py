@@ -41,10 +41,34 @@ class T:
     W: int
     up: bool = False
     f32: bool = False
+    # Zero-padded pieces (round 4; the fp16 path reads 8-channel pieces, so a C2f / C3k2 whose chunk width is 12 or 20 channels carries every
+    # chunk on the next multiple of 8): cmap[j] = which REAL channel of this tensor the stored channel j is, or -1 for a padding channel
+    # that is always zero (zero weight rows and bias where it is written, SiLU(0) = 0; zero weight columns where it is read).  None = all real.
+    cmap: Optional[Tuple[int, ...]] = None
 
     def slice(self, c0: int, c: int) -> "T":
         assert 0 <= c0 and c0 + c <= self.C
-        return T(self.buf, self.ld, self.coff + c0, c, self.H, self.W, self.up, self.f32)
+        cm = None
+        if self.cmap is not None:
+            before = sum(1 for v in self.cmap[:c0] if v >= 0)
+            cm = tuple(v - before if v >= 0 else -1 for v in self.cmap[c0:c0 + c])
+            if all(v >= 0 for v in cm):
+                cm = None
+        return T(self.buf, self.ld, self.coff + c0, c, self.H, self.W, self.up, self.f32, cm)
+
+    @property
+    def real(self) -> int:
+        """Channels that carry data (== C unless the tensor has padding pieces)."""
+        return self.C if self.cmap is None else sum(1 for v in self.cmap if v >= 0)
+
+    def padded(self, pieces: Sequence[Tuple[int, int]]) -> "T":
+        """This tensor seen as consecutive (stored width, real width) pieces, each zero-padded at its end."""
+        cm, base = [], 0
+        for width, real in pieces:
+            cm += [base + i if i < real else -1 for i in range(width)]
+            base += real
+        assert len(cm) == self.C
+        return T(self.buf, self.ld, self.coff, self.C, self.H, self.W, self.up, self.f32, tuple(cm))
 
     def view(self):
         return (self.buf, self.ld, self.coff, self.C)
@@ -79,6 +103,11 @@ def stem_supported(c0: int, c1: int, H: int, W: int) -> bool:
 def msca_spatial_supported(H: int, W: int) -> bool:
     """Maps whose (H x W x 8 channel) slabs fit LDS (mirror of csrc/bsyolo_ops.hip msca_spatial_supported)."""
     return H > 0 and W > 0 and H * W <= 1890
+
+
+def attention_supported(kd: int, hd: int) -> bool:
+    """Head shapes csrc/attention.hip is instantiated for (mirror of attention_supported there)."""
+    return 0 < kd <= 64 and kd % 16 == 0 and 0 < hd <= 128 and hd % 32 == 0
 
 
 def pmsfa_tail_supported(c: int) -> bool:
@@ -234,9 +263,22 @@ class Plan:
         assert dst.C == cout and dst.H == OH and dst.W == OW and dst.f32 == (out_f32 or self.f32_mode) and not dst.up
         if res is not None:
             assert res.C == cout and res.H == OH and res.W == OW and not res.up
+        if rows is None and cols is None and (any(t.cmap is not None for t in srcs) or dst.cmap is not None):
+            # padded pieces on either side: the op's weight matrix is the module's with zero rows / columns at the padding channels
+            assert perm is None and wshape is None and not real[1]
+            out_real = real[0] or dst.real
+            rows = list(dst.cmap) if dst.cmap is not None else [i if i < out_real else -1 for i in range(cout)]
+            cols, base = [], 0
+            for t in srcs:
+                cols += [base + v if v >= 0 else -1 for v in (t.cmap if t.cmap is not None else range(t.C))]
+                base += t.real
+            real = (out_real, base)
+            if real[0] < cout and dst.cmap is None:
+                dst = dst.padded([(cout, real[0])])
         if name2 is not None:
             assert not plain and perm is None and cout % 2 == 0
-            key = self._wrec(name + "+" + name2, name=name, kind="conv2", cout=cout, cin=cin, k=k, post=name2)
+            key = self._wrec(name + "+" + name2, name=name, kind="conv2", cout=cout, cin=cin, k=k, post=name2, rows=rows, cols=cols,
+                             real_cout=real[0], real_cin=real[1])
         else:
             wc, wi, wk = wshape or (cout, cin, k)  # wshape: the module's own weight shape where the op runs a re-laid-out copy
             key = self._wrec(name, name=name, kind=wkind or ("plain" if plain else "conv"), cout=wc, cin=wi, k=wk, perm=perm,
@@ -318,8 +360,8 @@ class Plan:
     # ---- module expansions -----------------------------------------------------------------------------------
     def bottleneck(self, name: str, x: T, dst: T, shortcut: bool, k=(3, 3), e=0.5):
         """block.py:3405-3419: x + cv2(cv1(x))."""
-        c_ = int(dst.C * e)
-        if (self.fuse_bneck and tuple(k) == (3, 3) and shortcut and x.C == dst.C and not x.up and not x.f32
+        c_ = int(dst.real * e)
+        if (self.fuse_bneck and tuple(k) == (3, 3) and shortcut and x.C == dst.C and not x.up and not x.f32 and x.cmap is None and dst.cmap is None
                 and bneck_supported(x.C, c_)):
             # one launch, hidden map kept in LDS (csrc/bneck_fused.hip)
             k1 = self._wrec(name + ".cv1", name=name + ".cv1", kind="conv", cout=c_, cin=x.C, k=3, perm=None)
@@ -335,6 +377,10 @@ class Plan:
             # hidden map is carried on the next multiple of 8 with zero weights and bias in the padding (weights.py real_cout /
             # real_cin, as Detect's class branch does for nc-dependent widths) -- SiLU(0) = 0 there, the real channels are unchanged
             c8 = make_divisible(c_, 8)
+            if x.cmap is not None or dst.cmap is not None:  # inside a block whose chunks are padded pieces themselves (c2f below)
+                t = self.conv(name + ".cv1", x, c8, k[0], 1, dst=self.alloc(c8, x.H, x.W).padded([(c8, c_)]))
+                self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=res)
+                return
             t = self.conv(name + ".cv1", x, c8, k[0], 1, real=(c_, 0))
             self.conv(name + ".cv2", t, dst.C, k[1], 1, dst=dst, res=res, real=(0, c_))
             return
@@ -344,19 +390,25 @@ class Plan:
     def c3k(self, name: str, x, dst: T, n: int, shortcut: bool, k=(3, 3)):
         """block.py:3320-3334 + :3807-3815: cv3(cat(m(cv1 x), cv2 x)), m = n x Bottleneck(c_, c_, k=(3,3), e=1); C3 itself
         (YOLOv5u) is the same with k = ((1,1), (3,3)) and may read a two-operand Concat."""
-        c_ = int(dst.C * 0.5)
+        cr = int(dst.real * 0.5)  # the module's hidden width
         x0 = x if isinstance(x, T) else x[0]
+        # fp16 path, hidden width not a multiple of 8 (a C3k of 12 / 20 / 24 channels ...): both halves of the concat are zero-padded pieces
+        pad = bool(cr % 8) and not self.f32_mode
+        c_ = make_divisible(cr, 8) if pad else cr
+        new = (lambda: self.alloc(c_, x0.H, x0.W).padded([(c_, cr)])) if pad else (lambda: self.alloc(c_, x0.H, x0.W))
         cat = self.alloc(2 * c_, x0.H, x0.W)
+        if pad:
+            cat = cat.padded([(c_, cr), (c_, cr)])
         if self.merge_c3k and n >= 2:
             # cv1 and cv2 read the same x: ONE launch writes [cv1 x | cv2 x] into the concat buffer (twice the cout per
             # pixel tile, one launch less); the last bottleneck then overwrites the cv1 half, which only the first one reads
             self.conv(name + ".cv1", x, 2 * c_, 1, 1, dst=cat, name2=name + ".cv2")
             cur = cat.slice(0, c_)
         else:
-            cur = self.conv(name + ".cv1", x, c_, 1, 1)
+            cur = self.conv(name + ".cv1", x, c_, 1, 1, dst=new())
             self.conv(name + ".cv2", x, c_, 1, 1, dst=cat.slice(c_, c_))
         for i in range(n):
-            out = cat.slice(0, c_) if i == n - 1 else self.alloc(c_, x0.H, x0.W)
+            out = cat.slice(0, c_) if i == n - 1 else new()
             self.bottleneck(f"{name}.m.{i}", cur, out, shortcut, k, 1.0)
             cur = out
         self.conv(name + ".cv3", cat, dst.C, 1, 1, dst=dst)
@@ -377,7 +429,14 @@ class Plan:
                                  act=1, wkeys=keys, mid_c=c, name=name, lane=self._lane, mfma_flops=fl))
             self.flops += fl
             return dst
+        # fp16 path, chunk width not a multiple of 8 (c = 12 / 20 ...; tasks.py:1016 scales c2 by any width multiple): every chunk of the
+        # concat is carried on the next multiple of 8 as a zero-padded piece (T.cmap) -- cv1 writes zero rows there, cv2 reads zero columns
+        cr = c
+        if cr % 8 and not self.f32_mode and inner in ("bottleneck", "c2f", "c3k"):
+            c = make_divisible(cr, 8)
         cat = self.alloc((2 + n) * c, xs[0].H, xs[0].W)
+        if c != cr:
+            cat = cat.padded([(c, cr)] * (2 + n))
         self.conv(name + ".cv1", xs, 2 * c, 1, 1, dst=cat.slice(0, 2 * c))
         for i in range(n):
             src, dst = cat.slice((1 + i) * c, c), cat.slice((2 + i) * c, c)
@@ -527,6 +586,9 @@ class Plan:
         nh = c // 64
         hd = c // nh
         kd = int(hd * 0.5)
+        if not self.f32_mode and not attention_supported(kd, hd):
+            # e.g. a width multiple of 0.3125: heads of 40 / 80 channels; the fp32-storage modes run any head shape
+            raise NotImplementedError(f"{name}: attention heads of key_dim {kd} / head_dim {hd} are not on the fp16 path (16..64 in steps of 16 / 32..128 in steps of 32)")
         ab = self.alloc(2 * c, x.H, x.W)
         self.conv(name + ".cv1", x, 2 * c, 1, 1, dst=ab)
         b = ab.slice(c, c)

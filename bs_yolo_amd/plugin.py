@@ -71,7 +71,7 @@ def cfg_of(model) -> dict:
     try:
         Plan(cfg, 1, 64, 64)  # raises NotImplementedError / AssertionError on unsupported graphs
     except NotImplementedError:
-        # widths only the fp32 mode takes (concat pieces that are not multiples of 8 channels, e.g. a width multiple of 0.1875): fp32
+        # widths only the fp32 modes take (BS-YOLO's PMSFA on a width that is not a multiple of 8, e.g. a width multiple of 0.1875): fp32
         # callers still get the engine, fp16 calls fall back to the reference forward when their engine is built
         Plan(cfg, 1, 64, 64, precision="fp32")
     return cfg
@@ -95,8 +95,8 @@ def _weights_version(model) -> tuple:
 
 
 def graph_support(cfg: dict) -> dict:
-    """Which engine precisions can run this yaml graph: {"fp16": bool, "fp32": bool} (the fp32 / fp32x modes also take concat piece
-    widths that are not multiples of 8 channels, e.g. a width multiple of 0.1875).  Decided once, on the host, from the plan alone."""
+    """Which engine precisions can run this yaml graph: {"fp16": bool, "fp32": bool} (the fp32 / fp32x modes also take PMSFA widths
+    that are not multiples of 8 channels, e.g. BS-YOLO at a width multiple of 0.1875).  Decided once, on the host, from the plan alone."""
     out = {}
     for prec in ("fp16", "fp32"):
         try:

@@ -248,7 +248,7 @@ def synth_state_dict(plan: Plan, seed: int = 0, cls_gain: float = 0.1, cls_bias:
         cin = 1 if r.kind == "dw" else (r.real_cin or r.cin)
         fan = cin * r.k * r.k
         # kind "conv2": two modules of half the width each, drawn in the order the unmerged plan draws them
-        for nm, co in (((r.name, r.cout // 2), (r.post, r.cout // 2)) if r.kind == "conv2" else ((r.name, r.real_cout or r.cout),)):
+        for nm, co in (((r.name, (r.real_cout or r.cout) // 2), (r.post, (r.real_cout or r.cout) // 2)) if r.kind == "conv2" else ((r.name, r.real_cout or r.cout),)):
             sd[nm + ".conv.weight"] = torch.randn(co, cin, r.k, r.k, generator=g) * (2.0 / fan) ** 0.5
             sd[nm + ".bn.weight"] = torch.rand(co, generator=g) * 0.6 + 0.7
             sd[nm + ".bn.bias"] = torch.rand(co, generator=g) * 0.6 - 0.3

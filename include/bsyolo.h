@@ -309,7 +309,8 @@ int bsy_dwconv3x3(const void* x, int ldx, int B, int H, int W, int C, const floa
 int bsy_sppf_pool(void* buf, int ld, int B, int H, int W, int C, bsy_stream stream);
 
 /* Attention core (block.py:4267-4286): qkv NHWC f16 with channel order [q(all heads) | k(all heads) | v(all heads)],
- * out[pixel][head*head_dim + d] = sum_j softmax_j(q_i . k_j * scale) v_j[d].  key_dim must be 32, head_dim 64. */
+ * out[pixel][head*head_dim + d] = sum_j softmax_j(q_i . k_j * scale) v_j[d].  key_dim in {16, 32, 48, 64}, head_dim in {32, 64, 96, 128}
+ * (the stock scales: 32 / 64; other width multiples give e.g. one head of 48 / 96, block.py:4253-4258); BSY_ERR_ARG otherwise. */
 int bsy_attention(const void* qkv, int ld, int B, int N, int heads, int key_dim, int head_dim, float scale, void* out,
                   int ldo, bsy_stream stream);
 

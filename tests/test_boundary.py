@@ -133,16 +133,19 @@ def test_accelerate_never_downcasts_fp32_callers_silently():
 
 
 def test_accelerate_on_a_graph_only_the_fp32_modes_take():
-    """a width multiple of 0.1875 gives C3k2 chunk widths of 12 channels, which only the fp32-storage modes run (the fp16
-    kernels read 8-channel pieces).  `accelerate` accepts the model; fp32 images take the engine; fp16 images go STRAIGHT to the
-    reference forward -- no engine build (device-to-host weight copy, engine create / destroy) per call: `rebuilds` does not grow."""
-    fam = "yolo11"
+    """a graph only the fp32-storage modes run -- BS-YOLO at a width multiple of 0.1875: its C3k2_gai chunks are 12 channels wide
+    and PMSFA's halves / quarters of 12 are not 8-channel pieces (round 4 carries the 12-wide chunks of the STOCK blocks as zero-padded
+    pieces on the fp16 path; PMSFA's depthwise pieces need a multiple of 8).  `accelerate` accepts the model; fp32 images take the engine;
+    fp16 images go STRAIGHT to the reference forward -- no engine build (device-to-host weight copy, engine create / destroy) per call:
+    `rebuilds` does not grow."""
+    fam = "bsyolo11"
     R.SCALES[fam] = dict(R.SCALES[fam], t=(0.5, 0.1875, 1024))
     try:
-        m = StandIn(fam, "t", 80, "detect", seed=2)
-        m.yaml = dict(stock_cfg(fam, "n", 80), scale="t", scales={"t": [0.5, 0.1875, 1024]})
+        m = StandIn(fam, "t", 12, "detect", seed=2)
+        m.yaml = dict(stock_cfg(fam, "n", 12), scale="t", scales={"t": [0.5, 0.1875, 1024]})
         m = m.to(DEV)
         assert plugin.graph_support(m.yaml) == {"fp16": False, "fp32": True}
+        assert plugin.graph_support(dict(stock_cfg("yolo11", "n", 80), scale="t", scales={"t": [0.5, 0.1875, 1024]})) == {"fp16": True, "fp32": True}
         plugin.accelerate(m)
         x = _x(seed=9).to(DEV)
         y_ref, _ = StandIn.forward(m, x)

@@ -717,9 +717,10 @@ def test_sppf_pool_exact():
     assert torch.equal(nchw(out.float().cpu()), ref)  # max of fp16 values is exact
 
 
-@pytest.mark.parametrize("B,heads,N", [(2, 2, 100), (1, 4, 400), (1, 2, 37)])
-def test_attention_matches_oracle(B, heads, N):
-    kd, hd = 32, 64
+@pytest.mark.parametrize("B,heads,N,kd,hd", [(2, 2, 100, 32, 64), (1, 4, 400, 32, 64), (1, 2, 37, 32, 64),
+                                             (2, 1, 100, 48, 96),   # one head of 48 / 96: C2PSA at a width multiple of 0.1875 (block.py:4253-4258)
+                                             (1, 3, 70, 16, 32), (1, 2, 400, 64, 128), (2, 2, 33, 48, 64), (1, 1, 9, 16, 128)])
+def test_attention_matches_oracle(B, heads, N, kd, hd):
     g = torch.Generator().manual_seed(7)
     q = h16(torch.randn(B, heads, kd, N, generator=g))
     k = h16(torch.randn(B, heads, kd, N, generator=g))
@@ -2228,11 +2229,16 @@ def test_engine_top_level_dwconv_layers_match_oracle():
             d_.pop(fam, None)
 
 
-@pytest.mark.parametrize("fam,width", [("yolo11", 0.375), ("yolo11", 0.125), ("yolov8", 0.375), ("bsyolo11", 0.375)])
+@pytest.mark.parametrize("fam,width", [("yolo11", 0.375), ("yolo11", 0.125), ("yolov8", 0.375), ("bsyolo11", 0.375), ("yolo11", 0.1875), ("yolov8", 0.1875),
+                                       ("yolov8", 0.3125), ("yolov5", 0.1875), ("yolov5", 0.3125)])
 def test_engine_on_custom_width_multiples(fam, width):
     """Width multiples other than the stock scales' (a `scales:` entry of the user's yaml, tasks.py:937-941): at 0.375 / 0.125 the
     Bottlenecks inside YOLO11's C3k2 blocks have 12 / 4 hidden channels (carried on 16 / 8 with zero weights in the padding,
-    plan.py bottleneck()), BS-YOLO's PMSFA runs on 24 channels (_pmsfa_padded).  Both precisions against the oracle."""
+    plan.py bottleneck()), BS-YOLO's PMSFA runs on 24 channels (_pmsfa_padded).  At 0.1875 / 0.3125 / 0.15625 the CHUNKS of C2f / C3k2 / C3 /
+    C3k blocks are 12 / 20 channels wide (block.py:3295-3317, 3320-3334; tasks.py:1016): round 4 carries them as zero-padded 16- / 24-channel
+    pieces of the concat buffers on the fp16 path (plan.py T.cmap; before, only the fp32-storage modes ran such graphs).
+    YOLO11's C2PSA then has one attention head of 48 / 96 channels (csrc/attention.hip takes key_dim 16 .. 64, head_dim 32 .. 128; 0.3125 would
+    give 40 / 80, which only the fp32-storage modes run: test_plan_says_which_precisions_run_a_width below).  Every precision against the oracle."""
     R.SCALES[fam] = dict(R.SCALES[fam], t=(0.5, width, 1024))
     try:
         nc = 12 if fam == "bsyolo11" else 80
@@ -2242,15 +2248,27 @@ def test_engine_on_custom_width_multiples(fam, width):
         cfg["scale"], cfg["scales"] = "t", {"t": [0.5, width, 1024]}
         x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(11))
         with torch.inference_mode():
-            yref, _ = m.forward(P, x)
+            yref, rref = m.forward(P, x)
         for prec in ("fp32", "fp32x"):  # fp32x: channel counts its kernels do not take (Cin % 8, Cout % 4) run on the exact ones
             e32 = YoloEngine(cfg, P, precision=prec)
             y32, _ = e32(x.to(DEV))
             assert float((y32.cpu()[:, 4:] - yref[:, 4:]).abs().max()) <= 1e-3 and float((y32.cpu()[:, :4] - yref[:, :4]).abs().max()) <= 1e-3 * 128, prec
             e32.close()
         e16 = YoloEngine(cfg, P)
-        y16, _ = e16(x.half().to(DEV))
+        y16, r16 = e16(x.half().to(DEV))
         d = (y16.float().cpu() - yref).abs()
+        if width in (0.1875, 0.3125):
+            # these seeded random models put logits of +-500 .. 800 on the head's raw maps (narrow stems, no trained normalisation), so the
+            # DECODED scores of fp16 storage flip wherever a logit sits near 0 (yolov5 0.1875: score max 0.25 at a mean of 7e-4) -- the bound
+            # is on the raw maps, relative to their range: measured max 2.3e-3 .. 3.0e-3, mean 3e-4 .. 4e-4 (the backbone layers of the same
+            # run: 2e-3 .. 3e-3 max).  A padding channel read as data would be O(1) of the range.
+            for a_, b_ in zip(r16, rref):
+                e = (a_.float().cpu() - b_).abs()
+                rng = float(b_.abs().max())
+                assert float(e.max()) <= 8e-3 * rng and float(e.mean()) <= 1.5e-3 * rng, (float(e.max()) / rng, float(e.mean()) / rng)
+            assert float(d[:, 4:].mean()) < 2e-3 and float(d[:, :4].mean()) < 0.5
+            e16.close()
+            return
         # fp16 storage on seeded random weights (test_engine_matches_reference_golden explains the statistics).  Measured (max / mean of
         # scores, max / mean px of boxes): yolo11 0.375 1.7e-2 / 3.8e-4 / 2.5 / 0.11, yolo11 0.125 6.9e-3 / 3.1e-5 / 0.66 / 0.04, yolov8 0.375
         # -- which has NO padded block -- 1.4e-2 / 3.7e-4 / 3.3 / 0.09, bsyolo11 0.375 6.5e-3 / 8.7e-5 / 1.1 / 0.08: the noise of these

@@ -265,6 +265,89 @@ def test_plan_consumes_exactly_the_reference_parameters():
                 assert p.buf_bytes[t.buf] == p.B * hs * ws * t.ld * (4 if t.f32 else 2)
 
 
+@pytest.mark.parametrize("fam,width", [("yolo11", 0.1875), ("yolov8", 0.1875), ("yolov8", 0.3125), ("yolov5", 0.3125), ("yolov5", 0.1875)])
+def test_c2f_chunks_that_are_not_multiples_of_8_are_zero_padded_pieces(fam, width):
+    """A width multiple like 0.1875 gives C2f / C3k2 chunk widths of 12 channels (tasks.py:1016, block.py:3295-3317), 0.3125 gives 20;
+    YOLOv5u's C3 then has halves of 12 / 20 channels (the C3k path).  The fp16 kernels read 8-channel pieces, so the plan carries every chunk on the next multiple of 8 as a
+    zero-padded piece (plan.py T.cmap): the conv that writes a piece has zero weight rows and bias at the padding, the conv that reads it zero
+    weight columns.  Checked on the packed matrices, against the module's own folded weights."""
+    R.SCALES[fam] = dict(R.SCALES[fam], t=(0.5, width, 1024))
+    try:
+        cfg = dict(stock_cfg(fam, "n"), scale="t", scales={"t": [0.5, width, 1024]})
+        p = Plan(cfg, 2, 96, 64)
+        m = R.Model(fam, "t", 80, "detect")
+        want = {n for n, _ in m.param_specs() if not n.endswith("dfl.conv.weight")}
+        used = set()
+        for r in p.wrecs.values():
+            if r.kind == "plain":
+                used |= {r.name + ".weight", r.name + ".bias"}
+            else:
+                for nm in ((r.name, r.post) if r.kind == "conv2" else (r.name,)):
+                    used |= {nm + ".conv.weight"} | {f"{nm}.bn.{s}" for s in ("weight", "bias", "running_mean", "running_var")}
+        assert used == want
+        sd = synth_state_dict(p, 3)
+        for n_, shape in m.param_specs():  # the synthetic parameters have the MODULE's shapes, not the padded ops'
+            if n_ in sd:
+                assert tuple(sd[n_].shape) == tuple(shape), (n_, tuple(sd[n_].shape), tuple(shape))
+        blob = pack_plan_weights(p, sd)
+        padded = 0
+        for o in p.ops:
+            if o["kind"] != L.OP_CONV:
+                continue
+            srcs = [t for t in (o["src0"], o.get("src1")) if t is not None]
+            dst = o["dst"]
+            if dst.cmap is None and all(t.cmap is None for t in srcs):
+                continue
+            padded += 1
+            r = p.wrecs[o["wkey"]]
+            k, cin, cout = o["ksize"], sum(t.C for t in srcs), dst.C
+            cp, kp = (cout + 127) // 128 * 128, (k * k * cin + 31) // 32 * 32
+            wp = torch.frombuffer(bytearray(blob[r.w_off:r.w_off + cp * kp * 2]), dtype=torch.float16).view(cp, kp).float()
+            bp = torch.frombuffer(bytearray(blob[r.b_off:r.b_off + cp * 4]), dtype=torch.float32)
+            if r.kind == "conv2":
+                (w0, b0), (w1, b1) = fold_conv_bn(sd, r.name), fold_conv_bn(sd, r.post)
+                wm, bm = torch.cat([w0, w1]), torch.cat([b0, b1])
+            else:
+                wm, bm = fold_conv_bn(sd, r.name)
+            rows = list(dst.cmap) if dst.cmap is not None else list(range(cout))
+            cols, base = [], 0
+            for t in srcs:
+                cols += [base + v if v >= 0 else -1 for v in (t.cmap if t.cmap is not None else range(t.C))]
+                base += t.real
+            assert wm.shape[0] == sum(v >= 0 for v in rows) and wm.shape[1] == base, (o["name"], tuple(wm.shape), base)
+            wk = wp[:cout, :k * k * cin].view(cout, k * k, cin)
+            for i, ri in enumerate(rows):
+                if ri < 0:
+                    assert torch.all(wk[i] == 0) and bp[i] == 0, o["name"]
+                    continue
+                assert abs(float(bp[i] - bm[ri])) < 1e-6
+                for j, cj in enumerate(cols):
+                    got = wk[i, :, j]
+                    if cj < 0:
+                        assert torch.all(got == 0), (o["name"], i, j)
+                    else:
+                        assert torch.equal(got, wm[ri, cj].reshape(-1).half().float()), (o["name"], i, j)
+        assert padded >= 3
+        for o in p.ops:  # pieces stay aligned
+            for key in ("src0", "src1", "dst", "res"):
+                t = o.get(key)
+                if t is not None and t.buf < L.BSY_EXT_BASE and not t.f32:
+                    assert t.coff % 8 == 0 and t.C % 8 == 0 or o["kind"] not in (L.OP_CONV, L.OP_BNECK), (o["name"], key, t)
+    finally:
+        R.SCALES[fam].pop("t", None)
+
+
+def test_plan_says_which_precisions_run_a_width():
+    """YOLO11 at a width multiple of 0.3125: C2PSA's attention heads are 40 / 80 channels wide (block.py:4253-4258), which the fp16 attention
+    kernel does not take -- the plan says so when it is built (plugin.graph_support relies on that), the fp32-storage modes build."""
+    cfg = dict(stock_cfg("yolo11", "n"), scale="t", scales={"t": [0.5, 0.3125, 1024]})
+    with pytest.raises(NotImplementedError, match="attention heads"):
+        Plan(cfg, 1, 64, 64)
+    Plan(cfg, 1, 64, 64, precision="fp32")
+    Plan(cfg, 1, 64, 64, precision="fp32x")
+    Plan(dict(cfg, scales={"t": [0.5, 0.1875, 1024]}), 1, 64, 64)  # 48 / 96: on the fp16 path
+
+
 def test_plan_rejects_unsupported_graphs():
     cfg = stock_cfg("yolo11", "n")
     cfg["backbone"] = list(cfg["backbone"])
