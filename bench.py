@@ -320,6 +320,8 @@ def main():
                     fam_bytes += B * 3 * o["H"] * o["W"] * (4 if f32 else 2)
                 else:
                     fam_bytes += B * o["H"] * o["W"] * t.C * (4 if t.f32 else 2) // (4 if t.up else 1)
+            if o["kind"] == L.OP_CHAIN:  # first conv's output where it is written, second conv's HBM K part, first conv's shortcut operand
+                fam_bytes += sum(B * o["H"] * o["W"] * t.C * 2 for t in o["box"] if t is not None)
             mode = o.get("out_f32", 0)  # 0 f16 map, 1 f32 map, 2 / 3 fused decoder: class rows / 4 box rows of y (f16)
             fam_bytes += B * o["OH"] * o["OW"] * ({2: o.get("cout", 0), 3: 4}.get(mode, o["dst"].C)) * (4 if (mode == 1 or f32) else 2)
         achieved = fam_flops / (fam_ms * 1e-3) / 1e12
@@ -367,7 +369,7 @@ def main():
                                    ("dense-conv family of the fp32 mode: every conv launch of one forward (conv32_mfma_kernel, v_mfma_f32_32x32x2_f32; "
                                     "peak = the fp32 matrix rate)") if f32 else
                                    ("dense-conv family: every MFMA conv launch of one forward (conv_mfma_kernel, conv3x3_patch_kernel, "
-                                    "conv1x1_persist_kernel and the fused stem / Bottleneck / C3k2 / DWConv+1x1 kernels)"),
+                                    "conv1x1_persist_kernel, the fused stem / Bottleneck / C3k2 / DWConv+1x1 kernels and the chained 1x1 pairs of chain1x1_kernel)"),
                          "launches_per_step": n_fam,
                          "flops_per_launch_avg": round(fam_flops / n_fam), "avg_launch_ms": round(fam_ms / n_fam, 5),
                          "family_ms_per_step": round(fam_ms, 4), "forward_ms_per_step_by_events": round(fwd_ms, 4),

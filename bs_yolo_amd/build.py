@@ -27,6 +27,7 @@ SOURCES = {
     "stem_fused.hip": [],
     "bneck_fused.hip": [],
     "c3k2_fused.hip": [],
+    "chain1x1.hip": [],
     "bsyolo_ops.hip": [],
     "pmsfa_fused.hip": [],
     "elementwise.hip": [],

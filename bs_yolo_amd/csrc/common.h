@@ -132,6 +132,33 @@ struct C3k2Args {
 bool c3k2_fused_supported(int Cin, int C, int C2);
 int launch_c3k2_fused(const C3k2Args& a, hipStream_t s);
 
+// Two chained 1x1 convs in one launch (chain1x1.hip): d2 = act2(W2 [h2 | keep(s1)] + b2) (+ r2), s1 = act1(W1 [a0 | a1] + b1) (+ r1);
+// s1 goes to d1 when set, its couts [keep0, keep0 + LC) stay in LDS as the LAST LC input channels of the second conv.
+struct ChainArgs {
+    const half_t *a0, *a1;     // stage-1 sources incl. channel offset (a1: second concat operand or nullptr)
+    int lda0, lda1, CA0, CA1;
+    const half_t* w1;          // packed [N1 pad 128][K1 pad 32]
+    const float* b1;
+    int N1, act1;
+    half_t* d1;                // stage-1 output view or nullptr
+    int ldd1;
+    const half_t* r1;          // shortcut operand of stage 1 or nullptr
+    int ldr1;
+    int keep0, LC;
+    const half_t* h2;          // stage-2 K part read from HBM (first CH2 input channels) or nullptr
+    int ldh2, CH2;
+    const half_t* w2;
+    const float* b2;
+    int N2, act2;
+    half_t* d2;
+    int ldd2;
+    const half_t* r2;
+    int ldr2;
+    long long M;               // pixels
+};
+bool chain_supported(int CA0, int CA1, int N1, int keep0, int LC, int CH2, int N2);
+int launch_chain(const ChainArgs& a, hipStream_t s);
+
 // ---- BS-YOLO-only modules (bsyolo_ops.hip) ----------------------------------------------------------------------------
 struct DwGenArgs {       // depthwise kh x kw, stride 1 / 2, "same" padding, + bias (+SiLU)
     const half_t* src;

@@ -476,6 +476,26 @@ int run_op(const bsy_plan* p, const bsy_op& op, Resolver& R, hipStream_t s, Conv
             if (!R.ok || op.src0.C != a.C || op.res.C != a.C) return BSY_ERR_ARG;
             return launch_pmsfa_tail(a, s);
         }
+        case BSY_OP_CHAIN: {
+            ChainArgs a;
+            memset(&a, 0, sizeof(a));
+            a.a0 = R.h(op.src0); a.a1 = R.h(op.src1);
+            a.lda0 = op.src0.ld; a.lda1 = op.src1.buf >= 0 ? op.src1.ld : 0;
+            a.CA0 = op.src0.C; a.CA1 = op.src1.buf >= 0 ? op.src1.C : 0;
+            a.w1 = (const half_t*)(wb + op.w_off); a.b1 = (const float*)(wb + op.b_off); a.N1 = op.heads; a.act1 = op.nl;
+            a.d1 = R.h(op.box[0]); a.ldd1 = op.box[0].buf >= 0 ? op.box[0].ld : 0;
+            a.r1 = R.h(op.box[2]); a.ldr1 = op.box[2].buf >= 0 ? op.box[2].ld : 0;
+            a.keep0 = op.key_dim; a.LC = op.mid_c;
+            a.h2 = R.h(op.box[1]); a.ldh2 = op.box[1].buf >= 0 ? op.box[1].ld : 0; a.CH2 = op.box[1].buf >= 0 ? op.box[1].C : 0;
+            a.w2 = (const half_t*)(wb + op.w2_off); a.b2 = (const float*)(wb + op.b2_off); a.N2 = op.dst.C; a.act2 = op.act;
+            a.d2 = R.h(op.dst); a.ldd2 = op.dst.ld;
+            a.r2 = R.h(op.res); a.ldr2 = op.res.buf >= 0 ? op.res.ld : 0;
+            a.M = (long long)op.B * op.H * op.W;
+            if (!R.ok) return BSY_ERR_ARG;
+            if (op.up0 || op.up1 || (op.box[0].buf >= 0 && op.box[0].C != a.N1) || (op.box[2].buf >= 0 && op.box[2].C != a.N1) || (op.res.buf >= 0 && op.res.C != a.N2))
+                BSY_FAIL(BSY_ERR_ARG, "chain: inconsistent views");
+            return launch_chain(a, s);
+        }
         case BSY_OP_COPY: {
             const half_t* src = R.h(op.src0);
             half_t* dst = R.h(op.dst);

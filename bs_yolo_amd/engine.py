@@ -27,7 +27,7 @@ class YoloEngine:
                  fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None, fuse_dwpw: Optional[bool] = None,
                  merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None, fuse_tail: Optional[bool] = None,
                  max_plans: Optional[int] = None, precision: str = "fp16", graph: Optional[bool] = None, graph_ring: int = 3,
-                 latency: Optional[bool] = None, fuse_pmsfa: Optional[bool] = None):
+                 latency: Optional[bool] = None, fuse_pmsfa: Optional[bool] = None, fuse_chain: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("bs_yolo_amd needs a ROCm GPU (there is no CPU fallback)")
         self.cfg = cfg
@@ -102,6 +102,7 @@ class YoloEngine:
         self.fuse_msca = fuse_msca
         self.fuse_tail = fuse_tail
         self.fuse_pmsfa = fuse_pmsfa
+        self.fuse_chain = fuse_chain
         self._packed = Plan(cfg, 1, 64, 64, **self._fuse_kw())
         blob = pack_plan_weights(self._packed, state_dict, bn_eps)
         self.weight_bytes = len(blob)
@@ -129,7 +130,7 @@ class YoloEngine:
         return dict(fuse_stem=self.fuse_stem, fuse_bneck=self.fuse_bneck, fuse_head=self.fuse_head, fuse_dwpw=self.fuse_dwpw,
                     merge_c3k=self.merge_c3k, fuse_msca=self.fuse_msca, fuse_tail=self.fuse_tail, precision=self.precision,
                     lanes=True if getattr(self, "graph", False) else None, latency=getattr(self, "latency", False),
-                    fuse_pmsfa=self.fuse_pmsfa)
+                    fuse_pmsfa=self.fuse_pmsfa, fuse_chain=self.fuse_chain)
 
     # -- plans --------------------------------------------------------------------------------------------------
     def plan_for(self, B: int, H: int, W: int, in_dtype: torch.dtype, out_dtype: torch.dtype):

@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ["BSY_LIB"]) if os.environ.get("BSY_LIB") else PKG / "
 
 BSY_F16, BSY_F32, BSY_U8 = 0, 1, 2
 BSY_EXT_BASE = 0x100000
-(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW, OP_MSCA_SPATIAL, OP_C3K2, OP_S2D, OP_PMSFA_TAIL) = range(21)
+(OP_CONV_FIRST, OP_CONV, OP_DWCONV, OP_SPPF_POOL, OP_ATTN, OP_DECODE, OP_RAW_NCHW, OP_NHWC2NCHW, OP_STEM, OP_BNECK, OP_DWCONV_G, OP_COPY, OP_GAP, OP_MSCA_MIX, OP_MUL, OP_ELA, OP_DWPW, OP_MSCA_SPATIAL, OP_C3K2, OP_S2D, OP_PMSFA_TAIL, OP_CHAIN) = range(22)
 
 SYMBOLS = [
     "bsy_engine_create", "bsy_engine_destroy", "bsy_engine_load_weights", "bsy_plan_create", "bsy_plan_create_arena", "bsy_engine_arena_bytes", "bsy_plan_set_tuning", "bsy_plan_destroy",

@@ -125,6 +125,18 @@ def c3k2_supported(cin: int, c: int, c2: int) -> bool:
     return (cin, c, c2) == (64, 32, 128)
 
 
+def chain_supported(ca0: int, ca1: int, n1: int, keep0: int, lc: int, ch2: int, n2: int) -> bool:
+    """Shapes csrc/chain1x1.hip takes (mirror of chain_supported there): whole 64-deep K-steps, whole 128-cout passes, a resident
+    tile of at most 256 channels inside stage 1's output."""
+    return (ca0 > 0 and ca0 % 64 == 0 and ca1 >= 0 and ca1 % 64 == 0 and n1 > 0 and n1 % 128 == 0 and n2 > 0 and n2 % 128 == 0
+            and 0 < lc <= 256 and lc % 64 == 0 and keep0 >= 0 and keep0 % 64 == 0 and keep0 + lc <= n1 and ch2 >= 0 and ch2 % 64 == 0)
+
+
+# pixels from which two chained 1x1 convs run as one launch (one 128-pixel tile per workgroup, every weight streamed once per tile: with
+# fewer tiles than CUs the two ordinary launches, which also tile along cout, are faster): 192 tiles
+CHAIN_MIN_PIXELS = 192 * 128
+
+
 def bneck_supported(c: int, ch: int) -> bool:
     """Widths csrc/bneck_fused.hip accepts (mirror of bsy_bottleneck_fused_supported)."""
     return (c, ch) in ((32, 16), (64, 32))
@@ -140,7 +152,7 @@ class Plan:
                  fuse_stem: Optional[bool] = None, fuse_bneck: Optional[bool] = None, fuse_head: Optional[bool] = None,
                  fuse_dwpw: Optional[bool] = None, merge_c3k: Optional[bool] = None, fuse_msca: Optional[bool] = None,
                  fuse_tail: Optional[bool] = None, precision: str = "fp16", lanes: Optional[bool] = None, latency: bool = False,
-                 fuse_pmsfa: Optional[bool] = None):
+                 fuse_pmsfa: Optional[bool] = None, fuse_chain: Optional[bool] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         # latency mode (round 4; fp16 path): long-K conv layers with few tiles per image run split-K (split_factors below)
         self.latency = bool(latency) and precision == "fp16"
@@ -151,7 +163,7 @@ class Plan:
         self.f32_mode = precision in ("fp32", "fp32x")
         self.split_f16 = precision == "fp32x"
         if self.f32_mode:
-            fuse_stem = fuse_bneck = fuse_head = fuse_dwpw = merge_c3k = fuse_msca = fuse_tail = fuse_pmsfa = False
+            fuse_stem = fuse_bneck = fuse_head = fuse_dwpw = merge_c3k = fuse_msca = fuse_tail = fuse_pmsfa = fuse_chain = False
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
         self.fuse_stem = (os.environ.get("BSY_FUSE_STEM", "1") != "0") if fuse_stem is None else bool(fuse_stem)
         self.fuse_bneck = (os.environ.get("BSY_FUSE_BNECK", "1") != "0") if fuse_bneck is None else bool(fuse_bneck)
@@ -164,6 +176,9 @@ class Plan:
         self.fuse_tail = (os.environ.get("BSY_FUSE_TAIL", "1") != "0") if fuse_tail is None else bool(fuse_tail)
         # PMSFA's depthwise 5x5 -> depthwise 7x7 -> 1x1 + shortcut as one launch (round 4, csrc/pmsfa_fused.hip)
         self.fuse_pmsfa = (os.environ.get("BSY_FUSE_PMSFA", "1") != "0") if fuse_pmsfa is None else bool(fuse_pmsfa)
+        # per-pixel chains of two 1x1 convs as one launch (round 4, csrc/chain1x1.hip): C3k2.cv1 -> C3k.cv1|cv2, C2PSA.cv1 -> qkv,
+        # C3k.cv3 -> C3k2.cv2, ffn[1] -> C2PSA.cv2; from CHAIN_MIN_PIXELS pixels
+        self.fuse_chain = (os.environ.get("BSY_FUSE_CHAIN", "1") != "0") if fuse_chain is None else bool(fuse_chain)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
@@ -846,6 +861,58 @@ class Plan:
         self.layer_out = outs
         self.meta.update(scale=scale, n_layers=len(layers), legacy=legacy)
         self._fuse_stem()
+        self._fuse_chains()
+
+    def _fuse_chains(self):
+        """Peephole: two consecutive 1x1 Conv launches A, B of which B reads (part of) A's output at the same pixel become one OP_CHAIN
+        launch (csrc/chain1x1.hip) -- the same bits, one launch, A's output (or the part B needs) handed over in LDS.
+        HEAD form: B's only source is a channel slice of A's output (C3k2.cv1 -> C3k.cv1|cv2; C2PSA.cv1 -> qkv): A's output is still
+        written.  TAIL form: A's output is the LAST channels of B's source view (C3k.cv3 -> C3k2.cv2; ffn[1] -> C2PSA.cv2): it is written
+        only if something else reads it."""
+        min_px = int(os.environ.get("BSY_CHAIN_MIN_PIXELS", CHAIN_MIN_PIXELS))  # (tests lower it to reach the kernel with small inputs)
+        if not self.fuse_chain or self.f32_mode or self.latency:
+            return
+
+        def plain(o):
+            if o["kind"] != L.OP_CONV or o["ksize"] != 1 or o["stride"] != 1 or o.get("out_f32", 0) or o.get("dst_scale", 1) != 1 or o.get("ksplit", 0):
+                return False
+            if o.get("lane", 0) != 0 or o["dst"].f32 or o["dst"].up or o["dst"].cmap is not None or o.get("cout", o["dst"].C) != o["dst"].C:
+                return False
+            w = self.wrecs[o["wkey"]]
+            if w.rows is not None or w.cols is not None or w.real_cout or w.real_cin:
+                return False
+            return all(t is None or (not t.up and not t.f32 and t.cmap is None) for t in (o["src0"], o.get("src1"), o.get("res")))
+
+        def overlaps(t, u):
+            return t is not None and t.buf == u.buf and t.coff < u.coff + u.C and u.coff < t.coff + t.C
+
+        i = 0
+        while i + 1 < len(self.ops):
+            a, b = self.ops[i], self.ops[i + 1]
+            i += 1
+            if not (plain(a) and plain(b)) or b.get("src1") is not None or self.B * a["OH"] * a["OW"] < min_px:
+                continue
+            ad, bs = a["dst"], b["src0"]
+            if bs.buf != ad.buf or bs.ld != ad.ld:
+                continue
+            ca0, ca1 = a["src0"].C, a["src1"].C if a.get("src1") is not None else 0
+            if a.get("res") is None and ad.coff <= bs.coff and bs.coff + bs.C <= ad.coff + ad.C:      # HEAD
+                keep0, lc, d1, h2 = bs.coff - ad.coff, bs.C, ad, None
+            elif ad.coff > bs.coff and ad.coff + ad.C == bs.coff + bs.C:                              # TAIL
+                keep0, lc, h2 = 0, ad.C, bs.slice(0, bs.C - ad.C)
+                readers = any(overlaps(o.get(k), ad) for o in self.ops[i + 1:] for k in self._VIEW_KEYS if k != "dst") or \
+                    any(overlaps(t, ad) for o in self.ops[i + 1:] for k in self._LIST_KEYS for t in (o.get(k) or []))
+                outs = [t for lo in self.layer_out if lo is not None for t in (lo if isinstance(lo, list) else [lo])]
+                d1 = ad if readers or any(overlaps(t, ad) for t in outs) else None
+            else:
+                continue
+            if not chain_supported(ca0, ca1, ad.C, keep0, lc, h2.C if h2 is not None else 0, b["dst"].C):
+                continue
+            self.ops[i - 1:i + 1] = [dict(kind=L.OP_CHAIN, H=a["H"], W=a["W"], OH=a["OH"], OW=a["OW"], src0=a["src0"], src1=a.get("src1"),
+                                          dst=b["dst"], res=b.get("res"), box=[d1, h2, a.get("res")], ksize=1, stride=1, pad=0, act=b["act"],
+                                          nl=a["act"], heads=ad.C, key_dim=keep0, mid_c=lc, wkey=a["wkey"], wkey2=b["wkey"],
+                                          name=a["name"] + "->" + b["name"].split(".", 2)[-1], lane=0,
+                                          mfma_flops=a["mfma_flops"] + b["mfma_flops"], chain=(a["name"], b["name"]))]
 
     def _fuse_stem(self):
         """Peephole: layer 0 (image conv) + layer 1 (3x3 s2 conv fed by layer 0 alone) -> one OP_STEM launch

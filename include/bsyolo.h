@@ -91,6 +91,12 @@ enum bsy_op_kind {
                             * [q1 | q2] = conv2(p1).  aux_off = (weights, bias) byte offsets of conv2 (f32 [25][heads]), conv3 (f32 [49][key_dim])
                             * and conv4 (packed 1x1); heads / key_dim = row lengths of the two depthwise weight tensors.  C in {32, 64, 128};
                             * the same bits as the three launches it replaces                                              */
+    BSY_OP_CHAIN = 21,     /* two 1x1 Conv modules chained per pixel as one launch (round 4, csrc/chain1x1.hip; nn/modules/conv.py:149-151 twice):
+                            * stage 1 = act(W1 [src0 | src1] + b1) (+ box[2] as shortcut operand), heads = its output channels, w_off / b_off;
+                            * box[0] = its HBM output view (buf < 0: not written: nobody else reads it); its channels [key_dim, key_dim + mid_c)
+                            * stay in LDS and are the LAST mid_c input channels of stage 2 = act2(W2 [box[1] | kept] + b2) (+ res) -> dst,
+                            * w2_off / b2_off, nl = 1 when stage 1 has SiLU, act = stage 2's.  C3k2.cv1 -> C3k.cv1|cv2, C2PSA.cv1 -> qkv,
+                            * C3k.cv3 -> C3k2.cv2, ffn[1] -> C2PSA.cv2 (block.py:3796-3815, :4429-4468); the same bits as the two launches    */
     BSY_OP_ELA = 15        /* ELA (nn/Addmodules/ELA.py:77-101): ksize = Conv1d taps; w_off -> f32 blob [spatial_conv C*k]
                             * [ch_att conv C*k][gn.weight C][gn.bias C]; scale, lvl_stride[0], lvl_stride[1] =
                             * sigmoid(ch_weight), sigmoid(sp_weight), sigmoid(res_weight);

@@ -1316,6 +1316,64 @@ def test_engine_stem_fusion_is_bit_identical(scale, monkeypatch):
     plain.close()
 
 
+@pytest.mark.parametrize("scale,shape", [("s", (3, 160, 224)), ("n", (2, 96, 160)), ("m", (1, 256, 192)), ("l", (1, 160, 160)), ("s", (5, 320, 320))])
+def test_engine_chain_fusion_is_bit_identical(scale, shape, monkeypatch):
+    """Two 1x1 convs chained per pixel as one launch (csrc/chain1x1.hip; C3k2.cv1 -> C3k.cv1|cv2, C2PSA.cv1 -> qkv, C3k.cv3 -> C3k2.cv2,
+    ffn[1] -> C2PSA.cv2, SPPF.cv2 -> C2PSA.cv1 and C3k -> C3k at the scales whose widths fit; block.py:3796-3815, :4429-4468) return
+    exactly what the two launches return -- the prediction, the raw maps and EVERY top-level layer output: 128- and 256-cout passes,
+    one- and two-operand first convs, resident tiles of 128 / 256 channels, the shortcut in the first epilogue (ffn[1]) and in the
+    second (ffn.0 -> ffn.1 at scale n), pixel counts that are not multiples of the 128-pixel tile (105 ... 1600 pixels)."""
+    monkeypatch.setenv("BSY_CHAIN_MIN_PIXELS", "1")
+    monkeypatch.setenv("BSY_ARENA_REUSE", "0")
+    m = R.Model("yolo11", scale, 80, "detect")
+    P = R.synth_params(m, 4)
+    cfg = stock_cfg("yolo11", scale)
+    fused = YoloEngine(cfg, P, fuse_chain=True, autotune=False)
+    plain = YoloEngine(cfg, P, fuse_chain=False, autotune=False)
+    B, H, W = shape
+    pf, hf = fused.plan_for(B, H, W, torch.float16, torch.float16)
+    pp, hp = plain.plan_for(B, H, W, torch.float16, torch.float16)
+    nchain = sum(o["kind"] == L.OP_CHAIN for o in pf.ops)
+    assert nchain >= {"n": 6, "s": 8, "m": 14, "l": 21}[scale] and len(pp.ops) - len(pf.ops) == nchain and not any(o["kind"] == L.OP_CHAIN for o in pp.ops)
+    assert sum(o.get("mfma_flops", 0) for o in pf.ops) == sum(o.get("mfma_flops", 0) for o in pp.ops)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W)).half().to(DEV)
+    yf, rf = fused(x)
+    yp, rp = plain(x)
+    torch.cuda.synchronize()
+    for i, (tf, tp) in enumerate(zip(pf.layer_out, pp.layer_out)):
+        if tf is None or isinstance(tf, list):
+            continue
+        assert torch.equal(fused.read_view(pf, hf, tf), plain.read_view(pp, hp, tp)), f"layer {i}"
+    assert torch.equal(yf, yp)
+    for a, b in zip(rf, rp):
+        assert torch.equal(a, b)
+    fused.close()
+    plain.close()
+
+
+def test_engine_chain_fusion_threshold_and_batch_independence():
+    """The chain launch is taken from plan.CHAIN_MIN_PIXELS pixels per layer on (one 128-pixel tile per workgroup: with fewer tiles than
+    CUs the two launches win); below it the plan keeps the two launches.  Both return the same bits, so a batch and its shards agree
+    whichever side of the threshold each falls on."""
+    from bs_yolo_amd.plan import CHAIN_MIN_PIXELS, Plan
+    cfg = stock_cfg("yolo11", "s")
+    big, small = Plan(cfg, 64, 640, 640), Plan(cfg, 8, 640, 640)
+    assert sum(o["kind"] == L.OP_CHAIN for o in big.ops) == 8
+    assert [o["name"] for o in small.ops if o["kind"] == L.OP_CHAIN] == []  # 8 x 40 x 40 = 12 800 pixels < CHAIN_MIN_PIXELS
+    assert CHAIN_MIN_PIXELS == 24576
+    m = R.Model("yolo11", "s", 80, "detect")
+    P = R.synth_params(m, 9)
+    eng = YoloEngine(cfg, P, autotune=False)
+    x = torch.rand(64, 3, 320, 320, generator=torch.Generator().manual_seed(5)).half().to(DEV)
+    y, _ = eng(x)          # 64 x 20 x 20 = 25 600 pixels at stride 16: chains there, none at stride 32
+    y8, _ = eng(x[8:16])   # no chain anywhere
+    p64, _ = eng.plan_for(64, 320, 320, torch.float16, torch.float16)
+    p8, _ = eng.plan_for(8, 320, 320, torch.float16, torch.float16)
+    assert sum(o["kind"] == L.OP_CHAIN for o in p64.ops) == 2 and not any(o["kind"] == L.OP_CHAIN for o in p8.ops)
+    assert torch.equal(y[8:16], y8)
+    eng.close()
+
+
 def test_engine_bsyolo_large_input_matches_oracle():
     """BS-YOLO11n on a 1024 x 1280 input (the golden graphs stop at 96 x 160): 128 x 160 ELA rows / columns, a 32 x 40 MSCA
     map through the one-launch spatial kernel, depthwise windows over 256 x 320 maps -- against the oracle with the engine's

@@ -110,6 +110,8 @@ def timing(scale="s", B=64, S=640, dt=torch.float16, family="yolo11", precision=
             if o.get("res"):
                 ins += outs
             by = ins + outs
+        if kind == L.OP_CHAIN:
+            fl = o["mfma_flops"]
         bykind[kind] = bykind.get(kind, 0.0) + t
         rows.append((t, name, kind, fl, by, o))
     print("time by kind (ms):", {k: round(v, 3) for k, v in bykind.items()})
@@ -121,6 +123,9 @@ def timing(scale="s", B=64, S=640, dt=torch.float16, family="yolo11", precision=
         if kind == L.OP_CONV:
             cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
             shape = f"{o['ksize']}x{o['ksize']}s{o['stride']} {cin:4d}->{o.get('cout', o['dst'].C):4d} @{o['OH']}x{o['OW']}"
+        if kind == L.OP_CHAIN:
+            cin = o["src0"].C + (o["src1"].C if o.get("src1") else 0)
+            shape = f"chain {cin}->{o['heads']}|{(o['box'][1].C if o['box'][1] else 0) + o['mid_c']}->{o['dst'].C} @{o['OH']}x{o['OW']}"
         print(f"  {t:8.4f} ms kind {kind} {name:26s} {shape:30s} {fl / t / 1e9 if t > 0 else 0:7.1f} TF/s {by / t / 1e6 if t > 0 else 0:8.1f} GB/s cfg {hex(tun.get(name, -1)) if name in tun else ''}")
     eng.close()
 

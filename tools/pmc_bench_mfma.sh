@@ -16,7 +16,7 @@ if NCONV <= 0:
     NCONV = int(json.loads(open(f"{R}/gpurun_out/pmc_bench_mfma.json").read().strip().splitlines()[-1])["roofline"]["launches_per_step"])
 f = sorted(glob.glob(f"{R}/gpurun_out/pmc_bench_mfma/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))
-CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")
+CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel", "chain1x1_kernel")
 disp = {}
 for r in rows:
     d = disp.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "t": int(r["Start_Timestamp"]), "dur": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})

@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = sorted(glob.glob(f"{R}/gpurun_out/pmc_bench_{c}/*/*counter_collection.csv"), key=os.path.getmtime)[-1]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")  # kernels behind the plan's OP_CONV ops
+    CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel", "chain1x1_kernel")  # kernels behind the plan's OP_CONV ops
     conv = [r for r in rows if any(k in r["Kernel_Name"] for k in CONV)]
     last = conv[-NCONV:]  # the last forward (bench's final profile pass)
     t0 = int(last[0]["Start_Timestamp"])

@@ -14,7 +14,7 @@ python3 - $R $TAG <<'PY' | tee $R/gpurun_out/${TAG}_tcc.txt
 import csv, glob, json, os, sys
 R, TAG = sys.argv[1], sys.argv[2]
 CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel",
-        "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")
+        "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel", "chain1x1_kernel")
 disp = {}
 n_fam = None
 for first in ("TCC_HIT_sum", "TCC_EA0_RDREQ_sum"):

@@ -14,7 +14,7 @@ from collections import defaultdict
 
 path, steps = sys.argv[1], int(sys.argv[2])
 per_step = int(sys.argv[3])
-CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel")
+CONV = ("conv_mfma_kernel", "conv1x1_persist_kernel", "conv1x1_wres_kernel", "conv3x3_patch_kernel", "stem_fused_kernel", "bneck_fused_kernel", "bneck_fused_wide_kernel", "c3k2_fused_kernel", "dwpw_fused_kernel", "conv_first_mfma_kernel", "chain1x1_kernel")
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 conv = [r for r in rows if any(k in r["Kernel_Name"] for k in CONV)]
