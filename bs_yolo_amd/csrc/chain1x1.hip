@@ -20,6 +20,8 @@
 // the ROUNDED value in f32 and rounded again (conv_mfma.hip conv_epilogue_lds): the same bits (tests/test_gpu_parity.py
 // test_engine_chain_fusion_is_bit_identical).
 // LDS: ring 2 x (128 + 256) x 64 halves = 96 KiB (staging tile aliases it between passes) + resident tile <= 256 ch x 128 px = 64 KiB.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct ChainK {
@@ -32,6 +34,7 @@ struct ChainK {
     unsigned wsp1;
     half_t* d1;                 // stage-1 output in HBM (null: resident tile only)
     int ldd1;
+    unsigned spd1, spd2;        // bytes addressable from d1 / d2 (stores go through descriptors)
     const half_t* r1;           // stage-1 shortcut operand (null: none)
     int ldr1;
     int keep0, LC;              // resident tile = stage-1 couts [keep0, keep0 + LC)
@@ -47,70 +50,123 @@ struct ChainK {
     const half_t* r2;
     int ldr2;
     int M;
+    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores
 };
 
 namespace {
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t ch_rsrc_t;
+typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ ch_rsrc_t ch_make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ void ch_dma16(ch_rsrc_t r, unsigned voff, unsigned soff, half_t* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
+// 16-byte store through a descriptor: ALWAYS issued (a lane whose voff is out of range stores nothing), so that every thread has the
+// same, compile-time number of stores in flight behind an epilogue -- the next pass's counted vmcnt wait relies on it
+__device__ __forceinline__ void ch_store16(ch_rsrc_t r, unsigned voff, const half8& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ch_u32x4, v), r, (int)voff, 0, 0);
+}
 #else
 typedef int ch_rsrc_t;
 __device__ __forceinline__ ch_rsrc_t ch_make_rsrc(const void*, unsigned) { return 0; }
 __device__ __forceinline__ void ch_dma16(ch_rsrc_t, unsigned, unsigned, half_t*) {}
+__device__ __forceinline__ void ch_store16(ch_rsrc_t, unsigned, const half8&) {}
 #endif
-constexpr unsigned CH_OOB = 0xFFFFFFF0u;  // out of range for every descriptor: the lane's 16 bytes land as zeros
+constexpr unsigned CH_OOB = 0xFFFFFFF0u;  // out of range for every descriptor: a load lands as zeros, a store is dropped
 constexpr int CH_P = 128, CH_BK = 64;
 constexpr int CH_PBLK = CH_P * CH_BK;            // one K-step of pixels: [128][64] halves, 16 KiB
 constexpr int CH_STAGE = (CH_P + 256) * CH_BK;   // ring stage: pixels + up to 256 weight rows
 constexpr int CH_RING = 2 * CH_STAGE;
 constexpr int CH_TILE = 4 * CH_PBLK;             // resident tile: up to 256 channels
 
-struct ChSeg {  // one HBM K segment of a pass
-    ch_rsrc_t rs;
-    unsigned off[2];  // per staged pixel row of this lane: byte offset of the row's first channel + this lane's swizzled chunk, or CH_OOB
-    int nsteps;
+// What a thread needs to stage any K-step of any pass: ONE continuous stream of K-steps runs through the two ring stages, across pass
+// boundaries (global step g lands in stage g & 1), so that the first K-step of a pass is fetched under the last K-step and the
+// epilogue of the pass before it.
+struct ChCtx {
+    ch_rsrc_t rsa0, rsa1, rsh2, rsw1, rsw2;
+    unsigned offa0[2], offa1[2], offh2[2];  // byte offset of this lane's two staged pixel rows (+ its swizzled 16-byte chunk) or CH_OOB
+    unsigned woff1[4], woff2[4];            // byte offset of this lane's staged weight rows (+ chunk) inside a pass's rows
+    int na0, na01, nh2, nl;                 // K-steps: stage 1 = a0 then a1; stage 2 = h2 then nl resident blocks
+    int np1, np2, w1, w2;                   // passes per stage and their width in 128-cout units (1 or 2)
+    unsigned k1pad, k2pad;
 };
 
-// K loop of one pass: acc[a][b] += W[cout0 + (wn NT + a) 32 ..][k] * B[k][wm 64 + b 32 ..] over seg0, seg1 (HBM, through the ring) and
-// then `nl` resident blocks starting at block lb0.
-template <int NT>
-__device__ __forceinline__ void chain_pass(half_t* smem, const ChSeg& s0, const ChSeg& s1, const int nl, const int lb0, const ch_rsrc_t rsw,
-                                           const unsigned kpad, const int cout0, f32x16 (&acc)[NT][2], const int wave, const int lane) {
-    constexpr int WIW = 2 * NT;  // weight DMA instructions per wave and K-step (128 NT rows, 8 rows each, 8 waves)
-    half_t* ring = smem;
-    const half_t* tile = smem + CH_RING;
-    const int rsub = lane >> 3, slot = lane & 7;
-    const int kc0 = slot ^ (rsub >> 1), kc1 = slot ^ (4 | (rsub >> 1));
-    const int wn = wave >> 1, wm = wave & 1, lrow = lane & 31, lh = lane >> 5;
-    unsigned woff[WIW];
+// LDS-DMA of K-step kt of pass pi into ring stage st
+__device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const int pi, const int kt, const int st, const int wave) {
+    half_t* sP = ring + st * CH_STAGE;
+    half_t* sW = sP + CH_PBLK;
+    if (pi < c.np1) {
+        const unsigned cout0 = 128u * (unsigned)(pi * c.w1);
+        if (kt < c.na0) {
 #pragma unroll
-    for (int j = 0; j < WIW; ++j) woff[j] = (unsigned)((wave * WIW + j) * 8 + rsub) * kpad * 2u + 16u * (unsigned)((j & 1) ? kc1 : kc0);
-    const int n0 = s0.nsteps, n01 = n0 + s1.nsteps, nk = n01 + nl;
-    auto issue = [&](const int kt, const int st) {
-        half_t* sP = ring + st * CH_STAGE;
-        half_t* sW = sP + CH_PBLK;
-        if (kt < n0) {
+            for (int i = 0; i < 2; ++i) ch_dma16(c.rsa0, c.offa0[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
+        } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ch_dma16(s0.rs, s0.off[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
-        } else if (kt < n01) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) ch_dma16(s1.rs, s1.off[i], 128u * (unsigned)(kt - n0), sP + (wave * 2 + i) * 512);
+            for (int i = 0; i < 2; ++i) ch_dma16(c.rsa1, c.offa1[i], 128u * (unsigned)(kt - c.na0), sP + (wave * 2 + i) * 512);
         }
+        const unsigned so = 2u * (cout0 * c.k1pad + 64u * (unsigned)kt);
+        if (c.w1 == 2) {
 #pragma unroll
-        for (int j = 0; j < WIW; ++j) ch_dma16(rsw, woff[j], 2u * ((unsigned)cout0 * kpad + 64u * (unsigned)kt), sW + (wave * WIW + j) * 512);
-    };
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // K-step kt landed for every wave; every wave is done reading the other stage
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const half_t* sP = kt < n01 ? ring + (kt & 1) * CH_STAGE : tile + (lb0 + kt - n01) * CH_PBLK;
-        const half_t* sW = ring + (kt & 1) * CH_STAGE + CH_PBLK;
+            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + (wave * 4 + j) * 512);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + (wave * 2 + j) * 512);
+        }
+    } else {
+        const unsigned cout0 = 128u * (unsigned)((pi - c.np1) * c.w2);
+        if (kt < c.nh2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ch_dma16(c.rsh2, c.offh2[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
+        }
+        const unsigned so = 2u * (cout0 * c.k2pad + 64u * (unsigned)kt);
+        if (c.w2 == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + (wave * 4 + j) * 512);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + (wave * 2 + j) * 512);
+        }
+    }
+}
+
+// One pass: K loop (acc += W[cout0 + (wn NT + a) 32 ..][k] * B[k][wm 64 + b 32 ..]) + epilogue.
+//   g    : global K-step counter (ring stage = g & 1); the DMA of this pass's first K-step is already in flight when the pass starts
+//   pend : 16-byte stores the previous epilogue left in flight per thread (issued AFTER that DMA: the first wait lets them fly on)
+// Epilogue: activation -> f16 (-> + shortcut operand, rounded again); STAGE1: the kept couts go to the resident tile; when `dst` is set
+// the pass's tile goes to HBM through a staging tile that aliases ONLY the ring stage this pass consumed last (the other stage is
+// receiving the next pass's first K-step), 64 pixel rows at a time, as coalesced 16-byte pieces.
+template <int NT, bool STAGE1>
+__device__ __forceinline__ void chain_pass(half_t* smem, const ChCtx& c, const ChainK& p, const int pi, const int cout0, int& g, int& pend,
+                                           const int m0, const int wave, const int lane, const int tid) {
+    half_t* ring = smem;
+    half_t* tile = smem + CH_RING;
+    const int wn = wave >> 1, wm = wave & 1, lrow = lane & 31, lh = lane >> 5;
+    const int n01 = STAGE1 ? c.na01 : c.nh2, nk = n01 + (STAGE1 ? 0 : c.nl);
+    const int npass = c.np1 + c.np2;
+    f32x16 acc[NT][2];
+    const float* bias = (STAGE1 ? p.b1 : p.b2) + cout0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc_bias(acc[a][b], bias + (wn * NT + a) * 32, lh);
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+        if (kt == 0) {  // this K-step's DMA is older than the previous epilogue's stores; its LDS writes (resident tile) must have landed too
+            if (pend == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (pend == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // K-step g landed for every wave; every wave is done with the other stage
+        if (!(p.dbg & 1)) {
+            if (kt + 1 < nk) chain_issue(ring, c, pi, kt + 1, (g + 1) & 1, wave);
+            else if (pi + 1 < npass) chain_issue(ring, c, pi + 1, 0, (g + 1) & 1, wave);
+        }
+        if (p.dbg & 2) continue;
+        const half_t* sP = kt < n01 ? ring + (g & 1) * CH_STAGE : tile + (kt - n01) * CH_PBLK;
+        const half_t* sW = ring + (g & 1) * CH_STAGE + CH_PBLK;
         half8 bfr[2][2], afr[2][NT];
         auto rd = [&](const int ks, const int buf) {
             const int chunk = 2 * ks + lh;
@@ -138,74 +194,75 @@ __device__ __forceinline__ void chain_pass(half_t* smem, const ChSeg& s0, const 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-}
-
-// Epilogue of one pass.  STAGE1: the kept couts go to the resident tile; either way the pass's tile goes to HBM through the staging tile
-// when `dst` is set.  Activation -> f16, then the shortcut operand added to the rounded value in f32 and rounded again.
-template <int NT, bool STAGE1>
-__device__ __forceinline__ void chain_epilogue(half_t* smem, f32x16 (&acc)[NT][2], const int act, half_t* dst, const int ldd, const half_t* res,
-                                               const int ldr, const int keep0, const int LC, const int cout0, const int m0, const int M,
-                                               const int wave, const int lane, const int tid) {
+    // ---- epilogue ----
     constexpr int NP = 128 * NT, LDT = NP + 8;
-    half_t* stage = smem;
-    half_t* tile = smem + CH_RING;
-    const int wn = wave >> 1, wm = wave & 1, lrow = lane & 31, lh = lane >> 5;
-    __syncthreads();  // every wave has left the K loop: the ring may become the staging tile
+    const int act = STAGE1 ? p.act1 : p.act2;
+    half_t* dst = STAGE1 ? p.d1 : p.d2;
+    const int ldd = STAGE1 ? p.ldd1 : p.ldd2;
+    half4 o[2][NT][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int prow = wm * 64 + b * 32 + lrow;
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
             const int cl = (wn * NT + a) * 32;
-            const int ck0 = cout0 + cl - keep0;
-            const bool keep = STAGE1 && ck0 >= 0 && ck0 < LC;  // wave-uniform (keep0, LC multiples of 64)
+            const int ck0 = cout0 + cl - p.keep0;
+            const bool keep = STAGE1 && ck0 >= 0 && ck0 < p.LC;  // wave-uniform (keep0, LC multiples of 64)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = cl + 8 * g + 4 * lh;
-                f32x4 t = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 t = f32x4{acc[a][b][4 * gq], acc[a][b][4 * gq + 1], acc[a][b][4 * gq + 2], acc[a][b][4 * gq + 3]};
                 if (act) t = silu4_f(t);
-                half4 o;
+                half4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)t[e];
-                if (STAGE1 && res && m0 + prow < M) {  // stage-1 shortcut: in registers (the resident tile must hold the sum)
-                    const half4 r = *reinterpret_cast<const half4*>(res + (size_t)(m0 + prow) * ldr + cout0 + c);
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)t[e];
+                if (STAGE1 && p.r1 && m0 + prow < p.M) {  // stage-1 shortcut: in registers (the resident tile must hold the sum)
+                    const half4 r = *reinterpret_cast<const half4*>(p.r1 + (size_t)(m0 + prow) * p.ldr1 + cout0 + cl + 8 * gq + 4 * lh);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)o[e] + (float)r[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = (half_t)((float)v[e] + (float)r[e]);
                 }
-                if (dst) *reinterpret_cast<half4*>(stage + prow * LDT + c) = o;
-                if (keep) {
-                    const int ck = ck0 + 8 * g + 4 * lh, cc = ck & 63;
-                    *reinterpret_cast<half4*>(tile + (ck >> 6) * CH_PBLK + prow * CH_BK + (((cc >> 3) ^ ((prow >> 1) & 7)) << 3) + (cc & 7)) = o;
+                o[b][a][gq] = v;
+                if (keep) {  // nobody reads the resident tile during stage 1
+                    const int ck = ck0 + 8 * gq + 4 * lh, cc = ck & 63;
+                    *reinterpret_cast<half4*>(tile + (ck >> 6) * CH_PBLK + prow * CH_BK + (((cc >> 3) ^ ((prow >> 1) & 7)) << 3) + (cc & 7)) = v;
                 }
             }
         }
     }
-    __syncthreads();
-    if (!dst) return;
-    constexpr int CPRW = NP / 8, ITER = CH_P * CPRW / 512;
+    pend = 0;
+    if (!dst || (p.dbg & 4)) return;
+    half_t* stage = ring + ((g - 1) & 1) * CH_STAGE;  // the stage of this pass's last K-step; 64 x LDT halves <= CH_STAGE
+    const ch_rsrc_t rsd = ch_make_rsrc(dst, STAGE1 ? p.spd1 : p.spd2);
+    const half_t* res = STAGE1 ? nullptr : p.r2;
+    constexpr int CPRW = NP / 8, ITERH = 64 * CPRW / 512;  // 16-byte pieces per row; pieces per thread and half (4 or 2)
+    __builtin_amdgcn_s_barrier();  // every wave has left the K loop (its fragment reads were consumed by its MFMAs)
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        const int id = tid + 512 * i;
-        const int row = id / CPRW, cc = (id % CPRW) * 8;
-        const int m = m0 + row;
-        if (m >= M) continue;
-        half8 v = *reinterpret_cast<const half8*>(stage + row * LDT + cc);
-        if (!STAGE1 && res) {
-            const half8 r = *reinterpret_cast<const half8*>(res + (size_t)m * ldr + cout0 + cc);
+    for (int h = 0; h < 2; ++h) {
+        if (wm == h) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r[e]);
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<half4*>(stage + (b * 32 + lrow) * LDT + (wn * NT + a) * 32 + 8 * gq + 4 * lh) = o[b][a][gq];
         }
-        *reinterpret_cast<half8*>(dst + (size_t)m * ldd + cout0 + cc) = v;
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < ITERH; ++i) {
+            const int id = tid + 512 * i;
+            const int row = id / CPRW, cc = (id % CPRW) * 8;
+            const int m = m0 + h * 64 + row;
+            half8 v = *reinterpret_cast<const half8*>(stage + row * LDT + cc);
+            if (res && m < p.M) {
+                const half8 r = *reinterpret_cast<const half8*>(res + (size_t)m * p.ldr2 + cout0 + cc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r[e]);
+            }
+            ch_store16(rsd, m < p.M ? 2u * ((unsigned)m * (unsigned)ldd + (unsigned)(cout0 + cc)) : CH_OOB, v);
+        }
+        lds_barrier();  // the staging rows have been read (lgkmcnt(0)): the other half, or the next DMA into this stage, may overwrite them
     }
-    __syncthreads();  // the staging tile has been read: the next pass's first DMA may overwrite the ring
-}
-
-template <int NT>
-__device__ __forceinline__ void chain_bias(f32x16 (&acc)[NT][2], const float* bias, const int cout0, const int wave, const int lane) {
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc_bias(acc[a][b], bias + cout0 + ((wave >> 1) * NT + a) * 32, lane >> 5);
+    pend = 2 * ITERH;
 }
 }  // namespace
 
@@ -216,53 +273,38 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainK p) {
     const int m0 = blockIdx.x * CH_P;
     const int rsub = lane >> 3, slot = lane & 7;
     const int kc[2] = {slot ^ (rsub >> 1), slot ^ (4 | (rsub >> 1))};
-    // byte offsets of this lane's two staged pixel rows in each HBM source
-    ChSeg sa0, sa1, sh2, none;
-    none.rs = ch_make_rsrc(p.a0, 0u); none.off[0] = none.off[1] = CH_OOB; none.nsteps = 0;
-    sa0.rs = ch_make_rsrc(p.a0, p.spa0); sa0.nsteps = p.CA0 >> 6;
-    sa1.rs = ch_make_rsrc(p.a1 ? p.a1 : p.a0, p.a1 ? p.spa1 : 0u); sa1.nsteps = p.a1 ? p.CA1 >> 6 : 0;
-    sh2.rs = ch_make_rsrc(p.h2 ? p.h2 : p.a0, p.h2 ? p.sph2 : 0u); sh2.nsteps = p.h2 ? p.CH2 >> 6 : 0;
+    ChCtx c;
+    c.rsa0 = ch_make_rsrc(p.a0, p.spa0);
+    c.rsa1 = ch_make_rsrc(p.a1 ? p.a1 : p.a0, p.a1 ? p.spa1 : 0u);
+    c.rsh2 = ch_make_rsrc(p.h2 ? p.h2 : p.a0, p.h2 ? p.sph2 : 0u);
+    c.rsw1 = ch_make_rsrc(p.w1, p.wsp1);
+    c.rsw2 = ch_make_rsrc(p.w2, p.wsp2);
+    c.na0 = p.CA0 >> 6; c.na01 = c.na0 + (p.a1 ? p.CA1 >> 6 : 0); c.nh2 = p.h2 ? p.CH2 >> 6 : 0; c.nl = p.LC >> 6;
+    c.w1 = (p.N1 & 255) ? 1 : 2; c.w2 = (p.N2 & 255) ? 1 : 2;
+    c.np1 = p.N1 / (128 * c.w1); c.np2 = p.N2 / (128 * c.w2);
+    c.k1pad = (unsigned)p.K1pad; c.k2pad = (unsigned)p.K2pad;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + (wave * 2 + i) * 8 + rsub;
         const bool v = m < p.M;
-        sa0.off[i] = v ? 2u * (unsigned)m * (unsigned)p.lda0 + 16u * (unsigned)kc[i] : CH_OOB;
-        sa1.off[i] = v ? 2u * (unsigned)m * (unsigned)p.lda1 + 16u * (unsigned)kc[i] : CH_OOB;
-        sh2.off[i] = v ? 2u * (unsigned)m * (unsigned)p.ldh2 + 16u * (unsigned)kc[i] : CH_OOB;
+        c.offa0[i] = v ? 2u * (unsigned)m * (unsigned)p.lda0 + 16u * (unsigned)kc[i] : CH_OOB;
+        c.offa1[i] = v ? 2u * (unsigned)m * (unsigned)p.lda1 + 16u * (unsigned)kc[i] : CH_OOB;
+        c.offh2[i] = v ? 2u * (unsigned)m * (unsigned)p.ldh2 + 16u * (unsigned)kc[i] : CH_OOB;
     }
-    const ch_rsrc_t rw1 = ch_make_rsrc(p.w1, p.wsp1), rw2 = ch_make_rsrc(p.w2, p.wsp2);
-    // ---- stage 1 ----
-    if (!(p.N1 & 255)) {
-        for (int c0 = 0; c0 < p.N1; c0 += 256) {
-            f32x16 acc[2][2];
-            chain_bias<2>(acc, p.b1, c0, wave, lane);
-            chain_pass<2>(smem, sa0, sa1, 0, 0, rw1, (unsigned)p.K1pad, c0, acc, wave, lane);
-            chain_epilogue<2, true>(smem, acc, p.act1, p.d1, p.ldd1, p.r1, p.ldr1, p.keep0, p.LC, c0, m0, p.M, wave, lane, tid);
-        }
-    } else {
-        for (int c0 = 0; c0 < p.N1; c0 += 128) {
-            f32x16 acc[1][2];
-            chain_bias<1>(acc, p.b1, c0, wave, lane);
-            chain_pass<1>(smem, sa0, sa1, 0, 0, rw1, (unsigned)p.K1pad, c0, acc, wave, lane);
-            chain_epilogue<1, true>(smem, acc, p.act1, p.d1, p.ldd1, p.r1, p.ldr1, p.keep0, p.LC, c0, m0, p.M, wave, lane, tid);
-        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // pass rows (wave WIW + j) 8 + rsub, WIW = 2 x pass width; j & 1 = parity of the 8-row group
+        c.woff1[j] = (unsigned)((wave * 2 * c.w1 + j) * 8 + rsub) * c.k1pad * 2u + 16u * (unsigned)kc[j & 1];
+        c.woff2[j] = (unsigned)((wave * 2 * c.w2 + j) * 8 + rsub) * c.k2pad * 2u + 16u * (unsigned)kc[j & 1];
     }
-    // ---- stage 2 ----
-    const int nl = p.LC >> 6;
-    if (!(p.N2 & 255)) {
-        for (int c0 = 0; c0 < p.N2; c0 += 256) {
-            f32x16 acc[2][2];
-            chain_bias<2>(acc, p.b2, c0, wave, lane);
-            chain_pass<2>(smem, sh2, none, nl, 0, rw2, (unsigned)p.K2pad, c0, acc, wave, lane);
-            chain_epilogue<2, false>(smem, acc, p.act2, p.d2, p.ldd2, p.r2, p.ldr2, 0, 0, c0, m0, p.M, wave, lane, tid);
-        }
-    } else {
-        for (int c0 = 0; c0 < p.N2; c0 += 128) {
-            f32x16 acc[1][2];
-            chain_bias<1>(acc, p.b2, c0, wave, lane);
-            chain_pass<1>(smem, sh2, none, nl, 0, rw2, (unsigned)p.K2pad, c0, acc, wave, lane);
-            chain_epilogue<1, false>(smem, acc, p.act2, p.d2, p.ldd2, p.r2, p.ldr2, 0, 0, c0, m0, p.M, wave, lane, tid);
-        }
+    int g = 0, pend = 0;
+    if (!(p.dbg & 1)) chain_issue(smem, c, 0, 0, 0, wave);
+    for (int pi = 0; pi < c.np1; ++pi) {
+        if (c.w1 == 2) chain_pass<2, true>(smem, c, p, pi, 256 * pi, g, pend, m0, wave, lane, tid);
+        else chain_pass<1, true>(smem, c, p, pi, 128 * pi, g, pend, m0, wave, lane, tid);
+    }
+    for (int pi = 0; pi < c.np2; ++pi) {
+        if (c.w2 == 2) chain_pass<2, false>(smem, c, p, c.np1 + pi, 256 * pi, g, pend, m0, wave, lane, tid);
+        else chain_pass<1, false>(smem, c, p, c.np1 + pi, 128 * pi, g, pend, m0, wave, lane, tid);
     }
 }
 
@@ -297,6 +339,11 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
     k.w2 = a.w2; k.b2 = a.b2; k.K2pad = round_up(k.CH2 + a.LC, 32); k.N2 = a.N2; k.act2 = a.act2;
     k.wsp2 = (unsigned)((long long)round_up(a.N2, 128) * k.K2pad * 2);
     k.d2 = a.d2; k.ldd2 = a.ldd2; k.r2 = a.r2; k.ldr2 = a.ldr2; k.M = (int)a.M;
+    k.spd1 = a.d1 ? (unsigned)(((a.M - 1) * a.ldd1 + a.N1) * 2) : 0u;
+    k.spd2 = (unsigned)(((a.M - 1) * a.ldd2 + a.N2) * 2);
+    if (a.M * (long long)(a.ldd1 > a.ldd2 ? a.ldd1 : a.ldd2) >= (1LL << 31)) BSY_FAIL(BSY_ERR_ARG, "chain: destination view exceeds 2^31 elements (split the batch)");
+    static const int dbg = [] { const char* e = getenv("BSY_CHAIN_DBG"); return e ? atoi(e) : 0; }();
+    k.dbg = dbg;
     const long long nblk = (a.M + CH_P - 1) / CH_P;
     hipLaunchKernelGGL(chain1x1_kernel, dim3((unsigned)nblk), dim3(512), 0, s, k);
     HIP_TRY(hipGetLastError());

@@ -177,8 +177,10 @@ class Plan:
         # PMSFA's depthwise 5x5 -> depthwise 7x7 -> 1x1 + shortcut as one launch (round 4, csrc/pmsfa_fused.hip)
         self.fuse_pmsfa = (os.environ.get("BSY_FUSE_PMSFA", "1") != "0") if fuse_pmsfa is None else bool(fuse_pmsfa)
         # per-pixel chains of two 1x1 convs as one launch (round 4, csrc/chain1x1.hip): C3k2.cv1 -> C3k.cv1|cv2, C2PSA.cv1 -> qkv,
-        # C3k.cv3 -> C3k2.cv2, ffn[1] -> C2PSA.cv2; from CHAIN_MIN_PIXELS pixels
-        self.fuse_chain = (os.environ.get("BSY_FUSE_CHAIN", "1") != "0") if fuse_chain is None else bool(fuse_chain)
+        # C3k.cv3 -> C3k2.cv2, ffn[1] -> C2PSA.cv2; from CHAIN_MIN_PIXELS pixels.  Bit-identical to the two launches and OFF by default:
+        # measured 10-25 % SLOWER than them on YOLO11s at 64 images (docs/experiments.md section 0.5: a 128-pixel tile streams every
+        # weight byte once per tile, 11.7 KB staged per MFLOP against 7.8 for the two launches' 256 x 256 tiles); BSY_FUSE_CHAIN=1 opts in
+        self.fuse_chain = (os.environ.get("BSY_FUSE_CHAIN", "0") == "1") if fuse_chain is None else bool(fuse_chain)
         self.buf_bytes: List[int] = []
         self.ops: List[dict] = []
         self.wrecs: "OrderedDict[str, WRec]" = OrderedDict()
