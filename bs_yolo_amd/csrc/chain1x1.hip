@@ -50,7 +50,7 @@ struct ChainK {
     const half_t* r2;
     int ldr2;
     int M;
-    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores
+    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA
 };
 
 namespace {
@@ -94,12 +94,13 @@ struct ChCtx {
 };
 
 // LDS-DMA of K-step kt of pass pi into ring stage st
-__device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const int pi, const int kt, const int st, const int wave) {
+__device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const int pi, const int kt, const int st, const int wave, const int dbg) {
     half_t* sP = ring + st * CH_STAGE;
     half_t* sW = sP + CH_PBLK;
     if (pi < c.np1) {
         const unsigned cout0 = 128u * (unsigned)(pi * c.w1);
-        if (kt < c.na0) {
+        if (dbg & 8) {
+        } else if (kt < c.na0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) ch_dma16(c.rsa0, c.offa0[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
         } else {
@@ -107,7 +108,8 @@ __device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const 
             for (int i = 0; i < 2; ++i) ch_dma16(c.rsa1, c.offa1[i], 128u * (unsigned)(kt - c.na0), sP + (wave * 2 + i) * 512);
         }
         const unsigned so = 2u * (cout0 * c.k1pad + 64u * (unsigned)kt);
-        if (c.w1 == 2) {
+        if (dbg & 16) {
+        } else if (c.w1 == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + (wave * 4 + j) * 512);
         } else {
@@ -116,12 +118,13 @@ __device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const 
         }
     } else {
         const unsigned cout0 = 128u * (unsigned)((pi - c.np1) * c.w2);
-        if (kt < c.nh2) {
+        if (kt < c.nh2 && !(dbg & 8)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) ch_dma16(c.rsh2, c.offh2[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
         }
         const unsigned so = 2u * (cout0 * c.k2pad + 64u * (unsigned)kt);
-        if (c.w2 == 2) {
+        if (dbg & 16) {
+        } else if (c.w2 == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + (wave * 4 + j) * 512);
         } else {
@@ -161,8 +164,8 @@ __device__ __forceinline__ void chain_pass(half_t* smem, const ChCtx& c, const C
         }
         __builtin_amdgcn_s_barrier();  // K-step g landed for every wave; every wave is done with the other stage
         if (!(p.dbg & 1)) {
-            if (kt + 1 < nk) chain_issue(ring, c, pi, kt + 1, (g + 1) & 1, wave);
-            else if (pi + 1 < npass) chain_issue(ring, c, pi + 1, 0, (g + 1) & 1, wave);
+            if (kt + 1 < nk) chain_issue(ring, c, pi, kt + 1, (g + 1) & 1, wave, p.dbg);
+            else if (pi + 1 < npass) chain_issue(ring, c, pi + 1, 0, (g + 1) & 1, wave, p.dbg);
         }
         if (p.dbg & 2) continue;
         const half_t* sP = kt < n01 ? ring + (g & 1) * CH_STAGE : tile + (kt - n01) * CH_PBLK;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainK p) {
         c.woff2[j] = (unsigned)((wave * 2 * c.w2 + j) * 8 + rsub) * c.k2pad * 2u + 16u * (unsigned)kc[j & 1];
     }
     int g = 0, pend = 0;
-    if (!(p.dbg & 1)) chain_issue(smem, c, 0, 0, 0, wave);
+    if (!(p.dbg & 1)) chain_issue(smem, c, 0, 0, 0, wave, p.dbg);
     for (int pi = 0; pi < c.np1; ++pi) {
         if (c.w1 == 2) chain_pass<2, true>(smem, c, p, pi, 256 * pi, g, pend, m0, wave, lane, tid);
         else chain_pass<1, true>(smem, c, p, pi, 128 * pi, g, pend, m0, wave, lane, tid);
