@@ -50,7 +50,7 @@ struct ChainK {
     const half_t* r2;
     int ldr2;
     int M;
-    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA
+    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA, 32 = weight addresses of a K-step-major layout [kt][cout][64] (timing only)
 };
 
 namespace {
@@ -107,7 +107,8 @@ __device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const 
 #pragma unroll
             for (int i = 0; i < 2; ++i) ch_dma16(c.rsa1, c.offa1[i], 128u * (unsigned)(kt - c.na0), sP + (wave * 2 + i) * 512);
         }
-        const unsigned so = 2u * (cout0 * c.k1pad + 64u * (unsigned)kt);
+        unsigned so = 2u * (cout0 * c.k1pad + 64u * (unsigned)kt);
+        if (dbg & 32) so = 128u * ((unsigned)kt * 128u * (unsigned)(c.np1 * c.w1) + cout0);  // K-step-major block [kt][cout][64] (timing experiment: wrong data)
         if (dbg & 16) {
         } else if (c.w1 == 2) {
 #pragma unroll
@@ -122,7 +123,8 @@ __device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const 
 #pragma unroll
             for (int i = 0; i < 2; ++i) ch_dma16(c.rsh2, c.offh2[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
         }
-        const unsigned so = 2u * (cout0 * c.k2pad + 64u * (unsigned)kt);
+        unsigned so = 2u * (cout0 * c.k2pad + 64u * (unsigned)kt);
+        if (dbg & 32) so = 128u * ((unsigned)kt * 128u * (unsigned)(c.np2 * c.w2) + cout0);
         if (dbg & 16) {
         } else if (c.w2 == 2) {
 #pragma unroll
@@ -296,8 +298,8 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainK p) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // pass rows (wave WIW + j) 8 + rsub, WIW = 2 x pass width; j & 1 = parity of the 8-row group
-        c.woff1[j] = (unsigned)((wave * 2 * c.w1 + j) * 8 + rsub) * c.k1pad * 2u + 16u * (unsigned)kc[j & 1];
-        c.woff2[j] = (unsigned)((wave * 2 * c.w2 + j) * 8 + rsub) * c.k2pad * 2u + 16u * (unsigned)kc[j & 1];
+        c.woff1[j] = (unsigned)((wave * 2 * c.w1 + j) * 8 + rsub) * ((p.dbg & 32) ? 64u : c.k1pad) * 2u + 16u * (unsigned)kc[j & 1];
+        c.woff2[j] = (unsigned)((wave * 2 * c.w2 + j) * 8 + rsub) * ((p.dbg & 32) ? 64u : c.k2pad) * 2u + 16u * (unsigned)kc[j & 1];
     }
     int g = 0, pend = 0;
     if (!(p.dbg & 1)) chain_issue(smem, c, 0, 0, 0, wave, p.dbg);
