@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--serial-nms", action="store_true",
                     help="run NMS (and the detection all-gather) on the forward's stream; default: on a second stream, so that "
                          "NMS of step i runs beside the forward of step i + 1 (every step's work still lies inside the timed region)")
+    ap.add_argument("--inflight", type=int, default=1, choices=[1, 2],
+                    help="forwards in flight: 2 = a second engine (its own activation arena) on a second stream takes every other step, so that step "
+                         "i + 1 runs beside step i (a pipelined server's two batches in flight); every step's work still lies inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-runs", type=int, default=20, help="CPU baseline sample: runs of --cpu-batch images (~10 s in all)")
@@ -217,11 +220,26 @@ def main():
     # graph mode returns outputs from a ring of preallocated tensors that a later replay overwrites: a consumer on another stream
     # could still be reading them -- NMS stays on the forward's stream there
     post = main if (args.serial_nms or use_graph) else torch.cuda.Stream(device=dev)
+    # --inflight 2: engines[1] is a second engine (same weights, its own arena and plans) on a stream of its own; steps alternate
+    engines, fstreams, nstep = [eng], [main], 0
+    if args.inflight == 2:
+        if use_graph or args.serial_nms:
+            sys.exit("--inflight 2 needs the eager forward and the NMS stream")
+        engines.append(YoloEngine(cfg, sd, device=local, precision=args.precision))
+        fstreams.append(torch.cuda.Stream(device=dev))
 
     def step():
-        nonlocal pending, gathered
-        y, _ = eng(x, want_raw=False)
-        if post is not main:
+        nonlocal pending, gathered, nstep
+        k = nstep % len(engines)
+        nstep += 1
+        if k:
+            with torch.cuda.stream(fstreams[k]):
+                y, _ = engines[k](x, want_raw=False)
+            y.record_stream(fstreams[k])
+            post.wait_stream(fstreams[k])
+        else:
+            y, _ = eng(x, want_raw=False)
+        if post is not main and not k:
             post.wait_stream(main)
         with torch.cuda.stream(post):
             det, counts = HN.nms_batched(y, 0.25, 0.7, max_det=300)
@@ -250,7 +268,11 @@ def main():
         # Parity of the benchmarked path, so that the headline number travels with its tolerance (north-star: 1e-3 on scores, 1e-3 * imgsz on
         # boxes against the CPU reference).  With the cpu_baseline leg: against the oracle's own outputs on that leg's sample; always:
         # against the engine's exact fp32 mode on 8 of the benchmark's images (that mode is pinned to the reference at ~1e-5 by the tests).
-        parity = {"tolerance_claimed": "1e-3 scores, 1e-3 * imgsz boxes" if f32 else "fp16 storage: score max < 1e-2 / p99.9 < 5e-3, box max < 16 px / p99.9 < 4 px (NOT 1e-3)"}
+        parity = {"tolerance_claimed": "1e-3 scores, 1e-3 * imgsz boxes" if f32 else
+                  ("fp16 storage, BS-YOLO graph with synthetic weights: mean score error < 1e-3, mean box error < 0.2 px; no max / p99.9 bound "
+                   "(the graph amplifies f16 storage rounding on flat DFL distributions: the CPU oracle with f16 storage emulation shows the same "
+                   "tails, tests/test_gpu_parity.py test_engine_bsyolo_large_input_matches_oracle)") if args.family == "bsyolo11" else
+                  "fp16 storage: score max < 1e-2 / p99.9 < 5e-3, box max < 16 px / p99.9 < 4 px (NOT 1e-3)"}
         nb = min(8, B)
         xs = x[:nb]
         y_path = eng(xs, want_raw=False)[0].float()
@@ -353,7 +375,8 @@ def main():
                                    + ", seeded random weights, engine forward + HIP NMS (conf 0.25, iou 0.7, max_det 300)"
                                    + ((" + RCCL all-gather of detections" if backend == "nccl" else f" + {backend} all-gather of detections (rehearsal backend, not RCCL)") if use_dist else ""),
                        "global_batch": global_batch, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",
-                       "pipeline": "NMS on the forward's stream" if args.serial_nms else "NMS of step i on a second stream beside the forward of step i + 1",
+                       "pipeline": ("NMS on the forward's stream" if args.serial_nms else "NMS of step i on a second stream beside the forward of step i + 1")
+                                   + (", two forwards in flight (two engines with their own activation arenas on two streams take alternate steps)" if args.inflight == 2 else ""),
                        "forward_launch": ("one captured hipGraph launch per forward (%d captured, %d replayed)" % (eng.graph_stats["captures"], eng.graph_stats["replays"]))
                                          if use_graph else "eager: one launch per op",
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 1),
@@ -390,6 +413,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    for e in engines[1:]:
+        e.close()
     eng.close()
 
 
