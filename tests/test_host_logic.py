@@ -47,6 +47,68 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert L.lib.bsy_nms_workspace_bytes(2, 8400, 80, 1, 30000) >= 2 * (1 << 20) * 8
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/bsyolo.h compiles as strict C99 (no C++ in the signatures), and a C translation unit that
+    names every declared entry point links against the shared library (no GPU call is made)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    hdr = ROOT / "include" / "bsyolo.h"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", str(hdr)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    names = sorted(set(re.findall(r"\b(bsy_[a-z0-9_]+)\s*\(", hdr.read_text())))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "bsyolo.h"\n#include <stdio.h>\nint main(void) {\n  const void* f[] = {' + ", ".join(f"(const void*)(size_t){n}" for n in names) +
+                   '};\n  printf("%d %d %d\\n", (int)(sizeof(f) / sizeof(f[0])), bsy_version(), bsy_sizeof_op());\n  return 0;\n}\n')
+    exe = tmp_path / "abi"
+    r = subprocess.run([gcc, "-std=c99", "-I", str(hdr.parent), str(src), "-o", str(exe), str(L.LIB_PATH), f"-Wl,-rpath,{L.LIB_PATH.parent}",
+                        "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n, ver, sz = map(int, r.stdout.split())
+    import ctypes as C
+    assert n == len(names) == len(L.SYMBOLS) and ver >= 1 and sz == C.sizeof(L.Op)
+
+
+def test_chain_fusion_peephole():
+    """plan.py _fuse_chains (opt-in, csrc/chain1x1.hip): two consecutive 1x1 Conv launches of which the second reads (part of) the first's
+    output at the same pixel become ONE OP_CHAIN op: C3k2.cv1 -> C3k.cv1|cv2 and C2PSA.cv1 -> qkv (HEAD form: a channel slice of the first
+    output; it is still written), C3k.cv3 -> C3k2.cv2 and ffn[1] -> C2PSA.cv2 (TAIL form: the first output is the LAST channels of the
+    second's source and is no longer written).  Same weights records, same work, fewer ops; nothing below plan.CHAIN_MIN_PIXELS; off by default."""
+    from bs_yolo_amd.plan import CHAIN_MIN_PIXELS, chain_supported
+    cfg = stock_cfg("yolo11", "s")
+    a, b = Plan(cfg, 64, 640, 640, fuse_chain=False), Plan(cfg, 64, 640, 640, fuse_chain=True)
+    assert not any(o["kind"] == L.OP_CHAIN for o in Plan(cfg, 64, 640, 640).ops)
+    ch = [o for o in b.ops if o["kind"] == L.OP_CHAIN]
+    assert [o["name"] for o in ch] == ["model.6.cv1->m.0.cv1", "model.6.m.0.cv3->cv2", "model.8.cv1->m.0.cv1", "model.8.m.0.cv3->cv2",
+                                       "model.10.cv1->m.0.attn.qkv", "model.10.m.0.ffn.1->cv2", "model.22.cv1->m.0.cv1", "model.22.m.0.cv3->cv2"]
+    assert len(a.ops) - len(b.ops) == 8 and list(a.wrecs) == list(b.wrecs)
+    assert sum(o.get("mfma_flops", 0) for o in a.ops) == sum(o.get("mfma_flops", 0) for o in b.ops) and a.flops == b.flops
+    for o in ch:
+        d1, h2, r1 = o["box"]
+        n1, keep0, lc = o["heads"], o["key_dim"], o["mid_c"]
+        ca1 = o["src1"].C if o["src1"] is not None else 0
+        assert chain_supported(o["src0"].C, ca1, n1, keep0, lc, h2.C if h2 is not None else 0, o["dst"].C)
+        if h2 is None:   # HEAD: the first conv's output is written, the second reads its channels [keep0, keep0 + lc)
+            assert d1 is not None and d1.C == n1 and keep0 + lc <= n1 and r1 is None
+        else:            # TAIL: [h2 | kept] is the second conv's source view; the first output stays on chip
+            assert d1 is None and keep0 == 0 and lc == n1 and h2.C % 64 == 0
+        assert set(b.op_buffers(o)) >= {t.buf for t in (o["src0"], o["dst"]) if t.buf < L.BSY_EXT_BASE}
+    assert ch[5]["box"][2] is not None and ch[5]["nl"] == 0 and ch[5]["act"] == 1    # ffn[1]: no activation, shortcut operand in the first epilogue
+    assert ch[4]["act"] == 0 and ch[4]["nl"] == 1                                    # qkv: a bare conv behind cv1's SiLU
+    offs, top = b.assign_offsets()
+    assert top > 0 and len(offs) == len(b.buf_bytes)
+    small = Plan(cfg, 8, 640, 640, fuse_chain=True)     # 8 x 40 x 40 = 12 800 pixels < CHAIN_MIN_PIXELS: the two launches stay
+    assert CHAIN_MIN_PIXELS == 24576 and not any(o["kind"] == L.OP_CHAIN for o in small.ops)
+    assert not any(o["kind"] == L.OP_CHAIN for o in Plan(cfg, 64, 640, 640, fuse_chain=True, precision="fp32x").ops)
+    for sc, n in (("n", 6), ("m", 14), ("l", 21), ("x", 0)):  # x: 384-channel chunks exceed the 256-channel resident tile
+        assert sum(o["kind"] == L.OP_CHAIN for o in Plan(stock_cfg("yolo11", sc), 64, 640, 640, fuse_chain=True).ops) == n
+    assert L.OP_CHAIN == 21
+
+
 def test_op_struct_layout():
     import ctypes as C
     # mirrors include/bsyolo.h: the two int64 offsets sit on an 8-byte boundary after 32 int32 fields
