@@ -158,6 +158,10 @@ CONV32X_CASES = CONV32_CASES + [
     (2, 160, 160, 16, 32, 3, 1, True, True, 0),      # patch kernel: ONE 16-channel chunk (model.2.m.0.cv2 of YOLO11s)
     (3, 20, 20, 128, 128, 3, 1, True, True, 0),      # patch kernel, 6 x 20 tiles (W % 20 == 0): 4 tile rows, the last with 2 of 6 rows inside
     (2, 17, 40, 64, 48, 3, 1, True, False, 0),       # 6 x 20 tiles on a 40-wide map, ragged height, ragged couts
+    (2, 64, 96, 32, 64, 3, 2, True, False, 0),       # stride 2, 64 couts: model.1's shape class
+    (2, 80, 80, 128, 128, 3, 2, True, False, 0),     # stride 2, 128 couts: model.3 / model.17
+    (3, 37, 21, 48, 96, 3, 2, True, True, 8),        # stride 2 on an odd map (19 x 11 outputs), ragged couts, shortcut, padded rows
+    (1, 16, 16, 16, 40, 3, 2, False, False, 0),      # stride 2, one 16-channel K piece, no activation, 40 couts
 ]
 
 
