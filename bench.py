@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--serial-nms", action="store_true",
                     help="run NMS (and the detection all-gather) on the forward's stream; default: on a second stream, so that "
                          "NMS of step i runs beside the forward of step i + 1 (every step's work still lies inside the timed region)")
+    ap.add_argument("--latency", default="auto", choices=["auto", "on", "off"],
+                    help="the engine's latency mode (split-K by layer shape on the long thin conv layers: deterministic, shard-invariant; DESIGN.md "
+                         "section 6).  auto: on when --scaling strong leaves this rank 16 images or fewer")
     ap.add_argument("--inflight", type=int, default=1, choices=[1, 2],
                     help="forwards in flight: 2 = a second engine (its own activation arena) on a second stream takes every other step, so that step "
                          "i + 1 runs beside step i (a pipelined server's two batches in flight); every step's work still lies inside the timed region")
@@ -187,7 +190,8 @@ def main():
     else:
         B, global_batch = args.batch, world * args.batch
     use_graph = args.graph == "on"
-    eng = YoloEngine(cfg, sd, device=local, precision=args.precision, graph=use_graph)
+    use_latency = args.precision == "fp16" and (args.latency == "on" or (args.latency == "auto" and args.scaling == "strong" and B <= 16))
+    eng = YoloEngine(cfg, sd, device=local, precision=args.precision, graph=use_graph, latency=use_latency)
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(B, 3, S, S, generator=g).to(torch.float32 if f32 else torch.float16).to(dev)
     if not (args.family == "yolo11" and args.scale == "s"):
@@ -205,7 +209,7 @@ def main():
             elif ".cv3." in k and k.endswith(".2.bias"):
                 sd[k] = torch.full_like(sd[k], math.log(0.25 / 0.75) - q)
         eng.close()
-        eng = YoloEngine(cfg, sd, device=local, precision=args.precision, graph=use_graph)
+        eng = YoloEngine(cfg, sd, device=local, precision=args.precision, graph=use_graph, latency=use_latency)
     from bs_yolo_amd.parallel import gather_detections_async
     pending = None   # the previous step's detection all-gather, in flight on RCCL's stream
     gathered = None
@@ -225,7 +229,7 @@ def main():
     if args.inflight == 2:
         if use_graph or args.serial_nms:
             sys.exit("--inflight 2 needs the eager forward and the NMS stream")
-        engines.append(YoloEngine(cfg, sd, device=local, precision=args.precision))
+        engines.append(YoloEngine(cfg, sd, device=local, precision=args.precision, latency=use_latency))
         fstreams.append(torch.cuda.Stream(device=dev))
 
     def step():
@@ -377,6 +381,7 @@ def main():
                        "global_batch": global_batch, "imgsz": S, "parallelism": f"images sharded over {world} GPU(s)",
                        "pipeline": ("NMS on the forward's stream" if args.serial_nms else "NMS of step i on a second stream beside the forward of step i + 1")
                                    + (", two forwards in flight (two engines with their own activation arenas on two streams take alternate steps)" if args.inflight == 2 else ""),
+                       "latency_mode": bool(use_latency),
                        "forward_launch": ("one captured hipGraph launch per forward (%d captured, %d replayed)" % (eng.graph_stats["captures"], eng.graph_stats["replays"]))
                                          if use_graph else "eager: one launch per op",
                        "mean_detections_per_image": round(float(counts.float().mean().item()), 1),
