@@ -50,7 +50,7 @@ struct ChainK {
     const half_t* r2;
     int ldr2;
     int M;
-    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA, 32 = weight addresses of a K-step-major layout [kt][cout][64] (timing only)
+    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA, 32 = weight addresses of a K-step-major layout [kt][cout][64] (timing only), 64 = weights global -> registers -> LDS instead of LDS-DMA, 128 = per-workgroup rotation of the weight row-group order (results stay right)
 };
 
 namespace {
@@ -68,8 +68,12 @@ __device__ __forceinline__ void ch_dma16(ch_rsrc_t r, unsigned voff, unsigned so
 __device__ __forceinline__ void ch_store16(ch_rsrc_t r, unsigned voff, const half8& v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ch_u32x4, v), r, (int)voff, 0, 0);
 }
+__device__ __forceinline__ half8 ch_load16(ch_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 #else
 typedef int ch_rsrc_t;
+__device__ __forceinline__ half8 ch_load16(ch_rsrc_t, unsigned, unsigned) { return half8{0, 0, 0, 0, 0, 0, 0, 0}; }
 __device__ __forceinline__ ch_rsrc_t ch_make_rsrc(const void*, unsigned) { return 0; }
 __device__ __forceinline__ void ch_dma16(ch_rsrc_t, unsigned, unsigned, half_t*) {}
 __device__ __forceinline__ void ch_store16(ch_rsrc_t, unsigned, const half8&) {}
@@ -88,6 +92,7 @@ struct ChCtx {
     ch_rsrc_t rsa0, rsa1, rsh2, rsw1, rsw2;
     unsigned offa0[2], offa1[2], offh2[2];  // byte offset of this lane's two staged pixel rows (+ its swizzled 16-byte chunk) or CH_OOB
     unsigned woff1[4], woff2[4];            // byte offset of this lane's staged weight rows (+ chunk) inside a pass's rows
+    int wq1[4], wq2[4];                     // which 8-row group of the pass each of this wave's weight DMA instructions fetches
     int na0, na01, nh2, nl;                 // K-steps: stage 1 = a0 then a1; stage 2 = h2 then nl resident blocks
     int np1, np2, w1, w2;                   // passes per stage and their width in 128-cout units (1 or 2)
     unsigned k1pad, k2pad;
@@ -112,10 +117,10 @@ __device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const 
         if (dbg & 16) {
         } else if (c.w1 == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + (wave * 4 + j) * 512);
+            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + c.wq1[j] * 512);
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + (wave * 2 + j) * 512);
+            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + c.wq1[j] * 512);
         }
     } else {
         const unsigned cout0 = 128u * (unsigned)((pi - c.np1) * c.w2);
@@ -128,10 +133,10 @@ __device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const 
         if (dbg & 16) {
         } else if (c.w2 == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + (wave * 4 + j) * 512);
+            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + c.wq2[j] * 512);
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + (wave * 2 + j) * 512);
+            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + c.wq2[j] * 512);
         }
     }
 }
@@ -165,11 +170,24 @@ __device__ __forceinline__ void chain_pass(half_t* smem, const ChCtx& c, const C
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // K-step g landed for every wave; every wave is done with the other stage
+        half8 wreg[4];
+        const bool wr = (p.dbg & 64) && kt + 1 < nk;  // timing experiment: the next K-step's weights global -> registers -> LDS instead of LDS-DMA
         if (!(p.dbg & 1)) {
-            if (kt + 1 < nk) chain_issue(ring, c, pi, kt + 1, (g + 1) & 1, wave, p.dbg);
+            if (kt + 1 < nk) chain_issue(ring, c, pi, kt + 1, (g + 1) & 1, wave, wr ? (p.dbg | 16) : p.dbg);
             else if (pi + 1 < npass) chain_issue(ring, c, pi + 1, 0, (g + 1) & 1, wave, p.dbg);
+            if (wr) {
+                const unsigned so = 2u * ((unsigned)cout0 * (STAGE1 ? c.k1pad : c.k2pad) + 64u * (unsigned)(kt + 1));
+#pragma unroll
+                for (int j = 0; j < 2 * NT; ++j) wreg[j] = ch_load16(STAGE1 ? c.rsw1 : c.rsw2, STAGE1 ? c.woff1[j] : c.woff2[j], so);
+            }
         }
-        if (p.dbg & 2) continue;
+        if (p.dbg & 2) {
+            if (wr) {
+#pragma unroll
+                for (int j = 0; j < 2 * NT; ++j) *reinterpret_cast<half8*>(ring + ((g + 1) & 1) * CH_STAGE + CH_PBLK + (STAGE1 ? c.wq1[j] : c.wq2[j]) * 512 + lane * 8) = wreg[j];
+            }
+            continue;
+        }
         const half_t* sP = kt < n01 ? ring + (g & 1) * CH_STAGE : tile + (kt - n01) * CH_PBLK;
         const half_t* sW = ring + (g & 1) * CH_STAGE + CH_PBLK;
         half8 bfr[2][2], afr[2][NT];
@@ -197,6 +215,10 @@ __device__ __forceinline__ void chain_pass(half_t* smem, const ChCtx& c, const C
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks & 1][a], bfr[ks & 1][b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wr) {
+#pragma unroll
+            for (int j = 0; j < 2 * NT; ++j) *reinterpret_cast<half8*>(ring + ((g + 1) & 1) * CH_STAGE + CH_PBLK + (STAGE1 ? c.wq1[j] : c.wq2[j]) * 512 + lane * 8) = wreg[j];
         }
     }
     // ---- epilogue ----
@@ -297,9 +319,16 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainK p) {
         c.offh2[i] = v ? 2u * (unsigned)m * (unsigned)p.ldh2 + 16u * (unsigned)kc[i] : CH_OOB;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {  // pass rows (wave WIW + j) 8 + rsub, WIW = 2 x pass width; j & 1 = parity of the 8-row group
-        c.woff1[j] = (unsigned)((wave * 2 * c.w1 + j) * 8 + rsub) * ((p.dbg & 32) ? 64u : c.k1pad) * 2u + 16u * (unsigned)kc[j & 1];
-        c.woff2[j] = (unsigned)((wave * 2 * c.w2 + j) * 8 + rsub) * ((p.dbg & 32) ? 64u : c.k2pad) * 2u + 16u * (unsigned)kc[j & 1];
+    // 8-row group q of a pass (16 x width groups) is fetched by instruction j of wave (q - rot) / WIW: rot rotates the assignment per
+    // workgroup (dbg & 128), so that the CUs of an XCD -- which all want the same weight lines in the same K-step -- ask for them in
+    // different orders.  q & 1 = parity of the group (the swizzle's odd / even instruction form).
+    const int rot = (p.dbg & 128) ? (int)((blockIdx.x >> 3) * 5u) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q1 = (wave * 2 * c.w1 + j + rot) % (16 * c.w1), q2 = (wave * 2 * c.w2 + j + rot) % (16 * c.w2);
+        c.wq1[j] = q1; c.wq2[j] = q2;
+        c.woff1[j] = (unsigned)(q1 * 8 + rsub) * ((p.dbg & 32) ? 64u : c.k1pad) * 2u + 16u * (unsigned)kc[q1 & 1];
+        c.woff2[j] = (unsigned)(q2 * 8 + rsub) * ((p.dbg & 32) ? 64u : c.k2pad) * 2u + 16u * (unsigned)kc[q2 & 1];
     }
     int g = 0, pend = 0;
     if (!(p.dbg & 1)) chain_issue(smem, c, 0, 0, 0, wave, p.dbg);
