@@ -50,7 +50,7 @@ struct ChainK {
     const half_t* r2;
     int ldr2;
     int M;
-    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA, 32 = weight addresses of a K-step-major layout [kt][cout][64] (timing only), 64 = weights global -> registers -> LDS instead of LDS-DMA, 128 = per-workgroup rotation of the weight row-group order (results stay right)
+    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA, 32 = weight addresses of a K-step-major layout [kt][cout][64] (timing only), 64 = weights global -> registers -> LDS instead of LDS-DMA, 128 = per-workgroup rotation of the weight row-group order (results stay right), 256 = the next K-step's DMA issued between this step's MFMA groups (results stay right)
 };
 
 namespace {
@@ -99,7 +99,8 @@ struct ChCtx {
 };
 
 // LDS-DMA of K-step kt of pass pi into ring stage st
-__device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const int pi, const int kt, const int st, const int wave, const int dbg) {
+// part < 0: the whole K-step; part = 0..3: the slice issued behind MFMA sub-step `part` (interleaved form: one pixel piece and one weight piece)
+__device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const int pi, const int kt, const int st, const int wave, const int dbg, const int part = -1) {
     half_t* sP = ring + st * CH_STAGE;
     half_t* sW = sP + CH_PBLK;
     if (pi < c.np1) {
@@ -107,36 +108,36 @@ __device__ __forceinline__ void chain_issue(half_t* ring, const ChCtx& c, const 
         if (dbg & 8) {
         } else if (kt < c.na0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ch_dma16(c.rsa0, c.offa0[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
+            for (int i = 0; i < 2; ++i) if (part < 0 || part == i) ch_dma16(c.rsa0, c.offa0[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ch_dma16(c.rsa1, c.offa1[i], 128u * (unsigned)(kt - c.na0), sP + (wave * 2 + i) * 512);
+            for (int i = 0; i < 2; ++i) if (part < 0 || part == i) ch_dma16(c.rsa1, c.offa1[i], 128u * (unsigned)(kt - c.na0), sP + (wave * 2 + i) * 512);
         }
         unsigned so = 2u * (cout0 * c.k1pad + 64u * (unsigned)kt);
         if (dbg & 32) so = 128u * ((unsigned)kt * 128u * (unsigned)(c.np1 * c.w1) + cout0);  // K-step-major block [kt][cout][64] (timing experiment: wrong data)
         if (dbg & 16) {
         } else if (c.w1 == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + c.wq1[j] * 512);
+            for (int j = 0; j < 4; ++j) if (part < 0 || part == j) ch_dma16(c.rsw1, c.woff1[j], so, sW + c.wq1[j] * 512);
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw1, c.woff1[j], so, sW + c.wq1[j] * 512);
+            for (int j = 0; j < 2; ++j) if (part < 0 || part == j) ch_dma16(c.rsw1, c.woff1[j], so, sW + c.wq1[j] * 512);
         }
     } else {
         const unsigned cout0 = 128u * (unsigned)((pi - c.np1) * c.w2);
         if (kt < c.nh2 && !(dbg & 8)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ch_dma16(c.rsh2, c.offh2[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
+            for (int i = 0; i < 2; ++i) if (part < 0 || part == i) ch_dma16(c.rsh2, c.offh2[i], 128u * (unsigned)kt, sP + (wave * 2 + i) * 512);
         }
         unsigned so = 2u * (cout0 * c.k2pad + 64u * (unsigned)kt);
         if (dbg & 32) so = 128u * ((unsigned)kt * 128u * (unsigned)(c.np2 * c.w2) + cout0);
         if (dbg & 16) {
         } else if (c.w2 == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + c.wq2[j] * 512);
+            for (int j = 0; j < 4; ++j) if (part < 0 || part == j) ch_dma16(c.rsw2, c.woff2[j], so, sW + c.wq2[j] * 512);
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ch_dma16(c.rsw2, c.woff2[j], so, sW + c.wq2[j] * 512);
+            for (int j = 0; j < 2; ++j) if (part < 0 || part == j) ch_dma16(c.rsw2, c.woff2[j], so, sW + c.wq2[j] * 512);
         }
     }
 }
@@ -172,7 +173,10 @@ __device__ __forceinline__ void chain_pass(half_t* smem, const ChCtx& c, const C
         __builtin_amdgcn_s_barrier();  // K-step g landed for every wave; every wave is done with the other stage
         half8 wreg[4];
         const bool wr = (p.dbg & 64) && kt + 1 < nk;  // timing experiment: the next K-step's weights global -> registers -> LDS instead of LDS-DMA
-        if (!(p.dbg & 1)) {
+        const bool inter = (p.dbg & 256) != 0;  // the next K-step's DMA instructions issued BETWEEN this step's MFMA groups instead of in front of them
+        const int npi = kt + 1 < nk ? pi : pi + 1, nkt = kt + 1 < nk ? kt + 1 : 0;
+        const bool has_next = kt + 1 < nk || pi + 1 < npass;
+        if (!(p.dbg & 1) && !inter) {
             if (kt + 1 < nk) chain_issue(ring, c, pi, kt + 1, (g + 1) & 1, wave, wr ? (p.dbg | 16) : p.dbg);
             else if (pi + 1 < npass) chain_issue(ring, c, pi + 1, 0, (g + 1) & 1, wave, p.dbg);
             if (wr) {
@@ -215,6 +219,10 @@ __device__ __forceinline__ void chain_pass(half_t* smem, const ChCtx& c, const C
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks & 1][a], bfr[ks & 1][b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (inter && has_next && !(p.dbg & 1)) {
+                chain_issue(ring, c, npi, nkt, (g + 1) & 1, wave, p.dbg, ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (wr) {
 #pragma unroll
