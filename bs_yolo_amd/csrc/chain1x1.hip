@@ -50,7 +50,7 @@ struct ChainK {
     const half_t* r2;
     int ldr2;
     int M;
-    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA, 32 = weight addresses of a K-step-major layout [kt][cout][64] (timing only), 64 = weights global -> registers -> LDS instead of LDS-DMA, 128 = per-workgroup rotation of the weight row-group order (results stay right), 256 = the next K-step's DMA issued between this step's MFMA groups (results stay right)
+    int dbg;  // ablation switches for profiling (BSY_CHAIN_DBG; results are WRONG under them): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no HBM stores, 8 = no pixel DMA, 16 = no weight DMA, 32 = weight addresses of a K-step-major layout [kt][cout][64] (timing only), 64 = weights global -> registers -> LDS instead of LDS-DMA, 128 = NO per-workgroup rotation of the weight row-group order (results stay right), 256 = the next K-step's DMA issued between this step's MFMA groups (results stay right)
 };
 
 namespace {
@@ -326,11 +326,10 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChainK p) {
         c.offa1[i] = v ? 2u * (unsigned)m * (unsigned)p.lda1 + 16u * (unsigned)kc[i] : CH_OOB;
         c.offh2[i] = v ? 2u * (unsigned)m * (unsigned)p.ldh2 + 16u * (unsigned)kc[i] : CH_OOB;
     }
-#pragma unroll
     // 8-row group q of a pass (16 x width groups) is fetched by instruction j of wave (q - rot) / WIW: rot rotates the assignment per
-    // workgroup (dbg & 128), so that the CUs of an XCD -- which all want the same weight lines in the same K-step -- ask for them in
+    // workgroup (dbg & 128 switches it off), so that the CUs of an XCD -- which all want the same weight lines in the same K-step -- ask for them in
     // different orders.  q & 1 = parity of the group (the swizzle's odd / even instruction form).
-    const int rot = (p.dbg & 128) ? (int)((blockIdx.x >> 3) * 5u) : 0;
+    const int rot = (p.dbg & 128) ? 0 : (int)((blockIdx.x >> 3) * 5u);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q1 = (wave * 2 * c.w1 + j + rot) % (16 * c.w1), q2 = (wave * 2 * c.w2 + j + rot) % (16 * c.w2);

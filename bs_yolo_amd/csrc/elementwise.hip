@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(half_t* __restrict__
             A[it] = m;
             *reinterpret_cast<half8*>(base + (size_t)i * ld + pass * C + ck * 8) = m;
         }
-        __syncthreads();
+        lds_barrier();  // orders the LDS maps only: this pass's global stores stay in flight under the next pass (__syncthreads() drained them)
     }
 }
 
