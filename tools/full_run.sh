@@ -4,6 +4,9 @@
 # usage: tools/full_run.sh <tag>
 tag=$1; nfam=${2:-0}  # 0: the PMC scripts read the family's launch count from their own bench run
 mkdir -p gpurun_out
+# the library must be the one the sources build (objects and their signatures travel with the snapshot: a no-op when up to date, loud when a source does not compile)
+python -m bs_yolo_amd.build > gpurun_out/${tag}_build.log 2>&1 || { echo "BUILD FAILED"; tail -20 gpurun_out/${tag}_build.log; exit 1; }
+tail -1 gpurun_out/${tag}_build.log | cut -c1-120
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${tag}_tests.log 2>&1; rc=$?
 tail -4 gpurun_out/${tag}_tests.log
 if [ $rc -gt 1 ]; then echo "tests rc=$rc: stopping"; exit $rc; fi
