@@ -73,6 +73,32 @@ def _signature(cmd, src: Path, headers) -> str:
     return h.hexdigest()
 
 
+def stale_sources() -> list:
+    """Sources of SOURCES whose object file was NOT built from their current text (or from the current flags / headers): the in-tree
+    library then is not the one the tree describes.  Empty when the objects directory does not travel with the library (nothing to
+    compare) or everything is up to date.  bs_yolo_amd/lib.py refuses a stale library at import: a source that no longer compiles
+    otherwise leaves yesterday's .so in place and every test and measurement silently runs it (round 4: two experiments did)."""
+    objdir = CSRC / "build"
+    if not objdir.is_dir() or not LIB.exists():
+        return []
+    headers = sorted(CSRC.glob("*.h")) + sorted((PKG.parent / "include").glob("*.h"))
+    try:
+        hipcc = _hipcc()
+    except RuntimeError:
+        return []
+    out = []
+    for src, extra in SOURCES.items():
+        if not (CSRC / src).exists():
+            out.append(src)
+            continue
+        stamp = objdir / (src.rsplit(".", 1)[0] + ".sig")
+        obj = stamp.with_suffix(".o")
+        sig = _signature([hipcc, ARCH, *COMMON, *extra, src], CSRC / src, headers)
+        if not stamp.exists() or not obj.exists() or stamp.read_text() != sig or obj.stat().st_mtime > LIB.stat().st_mtime + 1:
+            out.append(src)
+    return out
+
+
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)

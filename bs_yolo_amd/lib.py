@@ -72,6 +72,12 @@ def _load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m bs_yolo_amd.build` (hipcc, gfx950). "
             "bs_yolo_amd has no CPU fallback.")
+    if not os.environ.get("BSY_LIB") and os.environ.get("BSY_ALLOW_STALE_LIB") != "1":
+        from .build import stale_sources
+        stale = stale_sources()
+        if stale:
+            raise ImportError(f"{LIB_PATH} was not built from the current sources ({', '.join(stale)} changed or failed to compile): run "
+                              "`python -m bs_yolo_amd.build` (BSY_ALLOW_STALE_LIB=1 loads it anyway)")
     lib = C.CDLL(str(LIB_PATH))
     missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:

@@ -815,6 +815,23 @@ def test_build_signature_tracks_flags_and_headers(tmp_path):
     assert "image_conv.h" in hdrs and "common.h" in hdrs
 
 
+def test_stale_library_is_refused(monkeypatch):
+    """bs_yolo_amd.lib refuses an in-tree library that was not built from the current sources (bs_yolo_amd/build.py stale_sources: object
+    signatures = flags + source + every header): a source that stops compiling must not leave every test running yesterday's .so."""
+    import importlib
+    import bs_yolo_amd.build as BLD
+    assert BLD.stale_sources() == []          # the tree the tests run on is up to date
+    real = BLD._signature
+    monkeypatch.setattr(BLD, "_signature", lambda cmd, src, headers: real(cmd, src, headers) + ("x" if src.name == "nms.hip" else ""))
+    assert BLD.stale_sources() == ["nms.hip"]
+    import bs_yolo_amd.lib as LL
+    with pytest.raises(ImportError, match="not built from the current sources"):
+        LL._load()
+    monkeypatch.setenv("BSY_ALLOW_STALE_LIB", "1")
+    assert LL._load() is not None
+    importlib.reload(BLD)
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (it exited asking for
     torch.distributed.run).  Without a GPU every rank stops at bench.py's own "needs a ROCm GPU" check -- which proves that
