@@ -82,20 +82,28 @@ def stale_sources() -> list:
     if not objdir.is_dir() or not LIB.exists():
         return []
     headers = sorted(CSRC.glob("*.h")) + sorted((PKG.parent / "include").glob("*.h"))
+    # the compiler's path is part of a signature; the box that loads the library may name it differently than the one that built it
+    compilers = {"/opt/rocm/bin/hipcc", "hipcc"}
     try:
-        hipcc = _hipcc()
+        compilers.add(_hipcc())
     except RuntimeError:
-        return []
+        pass
     out = []
-    for src, extra in SOURCES.items():
-        if not (CSRC / src).exists():
-            out.append(src)
-            continue
-        stamp = objdir / (src.rsplit(".", 1)[0] + ".sig")
-        obj = stamp.with_suffix(".o")
-        sig = _signature([hipcc, ARCH, *COMMON, *extra, src], CSRC / src, headers)
-        if not stamp.exists() or not obj.exists() or stamp.read_text() != sig:  # (build_library removes the stamp before it compiles)
-            out.append(src)
+    try:
+        for src, extra in SOURCES.items():
+            if not (CSRC / src).exists():
+                out.append(src)
+                continue
+            stamp = objdir / (src.rsplit(".", 1)[0] + ".sig")
+            obj = stamp.with_suffix(".o")
+            if not stamp.exists() or not obj.exists():  # (build_library removes the stamp before it compiles)
+                out.append(src)
+                continue
+            have = stamp.read_text()
+            if not any(have == _signature([cc, ARCH, *COMMON, *extra, src], CSRC / src, headers) for cc in compilers):
+                out.append(src)
+    except OSError:
+        return []  # the guard must never be the reason an intact library does not load
     return out
 
 
