@@ -79,8 +79,8 @@ def stale_sources() -> list:
     compare) or everything is up to date.  bs_yolo_amd/lib.py refuses a stale library at import: a source that no longer compiles
     otherwise leaves yesterday's .so in place and every test and measurement silently runs it (round 4: two experiments did)."""
     objdir = CSRC / "build"
-    if not objdir.is_dir() or not LIB.exists():
-        return []
+    if not objdir.is_dir() or not LIB.exists() or not any(objdir.glob("*.sig")):
+        return []  # (no signature travelled with the library: nothing to compare)
     headers = sorted(CSRC.glob("*.h")) + sorted((PKG.parent / "include").glob("*.h"))
     # the compiler's path is part of a signature; the box that loads the library may name it differently than the one that built it
     compilers = {"/opt/rocm/bin/hipcc", "hipcc"}
