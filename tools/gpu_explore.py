@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU-box exploration: per-layer error of the engine vs the oracle, per-op timings, quick throughput number."""
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -136,5 +137,5 @@ if __name__ == "__main__":
         for tag in (sys.argv[2:] or ["yolo11n_detect", "yolo11s_detect"]):
             per_layer(tag)
     if what in ("time", "all"):
-        timing("s", int(sys.argv[2]) if len(sys.argv) > 2 else 64, 640, family=sys.argv[3] if len(sys.argv) > 3 else "yolo11",
+        timing(os.environ.get("BSY_EXPLORE_SCALE", "s"), int(sys.argv[2]) if len(sys.argv) > 2 else 64, 640, family=sys.argv[3] if len(sys.argv) > 3 else "yolo11",
                precision=sys.argv[4] if len(sys.argv) > 4 else "fp16")
