@@ -10,16 +10,26 @@
 //   * PSABlock.ffn[1] (+ shortcut) -> C2PSA.cv2 (block.py:4382, :4467): likewise, with the shortcut operand added in the first epilogue.
 //
 // One workgroup = 128 pixels, 8 waves (4 along cout x 2 along pixels, wave tile 64 couts x 64 pixels), one workgroup per CU:
-//   stage 1: for every 256- (or 128-) cout pass: K loop over the HBM sources (pixels + weights staged by LDS-DMA, 64-deep K-steps,
-//            two ring stages: conv_mfma.hip's ALIGNED BK-64 form) -> SiLU -> f16 -> optional HBM store through an LDS staging tile
-//            (coalesced 16-byte pieces) + the kept channel range parked in the RESIDENT tile, laid out as K-step pixel blocks
-//            [block][128 px][64 ch] with the ring's XOR swizzle, so that stage 2 reads its B fragments from it exactly as from a ring stage;
+//   stage 1: for every 256- (or 128-) cout pass: K loop over the HBM sources (pixels + weights staged by LDS-DMA, 64-deep K-steps:
+//            conv_mfma.hip's ALIGNED BK-64 form) -> SiLU -> f16 -> optional HBM store + the kept channel range parked in the RESIDENT
+//            tile, laid out as K-step pixel blocks [block][128 px][64 ch] with the ring's XOR swizzle, so that stage 2 reads its B
+//            fragments from it exactly as from a ring stage;
 //   stage 2: per cout pass: K loop = HBM part (ring) then resident blocks (weights only through the ring) -> epilogue -> HBM.
+// ONE continuous stream of K-steps runs through the two ring stages across pass boundaries (global step g -> stage g & 1): the next
+// pass's first K-step is fetched under this pass's last K-step and its epilogue.  A pass's output leaves through a staging tile that
+// aliases only the ring stage the pass consumed last, 64 pixel rows at a time, as 16-byte descriptor stores that are ALWAYS issued (rows
+// past M: out of range = dropped), so that every thread has a compile-time number of stores in flight and the next pass's first wait can
+// be a counted vmcnt that lets them fly on.  Which 8-row group of a K-step's weights each DMA instruction fetches is rotated per
+// workgroup: this kernel's workgroups march in lockstep over the same weight lines, and asking for them in different orders is worth
+// 4-9 % (docs/experiments.md section 0.5).
 // Every accumulator starts at the bias and takes its products in ascending k, 16 at a time, through v_mfma_f32_32x32x16_f16 -- the K walk
 // (order 0) of the un-fused 1x1 launches; activations are rounded to f16 where the un-fused pair stores them, the shortcut is added to
 // the ROUNDED value in f32 and rounded again (conv_mfma.hip conv_epilogue_lds): the same bits (tests/test_gpu_parity.py
 // test_engine_chain_fusion_is_bit_identical).
-// LDS: ring 2 x (128 + 256) x 64 halves = 96 KiB (staging tile aliases it between passes) + resident tile <= 256 ch x 128 px = 64 KiB.
+// LDS: ring 2 x (128 + 256) x 64 halves = 96 KiB + resident tile <= 256 ch x 128 px = 64 KiB = all 160 KiB.
+// MEASURED (YOLO11s, 64 images): 10-25 % SLOWER than the pairs it replaces -- the kernel is its operand stream (36-40 GB/s per CU; the
+// MFMAs hide under it completely) and a 128-pixel tile stages 11.7 KB per MFLOP against 7.8 for the pairs' 256 x 256 tiles.  Opt-in
+// (bs_yolo_amd/plan.py fuse_chain / BSY_FUSE_CHAIN=1); BSY_CHAIN_DBG holds the ablation switches behind those numbers.
 #include <stdlib.h>
 
 #include "common.h"
